@@ -1,0 +1,104 @@
+/*
+ * esac_oracle.h -- CPU oracle for the ESAC hypothesis/inlier hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under esac_amd/ (the product) may include,
+ * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (vislearn/esac, code/esac/esac.cpp) cannot be
+ * built in this image (needs OpenCV 3.4.2: opencv_core, opencv_calib3d) and it
+ * ships no tests or golden vectors.  This file restates
+ *   - the reference's own control flow (esac.cpp:64-190, esac_util.h) line by
+ *     line, and
+ *   - the OpenCV routines it calls (solvePnP P3P / ITERATIVE, projectPoints,
+ *     Rodrigues, Mat::inv) from their published algorithms, FROM MEMORY.
+ * See oracle/README.md for the list of known deviations.
+ */
+#ifndef ESAC_ORACLE_H
+#define ESAC_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESAC_ORACLE_MAX_REF_STEPS 100   /* esac.cpp:45  MAX_REF_STEPS */
+#define ESAC_ORACLE_MAX_TRIES 1000000   /* esac.cpp:44  MAX_SAMPLING_TRIES */
+
+/* RNG modes. 0 = counter-based Philox4x32-10 keyed (seed, call, hyp, try, block):
+ * shared with the HIP path so both draw identical minimal sets.
+ * 1 = sequential callback stream (used to replay the reference's single-thread
+ * mt19937 stream when validating against oracle/_ref). */
+#define ESAC_RNG_PHILOX 0
+#define ESAC_RNG_CALLBACK 1
+
+typedef int (*esac_oracle_irand_fn)(int lo_incl, int hi_excl, void* user);
+
+typedef struct esac_oracle_args {
+    /* inputs (esac.cpp:64-77) */
+    const float* scene_coords;   /* [E,3,H,W], element strides below            */
+    int64_t sc_stride[4];
+    int E, H, W;
+    const int64_t* hyp_assign;   /* [N], element stride below (0 = expand())    */
+    int64_t assign_stride;
+    int N;
+    int shift_x, shift_y;
+    float focal, ppx, ppy;
+    float inlier_thresh, inlier_alpha, inlier_beta, max_reproj;
+    int sub_sampling;
+    /* RNG key */
+    uint64_t seed, call;
+    int rng_mode;
+    esac_oracle_irand_fn irand_cb;
+    void* irand_user;
+    /* limits (reference constants by default) */
+    int max_tries;        /* <=0 -> ESAC_ORACLE_MAX_TRIES     */
+    int max_ref_steps;    /* <0  -> ESAC_ORACLE_MAX_REF_STEPS */
+    int num_threads;      /* <=0 -> omp default               */
+    /* outputs (any may be NULL) */
+    float*   out_pose;        /* [16] row-major 4x4, esac.cpp:182-187           */
+    int32_t* out_sample_xy;   /* [N,4,2] sampled cells (x,y)                    */
+    int32_t* out_tries;       /* [N] accepted try index, -1 if budget exhausted */
+    double*  out_hyps;        /* [N,6] rvec,tvec before refinement              */
+    double*  out_scores;      /* [N]                                            */
+    double*  out_probs;       /* [N] softmax                                    */
+    double*  out_entropy;     /* [1]                                            */
+    int32_t* out_winner;      /* [1] hypothesis index                           */
+    double*  out_refined;     /* [6] rvec,tvec after refinement                 */
+    int32_t* out_ref_steps;   /* [1] number of accepted refinement re-fits      */
+    int32_t* out_inlier_counts; /* [max_ref_steps+1] inlier count seen at each step */
+    uint8_t* out_inlier_map;  /* [H*W] row-major (y,x), last accepted inlier set */
+    float*   out_winner_errs; /* [H*W] reprojection error image of the winner (pre-refinement) */
+    double*  out_phase_ms;    /* [4] sampling, scoring, selection, refinement   */
+} esac_oracle_args;
+
+/* returns winning expert (>=0) or <0 on argument error */
+int esac_oracle_forward(esac_oracle_args* a);
+
+/* ---- building blocks exported for known-answer tests ---- */
+void esac_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void esac_oracle_draw_cells(uint64_t seed, uint64_t call, uint32_t hyp, uint32_t tr,
+                            int W, int H, int32_t xy[8]);
+/* obj: 4x3 doubles, img: 4x2 doubles (pixels). returns 1 on success */
+int  esac_oracle_p3p(const double* obj, const double* img, double fx, double fy,
+                     double cx, double cy, double rvec[3], double tvec[3]);
+/* all solutions from the first 3 points; R [4][9], t [4][3]; returns count */
+int  esac_oracle_p3p_all(const double* obj3, const double* img3, double fx, double fy,
+                         double cx, double cy, double* R, double* t);
+int  esac_oracle_solve_deg4(double a, double b, double c, double d, double e, double roots[4]);
+void esac_oracle_rodrigues_vec2mat(const double r[3], double R[9], double dRdr[27]);
+void esac_oracle_rodrigues_mat2vec(const double R[9], double r[3]);
+void esac_oracle_project(const double rvec[3], const double tvec[3], double fx, double fy,
+                         double cx, double cy, const float* pts3, int n, float* uv);
+/* LM refit (cv::solvePnP ITERATIVE, useExtrinsicGuess=true). pose in/out (rvec,tvec).
+ * returns number of outer LM iterations */
+int  esac_oracle_lm_pnp(const float* obj, const float* img, int n, double fx, double fy,
+                        double cx, double cy, double pose[6]);
+void esac_oracle_pose2trans(const double pose[6], double T[16]);
+int  esac_oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

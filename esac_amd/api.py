@@ -1,0 +1,295 @@
+"""Host-side mirror of the reference's `esac` extension interface over the C ABI.
+
+Reference: `PYBIND11_MODULE(..)  m.def("forward", &esac_forward); m.def("backward", &esac_backward)`
+(code/esac/esac.cpp:513-516); call site test_esac.py:192-205.  `forward` below keeps
+the positional signature, the in-place `outPose` write and the Python-int return
+value; every failure the reference surfaces as a pybind11 `RuntimeError`
+(c10::Error from `accessor<>()`, cv::Exception) is a `RuntimeError` here too.
+
+The compute runs ONLY in libesac_hip.so (hand-written HIP for gfx950).  There is
+no CPU fallback: without the library or without a HIP device the call raises.
+torch is used for device memory, streams and (in distributed.py) RCCL -- never
+for the arithmetic of this path.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import torch
+
+from . import build as _build
+
+# ---------------------------------------------------------------- C ABI binding
+RES_SCORE, RES_HYP, RES_EXPERT, RES_RVEC, RES_TVEC, RES_POSE = 0, 1, 2, 3, 6, 9
+RES_REF_STEPS, RES_INLIERS, RES_PROB, RES_ENTROPY, RES_CONTENDERS, RES_LM_ITERS, RES_DOUBLES = 25, 26, 27, 28, 29, 30, 32
+BUF_HYPS, BUF_SAMPLE_XY, BUF_TRIES, BUF_SCORES, BUF_RESULT = 0, 1, 2, 3, 4
+BUF_INLIER_MAP, BUF_INLIER_COUNTS, BUF_WINNER_ERRS, BUF_EXACT_FLAGS = 5, 6, 7, 8
+MAX_REF_STEPS = 100
+
+ABI_SYMBOLS = [
+    "esac_hip_abi_version", "esac_hip_last_error", "esac_hip_device_count", "esac_hip_create", "esac_hip_destroy",
+    "esac_hip_forward", "esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine",
+    "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
+]
+
+
+class Params(C.Structure):
+    """struct esac_hip_params (include/esac_hip.h)."""
+    _fields_ = [
+        ("E", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("N", C.c_int32),
+        ("shift_x", C.c_int32), ("shift_y", C.c_int32),
+        ("focal", C.c_float), ("ppx", C.c_float), ("ppy", C.c_float),
+        ("inlier_thresh", C.c_float), ("inlier_alpha", C.c_float), ("inlier_beta", C.c_float),
+        ("max_reproj", C.c_float), ("sub_sampling", C.c_int32),
+        ("seed", C.c_uint64), ("call", C.c_uint64),
+        ("max_tries", C.c_int32), ("max_ref_steps", C.c_int32), ("hyp_offset", C.c_int32),
+        ("rescore_margin", C.c_float),
+        ("d_hyp_index", C.c_void_p),
+    ]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library():
+    """dlopen libesac_hip.so (built in-tree by esac_amd.build / __graft_entry__.build)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "esac: HIP extension %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path." % path)
+        lib = C.CDLL(path)
+        vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+        pp = C.POINTER(Params)
+        lib.esac_hip_abi_version.restype = i32
+        lib.esac_hip_last_error.restype = C.c_char_p
+        lib.esac_hip_device_count.restype = i32
+        lib.esac_hip_create.argtypes = [C.POINTER(vp), i32]
+        lib.esac_hip_destroy.argtypes = [vp]
+        lib.esac_hip_forward.argtypes = [vp, vp, vp, pp, vp, vp, vp, vp]
+        for name in ("esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine", "esac_hip_score_exact"):
+            getattr(lib, name).argtypes = [vp, vp, vp, pp, vp]
+        lib.esac_hip_read.argtypes = [vp, i32, vp, C.c_size_t]
+        lib.esac_hip_write_hyps.argtypes = [vp, vp, i32]
+        lib.esac_hip_phase_ms.argtypes = [vp, vp]
+        lib.esac_hip_set_timing.argtypes = [vp, i32]
+        for name in ABI_SYMBOLS:
+            if name not in ("esac_hip_last_error",):
+                getattr(lib, name).restype = i32
+        lib.esac_hip_last_error.restype = C.c_char_p
+        if lib.esac_hip_abi_version() != 1:
+            raise RuntimeError("esac: libesac_hip.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def _check(rc, lib):
+    if rc != 0:
+        raise RuntimeError("esac (HIP): %s [status %d]" % (lib.esac_hip_last_error().decode(), rc))
+
+
+class Engine:
+    """One device context (esac_hip_ctx): workspaces + stage entry points for one GPU."""
+
+    def __init__(self, device=None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("esac: no HIP device visible (torch.cuda.is_available() is False); "
+                               "the MI355X path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.ctx = C.c_void_p()
+        _check(self.lib.esac_hip_create(C.byref(self.ctx), self.device.index), self.lib)
+        self._shape = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.esac_hip_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    # -- helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def make_params(self, E, H, W, N, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
+                    inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0,
+                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0):
+        p = Params()
+        p.E, p.H, p.W, p.N = int(E), int(H), int(W), int(N)
+        p.shift_x, p.shift_y = int(shift_x), int(shift_y)
+        p.focal, p.ppx, p.ppy = float(focal), float(ppx), float(ppy)
+        p.inlier_thresh, p.inlier_alpha, p.inlier_beta = float(inlier_thresh), float(inlier_alpha), float(inlier_beta)
+        p.max_reproj, p.sub_sampling = float(max_reproj), int(sub_sampling)
+        p.seed, p.call = int(seed) & (2**64 - 1), int(call) & (2**64 - 1)
+        p.max_tries, p.max_ref_steps, p.hyp_offset = int(max_tries), int(max_ref_steps), int(hyp_offset)
+        p.rescore_margin = float(rescore_margin)
+        p.d_hyp_index = None
+        self._shape = (int(N), int(H), int(W))
+        return p
+
+    def set_hyp_index(self, params, index_tensor):
+        """Global hypothesis indices (device int32 [N]) for shards that are not a contiguous range."""
+        assert index_tensor.is_cuda and index_tensor.dtype == torch.int32 and index_tensor.is_contiguous()
+        params.d_hyp_index = index_tensor.data_ptr()
+        self._keep_idx = index_tensor
+
+    def _dev_inputs(self, scene_coords, hyp_assign):
+        sc = scene_coords if scene_coords.is_cuda else scene_coords.to(self.device, non_blocking=True)
+        ha = hyp_assign if hyp_assign.is_cuda else hyp_assign.to(self.device, non_blocking=True)
+        # accessor<> honours strides (incl. the stride-0 expand() of test_esac.py:171-173); the kernels want dense
+        return sc.contiguous(), ha.contiguous()
+
+    # -- whole path
+    def forward_device(self, scene_coords, hyp_assign, params, scores_out=None, result_out=None, want_host=True):
+        """scene_coords [E,3,H,W] f32 / hyp_assign [N] i64 on this device. Returns host result (np.float64[32]) or None."""
+        sc, ha = self._dev_inputs(scene_coords, hyp_assign)
+        host = np.zeros(RES_DOUBLES, np.float64) if want_host else None
+        with torch.cuda.device(self.device):
+            _check(self.lib.esac_hip_forward(
+                self.ctx, sc.data_ptr(), ha.data_ptr(), C.byref(params), self._stream(),
+                scores_out.data_ptr() if scores_out is not None else None,
+                result_out.data_ptr() if result_out is not None else None,
+                host.ctypes.data_as(C.c_void_p) if want_host else None), self.lib)
+        self._keep = (sc, ha)  # keep inputs alive until the (possibly asynchronous) kernels have run
+        return host
+
+    # -- single phases (stage-wise parity tests)
+    def _phase(self, fn, scene_coords, hyp_assign, params):
+        sc, ha = self._dev_inputs(scene_coords, hyp_assign)
+        with torch.cuda.device(self.device):
+            _check(fn(self.ctx, sc.data_ptr(), ha.data_ptr(), C.byref(params), self._stream()), self.lib)
+        self._keep = (sc, ha)
+
+    def sample(self, sc, ha, p):
+        self._phase(self.lib.esac_hip_sample, sc, ha, p)
+
+    def score(self, sc, ha, p):
+        self._phase(self.lib.esac_hip_score, sc, ha, p)
+
+    def select(self, sc, ha, p):
+        self._phase(self.lib.esac_hip_select, sc, ha, p)
+
+    def refine(self, sc, ha, p):
+        self._phase(self.lib.esac_hip_refine, sc, ha, p)
+
+    def score_exact(self, sc, ha, p):
+        self._phase(self.lib.esac_hip_score_exact, sc, ha, p)
+
+    def write_hyps(self, hyps):
+        h = np.ascontiguousarray(hyps, np.float64)
+        assert h.ndim == 2 and h.shape[1] == 6
+        _check(self.lib.esac_hip_write_hyps(self.ctx, h.ctypes.data_as(C.c_void_p), h.shape[0]), self.lib)
+
+    def read(self, which):
+        N, H, W = self._shape
+        shapes = {
+            BUF_HYPS: ((N, 6), np.float64), BUF_SAMPLE_XY: ((N, 4, 2), np.int32), BUF_TRIES: ((N,), np.int32),
+            BUF_SCORES: ((N,), np.float64), BUF_RESULT: ((RES_DOUBLES,), np.float64),
+            BUF_INLIER_MAP: ((H, W), np.uint8), BUF_INLIER_COUNTS: ((MAX_REF_STEPS + 1,), np.int32),
+            BUF_WINNER_ERRS: ((H, W), np.float32), BUF_EXACT_FLAGS: ((N,), np.uint8),
+        }
+        shape, dt = shapes[which]
+        out = np.zeros(shape, dt)
+        _check(self.lib.esac_hip_read(self.ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes), self.lib)
+        return out
+
+    def set_timing(self, on):
+        _check(self.lib.esac_hip_set_timing(self.ctx, 1 if on else 0), self.lib)
+
+    def phase_ms(self):
+        out = np.zeros(5, np.float32)
+        _check(self.lib.esac_hip_phase_ms(self.ctx, out.ctypes.data_as(C.c_void_p)), self.lib)
+        return out
+
+
+# ---------------------------------------------------------------- module-level state
+# The reference keeps a static RNG whose state advances from call to call
+# (thread_rand.cpp:4-5); here that state is (seed, call counter).
+_state = {"seed": 1305, "call": 0, "engines": {}, "last": None, "max_tries": 0, "max_ref_steps": -1}
+
+
+def set_seed(seed, call=0):
+    """ThreadRand::forceInit equivalent (thread_rand.cpp:7-11; not exported by the reference)."""
+    _state["seed"], _state["call"] = int(seed), int(call)
+
+
+def get_rng_state():
+    return _state["seed"], _state["call"]
+
+
+def set_limits(max_tries=0, max_ref_steps=-1):
+    """Override MAX_SAMPLING_TRIES / MAX_REF_STEPS (esac.cpp:44-45); 0 / -1 restore the reference values."""
+    _state["max_tries"], _state["max_ref_steps"] = int(max_tries), int(max_ref_steps)
+
+
+def engine(device=None):
+    idx = torch.cuda.current_device() if device is None else int(device)
+    eng = _state["engines"].get(idx)
+    if eng is None:
+        eng = _state["engines"][idx] = Engine(idx)
+    return eng
+
+
+def last_result():
+    """Details of the most recent forward(): scores tensor (device, float64 [N]) and the result record."""
+    return _state["last"]
+
+
+def _validate(sceneCoordinates, hypAssignment, outPose):
+    # what accessor<float,4>() / accessor<long,1>() / accessor<float,2>() enforce (esac.cpp:80-84,184)
+    for name, t, dt, nd in (("sceneCoordinates", sceneCoordinates, torch.float32, 4),
+                            ("hypAssignment", hypAssignment, torch.int64, 1), ("outPose", outPose, torch.float32, 2)):
+        if not isinstance(t, torch.Tensor):
+            raise RuntimeError("esac.forward: %s must be a torch.Tensor" % name)
+        if t.dtype != dt:
+            raise RuntimeError("esac.forward: expected scalar type %s for %s but found %s" % (dt, name, t.dtype))
+        if t.dim() != nd:
+            raise RuntimeError("esac.forward: expected %d dims for %s but tensor has %d" % (nd, name, t.dim()))
+    if sceneCoordinates.size(1) != 3:
+        raise RuntimeError("esac.forward: sceneCoordinates must be [E,3,H,W]")
+    if tuple(outPose.shape) != (4, 4):
+        raise RuntimeError("esac.forward: outPose must be [4,4]")
+    if hypAssignment.numel() == 0:
+        raise RuntimeError("esac.forward: hypAssignment is empty")
+
+
+def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLength, ppointX, ppointY,
+            inlierThreshold, inlierAlpha, inlierBeta, maxReproj, subSampling):
+    """Drop-in for `esac.forward` (esac.cpp:64-77): estimates the pose, writes the 4x4 camera
+    transform into `outPose` in place and returns the winning expert as a Python int.
+
+    Tensors may live on the CPU (as the reference requires) or already on the GPU
+    (then the `.cpu()` at test_esac.py:187 can be dropped)."""
+    _validate(sceneCoordinates, hypAssignment, outPose)
+    dev = sceneCoordinates.device.index if sceneCoordinates.is_cuda else None
+    eng = engine(dev)
+    E, _, H, W = sceneCoordinates.shape
+    N = hypAssignment.shape[0]
+    ha_host_check = hypAssignment if not hypAssignment.is_cuda else None
+    if ha_host_check is not None:
+        lo, hi = int(ha_host_check.min()), int(ha_host_check.max())
+        if lo < 0 or hi >= E:
+            raise RuntimeError("esac.forward: hypAssignment values must lie in [0,%d), found [%d,%d]" % (E, lo, hi))
+    p = eng.make_params(E, H, W, N, shiftX, shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha,
+                        inlierBeta, maxReproj, subSampling, seed=_state["seed"], call=_state["call"],
+                        max_tries=_state["max_tries"], max_ref_steps=_state["max_ref_steps"])
+    _state["call"] += 1
+    scores = torch.empty(N, dtype=torch.float64, device=eng.device)
+    res = eng.forward_device(sceneCoordinates, hypAssignment, p, scores_out=scores)
+    pose = torch.from_numpy(res[RES_POSE:RES_POSE + 16].astype(np.float32).reshape(4, 4))
+    outPose.copy_(pose)  # in place, caller-owned (esac.cpp:184-187)
+    _state["last"] = {"scores": scores, "result": res, "winner": int(res[RES_HYP]), "expert": int(res[RES_EXPERT])}
+    return int(res[RES_EXPERT])
+
+
+def backward(*args, **kwargs):
+    """`esac.backward` (esac.cpp:213-230) -- training path, SURVEY.md row f1: not built yet."""
+    raise NotImplementedError("esac.backward (esac.cpp:213-511) is scheduled after the forward hot path (SURVEY.md 8 f1)")

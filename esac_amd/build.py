@@ -1,0 +1,48 @@
+"""In-tree build of the HIP extension (libesac_hip.so) for gfx950.
+
+`hipcc --offload-arch=gfx950` cross-compiles without a GPU.  The shared object
+is written next to this file so that it travels with the source tree (it is
+git-ignored, not gpurun-ignored).
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libesac_hip.so")
+SOURCES = ["esac_kernels.hip", "esac_capi.hip"]
+HEADERS = ["esac_kernels.hpp", "pose_math.hpp", "rng.hpp", os.path.join("..", "..", "include", "esac_hip.h")]
+# -ffp-contract=off: the fp64 "exact" kernels follow IEEE op-by-op like the CPU
+# code they are compared with; the fp32 streaming kernel asks for FMAs explicitly.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libesac_hip.so")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_hip(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

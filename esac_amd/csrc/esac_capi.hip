@@ -1,0 +1,296 @@
+// esac_capi.hip -- C ABI (include/esac_hip.h) over the HIP kernels.
+// Host side of the drop-in boundary: argument validation with the reference's
+// failure convention (everything that would have thrown c10::Error / cv::Exception
+// through pybind11 becomes a negative status + message), workspace ownership,
+// kernel launches on the caller's stream, optional per-phase hipEvent timers
+// (the StopWatch prints of esac.cpp:124,149,161,179).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/esac_hip.h"
+#include "esac_kernels.hpp"
+
+using namespace esac;
+
+static_assert(ESAC_RES_SCORE == ESAC_RES_SCORE_K && ESAC_RES_HYP == ESAC_RES_HYP_K && ESAC_RES_EXPERT == ESAC_RES_EXPERT_K &&
+                  ESAC_RES_RVEC == ESAC_RES_RVEC_K && ESAC_RES_POSE == ESAC_RES_POSE_K &&
+                  ESAC_RES_REF_STEPS == ESAC_RES_REF_STEPS_K && ESAC_RES_INLIERS == ESAC_RES_INLIERS_K &&
+                  ESAC_RES_PROB == ESAC_RES_PROB_K && ESAC_RES_ENTROPY == ESAC_RES_ENTROPY_K &&
+                  ESAC_RES_CONTENDERS == ESAC_RES_CONTENDERS_K && ESAC_RES_LM_ITERS == ESAC_RES_LM_ITERS_K &&
+                  ESAC_MAX_REF_STEPS == ESAC_MAX_REF_STEPS_K,
+              "result layout drifted between include/esac_hip.h and esac_kernels.hpp");
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_OK(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail(-100 - (int)_e, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+struct esac_hip_ctx {
+    int device = 0;
+    int capN = 0, capP = 0;
+    KArgs ws{};  // only the workspace pointers are kept here
+    int lastN = 0, lastH = 0, lastW = 0;
+    bool timing = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};
+
+extern "C" int esac_hip_abi_version(void) { return ESAC_HIP_ABI_VERSION; }
+extern "C" const char* esac_hip_last_error(void) { return g_err; }
+extern "C" int esac_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static void free_ws(esac_hip_ctx* c) {
+    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.fast_scores,
+                    c->ws.scores,     c->ws.exact_flag,   c->ws.contenders, c->ws.n_contenders, c->ws.stats,
+                    c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->ws = KArgs{};
+    c->capN = c->capP = 0;
+}
+
+extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
+    if (!out) return fail(-1, "esac_hip_create: null ctx pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(-2, "esac_hip_create: no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(-3, "esac_hip_create: device %d out of range [0,%d)", device, n);
+    HIP_OK(hipSetDevice(device));
+    esac_hip_ctx* c = new esac_hip_ctx();
+    c->device = device;
+    for (auto& ev : c->ev) HIP_OK(hipEventCreate(&ev));
+    *out = c;
+    return 0;
+}
+
+extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    free_ws(c);
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    delete c;
+    return 0;
+}
+
+template <typename T>
+static int alloc(T** p, size_t n) {
+    HIP_OK(hipMalloc((void**)p, n * sizeof(T)));
+    return 0;
+}
+
+static int ensure_ws(esac_hip_ctx* c, int N, int P) {
+    if (N <= c->capN && P <= c->capP) return 0;
+    HIP_OK(hipDeviceSynchronize());
+    const int nN = N > c->capN ? N : c->capN, nP = P > c->capP ? P : c->capP;
+    free_ws(c);
+    int rc = 0;
+    rc |= alloc(&c->ws.hyps, (size_t)nN * 6);
+    rc |= alloc(&c->ws.rt32, (size_t)nN * 12);
+    rc |= alloc(&c->ws.sample_xy, (size_t)nN * 8);
+    rc |= alloc(&c->ws.tries, (size_t)nN);
+    rc |= alloc(&c->ws.fast_scores, (size_t)nN);
+    rc |= alloc(&c->ws.scores, (size_t)nN);
+    rc |= alloc(&c->ws.exact_flag, (size_t)nN);
+    rc |= alloc(&c->ws.contenders, (size_t)nN);
+    rc |= alloc(&c->ws.n_contenders, 4);
+    rc |= alloc(&c->ws.stats, 4);
+    rc |= alloc(&c->ws.errs, (size_t)nP);
+    rc |= alloc(&c->ws.inlier_map, (size_t)nP);
+    rc |= alloc(&c->ws.inlier_counts, (size_t)ESAC_MAX_REF_STEPS + 1);
+    rc |= alloc(&c->ws.result, (size_t)ESAC_RES_DOUBLES);
+    if (rc) return rc;
+    HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
+    HIP_OK(hipMemset(c->ws.result, 0, ESAC_RES_DOUBLES * sizeof(double)));
+    HIP_OK(hipMemset(c->ws.n_contenders, 0, 4 * sizeof(int)));
+    c->capN = nN;
+    c->capP = nP;
+    return 0;
+}
+
+// Validation: what the reference leaves to accessor<>() / OpenCV asserts.
+static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, KArgs* out) {
+    if (!c) return fail(-1, "null context");
+    if (!p) return fail(-1, "null params");
+    if (!d_sc || !d_assign) return fail(-1, "null scene-coordinate or assignment pointer");
+    if (p->E <= 0 || p->N <= 0) return fail(-4, "E=%d, N=%d must be positive", p->E, p->N);
+    if (p->H < 3 || p->W < 3 || (int64_t)(p->H - 1) * (p->W - 1) < 4)
+        return fail(-4, "grid %dx%d too small: 4 distinct cells must exist in [0,W-2]x[0,H-2] (esac_util.h:164-176)", p->H, p->W);
+    if ((int64_t)p->H * p->W > (int64_t)1 << 28) return fail(-4, "grid %dx%d too large", p->H, p->W);
+    if (p->sub_sampling <= 0) return fail(-4, "subSampling=%d must be positive", p->sub_sampling);
+    if (!(p->focal > 0)) return fail(-4, "focal length must be positive");
+    HIP_OK(hipSetDevice(c->device));
+    const int P = p->H * p->W;
+    int rc = ensure_ws(c, p->N, P);
+    if (rc) return rc;
+    KArgs a = c->ws;
+    a.sc = d_sc;
+    a.assign = d_assign;
+    a.E = p->E; a.H = p->H; a.W = p->W; a.N = p->N;
+    a.shift_x = p->shift_x; a.shift_y = p->shift_y; a.sub = p->sub_sampling;
+    a.focal = p->focal; a.ppx = p->ppx; a.ppy = p->ppy;
+    a.tau = p->inlier_thresh; a.alpha = p->inlier_alpha; a.beta = p->inlier_beta; a.max_reproj = p->max_reproj;
+    a.seed = p->seed; a.call = p->call;
+    a.max_tries = p->max_tries > 0 ? p->max_tries : ESAC_MAX_SAMPLING_TRIES;
+    a.max_ref_steps = p->max_ref_steps >= 0 ? (p->max_ref_steps < ESAC_MAX_REF_STEPS ? p->max_ref_steps : ESAC_MAX_REF_STEPS)
+                                            : ESAC_MAX_REF_STEPS;
+    a.hyp_offset = p->hyp_offset;
+    a.hyp_index = p->d_hyp_index;
+    a.margin = p->rescore_margin > 0 ? p->rescore_margin : fabsf(p->inlier_alpha) * ESAC_DEFAULT_MARGIN;
+    c->lastN = p->N; c->lastH = p->H; c->lastW = p->W;
+    *out = a;
+    return 0;
+}
+
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(-200 - (int)e, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+extern "C" int esac_hip_sample(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
+    KArgs a;
+    int rc = make_args(c, d_sc, d_assign, p, &a);
+    if (rc) return rc;
+    launch_sample(a, (hipStream_t)stream);
+    return check_launch("k_sample");
+}
+extern "C" int esac_hip_score(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
+    KArgs a;
+    int rc = make_args(c, d_sc, d_assign, p, &a);
+    if (rc) return rc;
+    launch_score_fast(a, (hipStream_t)stream);
+    return check_launch("k_score_fast");
+}
+extern "C" int esac_hip_select(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
+    KArgs a;
+    int rc = make_args(c, d_sc, d_assign, p, &a);
+    if (rc) return rc;
+    launch_select(a, (hipStream_t)stream);
+    if ((rc = check_launch("k_select"))) return rc;
+    launch_rescore(a, 0, (hipStream_t)stream);
+    return check_launch("k_rescore");
+}
+extern "C" int esac_hip_refine(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
+    KArgs a;
+    int rc = make_args(c, d_sc, d_assign, p, &a);
+    if (rc) return rc;
+    launch_refine(a, (hipStream_t)stream);
+    return check_launch("k_refine");
+}
+extern "C" int esac_hip_score_exact(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
+    KArgs a;
+    int rc = make_args(c, d_sc, d_assign, p, &a);
+    if (rc) return rc;
+    launch_rescore(a, 1, (hipStream_t)stream);
+    return check_launch("k_rescore(all)");
+}
+
+extern "C" int esac_hip_forward(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p,
+                                void* stream, double* d_scores_out, double* d_result_out, double* h_result_out) {
+    KArgs a;
+    int rc = make_args(c, d_sc, d_assign, p, &a);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const bool tm = c->timing;
+    if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
+    launch_sample(a, s);
+    if ((rc = check_launch("k_sample"))) return rc;
+    if (tm) HIP_OK(hipEventRecord(c->ev[1], s));
+    launch_score_fast(a, s);
+    if ((rc = check_launch("k_score_fast"))) return rc;
+    if (tm) HIP_OK(hipEventRecord(c->ev[2], s));
+    launch_select(a, s);
+    if ((rc = check_launch("k_select"))) return rc;
+    launch_rescore(a, 0, s);
+    if ((rc = check_launch("k_rescore"))) return rc;
+    if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
+    launch_refine(a, s);
+    if ((rc = check_launch("k_refine"))) return rc;
+    if (tm) {
+        HIP_OK(hipEventRecord(c->ev[4], s));
+        c->ev_valid = true;
+    }
+    if (d_scores_out) HIP_OK(hipMemcpyAsync(d_scores_out, a.scores, (size_t)a.N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (d_result_out)
+        HIP_OK(hipMemcpyAsync(d_result_out, a.result, ESAC_RES_DOUBLES * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (h_result_out) {
+        HIP_OK(hipMemcpyAsync(h_result_out, a.result, ESAC_RES_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t bytes) {
+    if (!c || !h_dst) return fail(-1, "esac_hip_read: null argument");
+    HIP_OK(hipSetDevice(c->device));
+    const size_t N = (size_t)c->lastN, P = (size_t)c->lastH * c->lastW;
+    const void* src = nullptr;
+    size_t want = 0;
+    switch (which) {
+        case ESAC_BUF_HYPS: src = c->ws.hyps; want = N * 6 * sizeof(double); break;
+        case ESAC_BUF_SAMPLE_XY: src = c->ws.sample_xy; want = N * 8 * sizeof(int32_t); break;
+        case ESAC_BUF_TRIES: src = c->ws.tries; want = N * sizeof(int32_t); break;
+        case ESAC_BUF_SCORES: src = c->ws.scores; want = N * sizeof(double); break;
+        case ESAC_BUF_RESULT: src = c->ws.result; want = ESAC_RES_DOUBLES * sizeof(double); break;
+        case ESAC_BUF_INLIER_MAP: src = c->ws.inlier_map; want = P; break;
+        case ESAC_BUF_INLIER_COUNTS: src = c->ws.inlier_counts; want = (ESAC_MAX_REF_STEPS + 1) * sizeof(int32_t); break;
+        case ESAC_BUF_WINNER_ERRS: src = c->ws.errs; want = P * sizeof(float); break;
+        case ESAC_BUF_EXACT_FLAGS: src = c->ws.exact_flag; want = N; break;
+        default: return fail(-5, "esac_hip_read: unknown buffer id %d", which);
+    }
+    if (!src || want == 0) return fail(-6, "esac_hip_read: buffer %d is empty (no call has run yet)", which);
+    if (bytes != want) return fail(-7, "esac_hip_read: buffer %d holds %zu bytes, caller asked for %zu", which, want, bytes);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(h_dst, src, want, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int esac_hip_write_hyps(esac_hip_ctx* c, const double* h_hyps, int N) {
+    if (!c || !h_hyps || N <= 0) return fail(-1, "esac_hip_write_hyps: bad argument");
+    HIP_OK(hipSetDevice(c->device));
+    int rc = ensure_ws(c, N, c->capP > 0 ? c->capP : 1);
+    if (rc) return rc;
+    HIP_OK(hipMemcpy(c->ws.hyps, h_hyps, (size_t)N * 6 * sizeof(double), hipMemcpyHostToDevice));
+    KArgs a = c->ws;
+    a.N = N;
+    launch_hyps_to_rt32(a, nullptr);
+    if ((rc = check_launch("k_hyps_to_rt32"))) return rc;
+    HIP_OK(hipDeviceSynchronize());
+    c->lastN = N;
+    return 0;
+}
+
+extern "C" int esac_hip_set_timing(esac_hip_ctx* c, int enabled) {
+    if (!c) return fail(-1, "null context");
+    c->timing = enabled != 0;
+    c->ev_valid = false;
+    return 0;
+}
+
+extern "C" int esac_hip_phase_ms(esac_hip_ctx* c, float out[5]) {
+    if (!c || !out) return fail(-1, "esac_hip_phase_ms: null argument");
+    if (!c->timing || !c->ev_valid) return fail(-8, "esac_hip_phase_ms: timing is off or no forward has run");
+    HIP_OK(hipEventSynchronize(c->ev[4]));
+    for (int i = 0; i < 4; i++) HIP_OK(hipEventElapsedTime(&out[i], c->ev[i], c->ev[i + 1]));
+    HIP_OK(hipEventElapsedTime(&out[4], c->ev[0], c->ev[4]));
+    return 0;
+}

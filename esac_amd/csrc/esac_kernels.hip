@@ -1,0 +1,611 @@
+// esac_kernels.hip -- the ESAC hypothesis/inlier hot path as HIP kernels for gfx950 (MI355X).
+//
+// Reference path: code/esac/esac.cpp:64-190 (esac_forward).  Phases -> kernels:
+//   K1 k_sample        sampleHypotheses + safeSolvePnP(P3P)        esac_util.h:129-225
+//   K2 k_score_fast    getReproErrs + getHypScores, fused, fp32    esac.cpp:131-147, esac_util.h:235-363
+//   K3 k_select        softMax / entropy / argmax band             esac_util.h:461-530
+//   K3b k_rescore      reference-arithmetic (fp64) re-score of the contenders
+//   K4 k_refine        draw(argmax) + refineHyp + pose2trans       esac_util.h:378-454,505-548
+//
+// Mapping to CDNA4: K1 = one hypothesis per 64-lane wavefront, lane l evaluates
+// sampling try 64*round+l with the whole P3P in fp64 registers, `ballot` picks the
+// lowest accepted try (= the try a sequential loop would stop at).  K2 = one
+// hypothesis per workgroup, the H x W map streamed with 16-byte coalesced loads
+// (x/y/z planes), ~30 fp32 VALU ops per cell, DPP wavefront reductions; no MFMA:
+// there is no dense contraction anywhere on this path.  K4 = one workgroup, LM
+// normal equations reduced with DPP + v_permlane swaps, pose state kept
+// redundantly in every lane so no broadcast is needed.
+//
+// Precision split: the streaming score (K2) runs in fp32 and only ranks; every
+// hypothesis within `margin` of the fp32 maximum is re-scored by K3b with the
+// reference's exact mixed float/double arithmetic, and the winner is the argmax
+// of those exact scores (first index on ties, esac_util.h:519).  All discrete
+// decisions of refinement (inlier tests, stopping rule) use the exact arithmetic.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pose_math.hpp"
+#include "rng.hpp"
+#include "esac_kernels.hpp"
+
+namespace esac {
+
+// ---------------------------------------------------------------- cross-lane sums
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    int x = __float_as_int(v);
+    x = __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+// all 64 lanes end up with the same (bitwise identical) total
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror
+    {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    {
+        const unsigned x = __float_as_uint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+    {
+        const unsigned x = __float_as_uint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+    return v;
+}
+
+// Sum NV doubles over a workgroup of B threads.  Fixed combination order ->
+// run-to-run deterministic.  s_part: NV*(B/64) doubles, s_tot: NV doubles.
+template <int NV, int B>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_part, double* s_tot) {
+    constexpr int NW = B / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const double w = wave_sum(v[k]);
+        if (lane == 0) s_part[wave * NV + k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) t += s_part[w * NV + threadIdx.x];
+        s_tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = s_tot[k];
+}
+
+__device__ __forceinline__ Cam make_cam(const KArgs& a) {
+    // camMat is a float matrix widened to double by the solver (esac.cpp:93-97)
+    return Cam{(double)a.focal, (double)a.focal, (double)a.ppx, (double)a.ppy};
+}
+// createSampling (esac_util.h:64-66): integer pixel centre of cell (x,y), then Point2f
+// global hypothesis index: keys the RNG stream and breaks ties, independent of the sharding
+__device__ __forceinline__ int global_hyp(const KArgs& a, int h) { return a.hyp_index ? a.hyp_index[h] : a.hyp_offset + h; }
+__device__ __forceinline__ float cell_px(const KArgs& a, int x) { return (float)(x * a.sub + a.sub / 2 - a.shift_x); }
+__device__ __forceinline__ float cell_py(const KArgs& a, int y) { return (float)(y * a.sub + a.sub / 2 - a.shift_y); }
+
+// ================================================================= K1: sample + P3P
+__global__ __launch_bounds__(64) void k_sample(KArgs a) {
+    const int h = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int e = (int)a.assign[h];
+    const int P = a.H * a.W;
+    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
+    const Philox rng(a.seed, a.call);
+    const Cam cam = make_cam(a);
+    const uint32_t gh = (uint32_t)global_hyp(a, h);
+    const double tau = (double)a.tau;
+
+    for (int base = 0; base < a.max_tries; base += 64) {
+        const int t = base + lane;
+        const bool active = t < a.max_tries;
+        int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
+        double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        bool accepted = false;
+        if (active) {
+            draw_cells(rng, gh, (uint32_t)t, a.W, a.H, cx, cy);
+            V3 Pt[4];
+            float Pf[4][3];
+            double mu[4], mv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int idx = cy[j] * a.W + cx[j];
+                Pf[j][0] = map[idx];
+                Pf[j][1] = map[P + idx];
+                Pf[j][2] = map[2 * P + idx];
+                Pt[j] = V3{(double)Pf[j][0], (double)Pf[j][1], (double)Pf[j][2]};
+                mu[j] = (double)cell_px(a, cx[j]);
+                mv[j] = (double)cell_py(a, cy[j]);
+            }
+            double Rp[9], Tp[3];
+            const bool solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp);
+            if (solved) {
+                // the reference stores (rvec, tvec) and re-expands it when projecting (esac_util.h:202)
+                rodrigues_mat2vec(Rp, rvec);
+                rodrigues_vec2mat<false>(rvec, R, nullptr);
+                T[0] = Tp[0]; T[1] = Tp[1]; T[2] = Tp[2];
+                accepted = true;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // 4 sampled points must reproject within tau (esac_util.h:210-221), norm in double
+                    const double Xd = Pf[j][0], Yd = Pf[j][1], Zd = Pf[j][2];
+                    double x = R[0] * Xd + R[1] * Yd + R[2] * Zd + T[0];
+                    double y = R[3] * Xd + R[4] * Yd + R[5] * Zd + T[1];
+                    double z = R[6] * Xd + R[7] * Yd + R[8] * Zd + T[2];
+                    z = z ? 1. / z : 1;
+                    x *= z;
+                    y *= z;
+                    const float u = (float)(x * cam.fx + cam.cx), v = (float)(y * cam.fy + cam.cy);
+                    const float dx = (float)mu[j] - u, dy = (float)mv[j] - v;
+                    const double nrm = sqrt((double)dx * dx + (double)dy * dy);
+                    if (nrm < tau) continue;
+                    accepted = false;
+                }
+            }
+            // a failed solve leaves the zero pose (safeSolvePnP, esac_util.h:107-111)
+        }
+        const unsigned long long m = __ballot(accepted);
+        const bool last_round = base + 64 >= a.max_tries;
+        int writer = -1, tries_val = -1;
+        if (m) {
+            writer = __ffsll((long long)m) - 1;
+            tries_val = base + writer;
+        } else if (last_round) {
+            writer = (a.max_tries - 1) - base;  // budget exhausted: state of the last try remains
+        }
+        if (writer >= 0) {
+            if (lane == writer) {
+                double* hp = a.hyps + (size_t)h * 6;
+                hp[0] = rvec[0]; hp[1] = rvec[1]; hp[2] = rvec[2];
+                hp[3] = T[0]; hp[4] = T[1]; hp[5] = T[2];
+                float* rt = a.rt32 + (size_t)h * 12;
+#pragma unroll
+                for (int k = 0; k < 9; k++) rt[k] = (float)R[k];
+                rt[9] = (float)T[0]; rt[10] = (float)T[1]; rt[11] = (float)T[2];
+                int* sx = a.sample_xy + (size_t)h * 8;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    sx[2 * j] = cx[j];
+                    sx[2 * j + 1] = cy[j];
+                }
+                a.tries[h] = tries_val;
+            }
+            return;
+        }
+    }
+}
+
+// (rvec,tvec) -> float [R|t] for the fp32 scoring stream (used after esac_hip_write_hyps)
+__global__ void k_hyps_to_rt32(KArgs a) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= a.N) return;
+    double R[9];
+    const double* hp = a.hyps + (size_t)h * 6;
+    const double r[3] = {hp[0], hp[1], hp[2]};
+    rodrigues_vec2mat<false>(r, R, nullptr);
+    float* rt = a.rt32 + (size_t)h * 12;
+#pragma unroll
+    for (int k = 0; k < 9; k++) rt[k] = (float)R[k];
+    rt[9] = (float)hp[3]; rt[10] = (float)hp[4]; rt[11] = (float)hp[5];
+}
+
+// ================================================================= K2: fused soft-inlier score, fp32
+struct PoseF {
+    float r0, r1, r2, r3, r4, r5, r6, r7, r8, t0, t1, t2;
+};
+
+// one cell: project, clamp, 1 - sigmoid(beta*(err - tau)) = 1 / (1 + exp(beta*(err - tau)))
+__device__ __forceinline__ float soft_inlier_fast(const PoseF& p, float fx, float fy, float cx, float cy, float X,
+                                                  float Y, float Z, float px, float py, float max_reproj,
+                                                  float beta_log2e, float tau) {
+    const float xc = fmaf(p.r0, X, fmaf(p.r1, Y, fmaf(p.r2, Z, p.t0)));
+    const float yc = fmaf(p.r3, X, fmaf(p.r4, Y, fmaf(p.r5, Z, p.t1)));
+    const float zc = fmaf(p.r6, X, fmaf(p.r7, Y, fmaf(p.r8, Z, p.t2)));
+    const float iz = (zc != 0.0f) ? __builtin_amdgcn_rcpf(zc) : 1.0f;
+    const float du = px - fmaf(fx, xc * iz, cx);
+    const float dv = py - fmaf(fy, yc * iz, cy);
+    const float err = fminf(__builtin_amdgcn_sqrtf(fmaf(du, du, dv * dv)), max_reproj);
+    const float ex = __builtin_amdgcn_exp2f((err - tau) * beta_log2e);
+    return __builtin_amdgcn_rcpf(1.0f + ex);
+}
+
+template <int B>
+__global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
+    __shared__ float s_w[B / 64];
+    const int h = blockIdx.x;
+    const int e = (int)a.assign[h];
+    const int P = a.H * a.W;
+    const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
+    const float* __restrict__ my = mx + P;
+    const float* __restrict__ mz = my + P;
+    const float* rt = a.rt32 + (size_t)h * 12;  // wave-uniform -> scalar loads
+    const PoseF p{rt[0], rt[1], rt[2], rt[3], rt[4], rt[5], rt[6], rt[7], rt[8], rt[9], rt[10], rt[11]};
+    const float fx = a.focal, fy = a.focal, cx = a.ppx, cy = a.ppy;
+    const float beta_log2e = a.beta * 1.4426950408889634f;
+    float acc = 0.0f;
+    if ((a.W & 3) == 0) {
+        // 4 consecutive cells of one row per lane: 16-byte coalesced loads from each plane
+        const int nq = P >> 2;
+        const int wq = a.W >> 2;
+        const float4* __restrict__ qx = reinterpret_cast<const float4*>(mx);
+        const float4* __restrict__ qy = reinterpret_cast<const float4*>(my);
+        const float4* __restrict__ qz = reinterpret_cast<const float4*>(mz);
+        const float step = (float)a.sub;
+        for (int i = threadIdx.x; i < nq; i += B) {
+            const float4 X = qx[i], Y = qy[i], Z = qz[i];
+            const int row = i / wq;
+            const int col = (i - row * wq) << 2;
+            const float py = cell_py(a, row);
+            const float px = cell_px(a, col);
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.x, Y.x, Z.x, px, py, a.max_reproj, beta_log2e, a.tau);
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.y, Y.y, Z.y, px + step, py, a.max_reproj, beta_log2e, a.tau);
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.z, Y.z, Z.z, px + 2 * step, py, a.max_reproj, beta_log2e, a.tau);
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.w, Y.w, Z.w, px + 3 * step, py, a.max_reproj, beta_log2e, a.tau);
+        }
+    } else {
+        for (int i = threadIdx.x; i < P; i += B) {
+            const int row = i / a.W;
+            const int col = i - row * a.W;
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, mx[i], my[i], mz[i], cell_px(a, col), cell_py(a, row),
+                                    a.max_reproj, beta_log2e, a.tau);
+        }
+    }
+    const float w = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0;
+#pragma unroll
+        for (int k = 0; k < B / 64; k++) tot += (double)s_w[k];
+        const float scale = a.alpha / a.W / a.H;  // float / int / int (esac_util.h:256)
+        a.fast_scores[h] = (float)(tot * (double)scale);
+    }
+}
+
+// ================================================================= K3: select (band of contenders)
+template <int B>
+__global__ __launch_bounds__(B) void k_select(KArgs a) {
+    __shared__ double s_part[3 * (B / 64)];
+    __shared__ double s_tot[3];
+    __shared__ float s_max[B / 64];
+    __shared__ int s_count;
+    // max (NaN-ignoring)
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < a.N; i += B) m = fmaxf(m, a.fast_scores[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    m = s_max[0];
+#pragma unroll
+    for (int k = 1; k < B / 64; k++) m = fmaxf(m, s_max[k]);
+    const float band = m - a.margin;
+    // softmax statistics (esac_util.h:461-497) from the fp32-path scores, in double
+    double acc[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < a.N; i += B) {
+        const float s = a.fast_scores[i];
+        a.scores[i] = (double)s;
+        a.exact_flag[i] = 0;
+        const double d = (double)s - (double)m;
+        const double ex = exp(d);
+        acc[0] += ex;
+        acc[1] += ex * d;
+        if (s >= band) {
+            const int slot = atomicAdd(&s_count, 1);
+            a.contenders[slot] = i;
+        }
+    }
+    block_sum<3, B>(acc, s_part, s_tot);
+    if (threadIdx.x == 0) {
+        const int n = s_count;
+        a.n_contenders[0] = n;
+        a.stats[0] = (double)m;  // max
+        a.stats[1] = acc[0];     // sum exp(s - max)
+        // entropy = -sum p log2 p,  p = exp(d)/S  ->  log2(S) - (sum exp(d) d) / (S ln 2)
+        a.stats[2] = log2(acc[0]) - acc[1] / (acc[0] * 0.6931471805599453);
+    }
+}
+
+// ================================================================= K3b: exact re-score
+template <int B>
+__global__ __launch_bounds__(B) void k_rescore(KArgs a, int all) {
+    __shared__ double s_part[B / 64];
+    __shared__ double s_tot[1];
+    const int n = all ? a.N : a.n_contenders[0];
+    const int P = a.H * a.W;
+    const Cam cam = make_cam(a);
+    for (int c = blockIdx.x; c < n; c += gridDim.x) {
+        const int h = all ? c : a.contenders[c];
+        const int e = (int)a.assign[h];
+        const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
+        const double* hp = a.hyps + (size_t)h * 6;
+        const double rv[3] = {hp[0], hp[1], hp[2]};
+        const double t[3] = {hp[3], hp[4], hp[5]};
+        double R[9];
+        rodrigues_vec2mat<false>(rv, R, nullptr);
+        double acc[1] = {0};
+        for (int i = threadIdx.x; i < P; i += B) {
+            const int row = i / a.W, col = i - row * a.W;
+            float err = project_exact_err(R, t, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
+            err = err < a.max_reproj ? err : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+            acc[0] += soft_inlier_exact(err, a.tau, a.beta);
+        }
+        block_sum<1, B>(acc, s_part, s_tot);
+        if (threadIdx.x == 0) {
+            const float scale = a.alpha / a.W / a.H;
+            double s = acc[0];
+            s *= scale;  // double *= float
+            a.scores[h] = s;
+            a.exact_flag[h] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================= K4: pick winner, refine, emit pose
+template <int B>
+__global__ __launch_bounds__(B) void k_refine(KArgs a) {
+    __shared__ double s_part[28 * (B / 64)];
+    __shared__ double s_tot[28];
+    __shared__ double s_best[B / 64];
+    __shared__ int s_besti[B / 64];
+    __shared__ int s_bestg[B / 64];
+    const int P = a.H * a.W;
+    const Cam cam = make_cam(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- draw(probs, training=false): argmax, first index on ties (esac_util.h:512-529)
+    const int nc = a.n_contenders[0];
+    double bs = -INFINITY;
+    int bi = 0x7fffffff;  // local index of the best so far; ties go to the lowest GLOBAL index
+    int bg = 0x7fffffff;
+    for (int c = threadIdx.x; c < nc; c += B) {
+        const int h = a.contenders[c];
+        const int g = global_hyp(a, h);
+        const double s = a.scores[h];
+        if (s > bs || (s == bs && g < bg)) {
+            bs = s;
+            bi = h;
+            bg = g;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(bs, o);
+        const int oi = __shfl_xor(bi, o);
+        const int og = __shfl_xor(bg, o);
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    if (lane == 0) {
+        s_best[wave] = bs;
+        s_besti[wave] = bi;
+        s_bestg[wave] = bg;
+    }
+    __syncthreads();
+    bs = s_best[0];
+    bi = s_besti[0];
+    bg = s_bestg[0];
+#pragma unroll
+    for (int w = 1; w < B / 64; w++) {
+        const double os = s_best[w];
+        const int oi = s_besti[w];
+        const int og = s_bestg[w];
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    const int win = (bi == 0x7fffffff) ? 0 : bi;
+    const double win_score = a.scores[win];
+    const int e = (int)a.assign[win];
+    const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
+
+    double pose[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
+
+    // ---- refineHyp (esac_util.h:378-454)
+    double R[9];
+    rodrigues_vec2mat<false>(pose, R, nullptr);
+    int n_inl = 0;
+    {   // error image of the selected hypothesis (reproErrs[hypIdx], esac.cpp:169)
+        int c = 0;
+        for (int i = threadIdx.x; i < P; i += B) {
+            const int row = i / a.W, col = i - row * a.W;
+            float err = project_exact_err(R, pose + 3, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
+            err = err < a.max_reproj ? err : a.max_reproj;
+            a.errs[i] = err;
+            a.inlier_map[i] = 0;
+            c += (err < a.tau) ? 1 : 0;
+        }
+        // per-thread counts -> workgroup total (through the double path: exact for counts < 2^53)
+        double cc[1] = {(double)c};
+        block_sum<1, B>(cc, s_part, s_tot);
+        n_inl = (int)cc[0];
+    }
+    for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;
+    __syncthreads();
+
+    unsigned best_inliers = 4;
+    int accepted = 0, last_inliers = 0, lm_total = 0;
+    for (int rstep = 0; rstep < a.max_ref_steps; rstep++) {
+        if (threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
+        if ((unsigned)n_inl <= best_inliers) break;  // converged
+        best_inliers = (unsigned)n_inl;
+
+        // ---- solvePnP(ITERATIVE, useExtrinsicGuess) on the inliers: Levenberg-Marquardt,
+        //      6 parameters, <=20 iterations, eps = FLT_EPSILON, lambda = 10^k
+        double param[6], prev[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) param[k] = pose[k];
+        int lambda_lg10 = -3, iters = 0;
+        double prev_err_norm = 1.7976931348623157e308;
+        for (;;) {
+            double Rm[9], dRdr[27];
+            rodrigues_vec2mat<true>(param, Rm, dRdr);
+            double acc[28];
+#pragma unroll
+            for (int k = 0; k < 28; k++) acc[k] = 0;
+            for (int i = threadIdx.x; i < P; i += B) {
+                if (a.errs[i] < a.tau) {
+                    const int row = i / a.W, col = i - row * a.W;
+                    double ex, ey, Ju[6], Jv[6];
+                    pnp_point_terms(Rm, dRdr, param + 3, cam, (double)mx[i], (double)mx[P + i], (double)mx[2 * P + i],
+                                    (double)cell_px(a, col), (double)cell_py(a, row), ex, ey, Ju, Jv);
+                    int k = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+#pragma unroll
+                        for (int c = r; c < 6; c++) {
+                            acc[k] += Ju[r] * Ju[c] + Jv[r] * Jv[c];
+                            k++;
+                        }
+#pragma unroll
+                    for (int r = 0; r < 6; r++) acc[21 + r] += Ju[r] * ex + Jv[r] * ey;
+                    acc[27] += ex * ex + ey * ey;
+                }
+            }
+            block_sum<28, B>(acc, s_part, s_tot);
+#pragma unroll
+            for (int k = 0; k < 6; k++) prev[k] = param[k];
+            if (iters == 0) prev_err_norm = sqrt(acc[27]);
+            double err_norm;
+            for (;;) {
+                // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
+                const double lambda = exp(lambda_lg10 * 2.302585092994046);
+                double dx[6];
+                lm_solve6(acc, acc + 21, lambda, dx);
+#pragma unroll
+                for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
+                // CHECK_ERR: residual norm at the stepped parameters
+                double Rn[9];
+                rodrigues_vec2mat<false>(param, Rn, nullptr);
+                double e2[1] = {0};
+                for (int i = threadIdx.x; i < P; i += B) {
+                    if (a.errs[i] < a.tau) {
+                        const int row = i / a.W, col = i - row * a.W;
+                        double ex, ey;
+                        pnp_point_residual(Rn, param + 3, cam, (double)mx[i], (double)mx[P + i], (double)mx[2 * P + i],
+                                           (double)cell_px(a, col), (double)cell_py(a, row), ex, ey);
+                        e2[0] += ex * ex + ey * ey;
+                    }
+                }
+                block_sum<1, B>(e2, s_part, s_tot);
+                err_norm = sqrt(e2[0]);
+                if (err_norm > prev_err_norm) {
+                    if (++lambda_lg10 <= 16) continue;
+                }
+                break;
+            }
+            lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
+            double dn = 0, pn = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                dn += (param[k] - prev[k]) * (param[k] - prev[k]);
+                pn += prev[k] * prev[k];
+            }
+            const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
+            ++iters;
+            if (iters >= 20 || rel < (double)FLT_EPSILON) break;
+            prev_err_norm = err_norm;
+        }
+        lm_total += iters;
+#pragma unroll
+        for (int k = 0; k < 6; k++) pose[k] = param[k];
+        accepted++;
+        last_inliers = n_inl;
+
+        // accept: inlierMap = this step's inlier set (esac_util.h:440); new error image (esac_util.h:445-452)
+        rodrigues_vec2mat<false>(pose, R, nullptr);
+        int c = 0;
+        for (int i = threadIdx.x; i < P; i += B) {
+            const int row = i / a.W, col = i - row * a.W;
+            a.inlier_map[i] = (a.errs[i] < a.tau) ? 1 : 0;
+            float err = project_exact_err(R, pose + 3, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
+            err = err < a.max_reproj ? err : a.max_reproj;
+            a.errs[i] = err;
+            c += (err < a.tau) ? 1 : 0;
+        }
+        double cc[1] = {(double)c};
+        block_sum<1, B>(cc, s_part, s_tot);
+        n_inl = (int)cc[0];
+    }
+
+    // ---- pose2trans (esac_util.h:537-548) and the result record
+    if (threadIdx.x == 0) {
+        rodrigues_vec2mat<false>(pose, R, nullptr);
+        double T[16];
+        pose_to_inverse_transform(R, pose + 3, T);
+        double* r = a.result;
+        r[ESAC_RES_SCORE_K] = win_score;
+        r[ESAC_RES_HYP_K] = (double)global_hyp(a, win);
+        r[ESAC_RES_EXPERT_K] = (double)e;
+#pragma unroll
+        for (int k = 0; k < 6; k++) r[ESAC_RES_RVEC_K + k] = pose[k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) r[ESAC_RES_POSE_K + k] = (double)(float)T[k];
+        r[ESAC_RES_REF_STEPS_K] = (double)accepted;
+        r[ESAC_RES_INLIERS_K] = (double)last_inliers;
+        const double smax = a.stats[0], ssum = a.stats[1];
+        r[ESAC_RES_PROB_K] = exp(win_score - smax) / ssum;
+        r[ESAC_RES_ENTROPY_K] = a.stats[2];
+        r[ESAC_RES_CONTENDERS_K] = (double)nc;
+        r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
+        r[31] = 0;
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+void launch_sample(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_sample, dim3(a.N), dim3(64), 0, s, a); }
+void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_hyps_to_rt32, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_score_fast(const KArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N), dim3(256), 0, s, a);
+}
+void launch_select(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_select<1024>, dim3(1), dim3(1024), 0, s, a); }
+void launch_rescore(const KArgs& a, int all, hipStream_t s) {
+    const int grid = all ? (a.N < 4096 ? a.N : 4096) : (a.N < 256 ? a.N : 256);
+    hipLaunchKernelGGL(k_rescore<256>, dim3(grid), dim3(256), 0, s, a, all);
+}
+void launch_refine(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_refine<512>, dim3(1), dim3(512), 0, s, a); }
+
+}  // namespace esac

@@ -1,0 +1,50 @@
+// esac_kernels.hpp -- kernel argument block shared by the launchers and the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace esac {
+
+// mirrors of the ESAC_RES_* layout in include/esac_hip.h (checked by static_assert in esac_capi.hip)
+constexpr int ESAC_RES_SCORE_K = 0, ESAC_RES_HYP_K = 1, ESAC_RES_EXPERT_K = 2, ESAC_RES_RVEC_K = 3,
+              ESAC_RES_POSE_K = 9, ESAC_RES_REF_STEPS_K = 25, ESAC_RES_INLIERS_K = 26, ESAC_RES_PROB_K = 27,
+              ESAC_RES_ENTROPY_K = 28, ESAC_RES_CONTENDERS_K = 29, ESAC_RES_LM_ITERS_K = 30;
+constexpr int ESAC_MAX_REF_STEPS_K = 100;
+
+struct KArgs {
+    // inputs (device)
+    const float* sc;        // [E,3,H,W]
+    const int64_t* assign;  // [N]
+    int E, H, W, N;
+    int shift_x, shift_y, sub;
+    float focal, ppx, ppy;
+    float tau, alpha, beta, max_reproj;
+    uint64_t seed, call;
+    int max_tries, max_ref_steps, hyp_offset;
+    float margin;
+    const int32_t* hyp_index;  // optional [N] global hypothesis indices
+    // workspaces (device)
+    double* hyps;         // [N,6]
+    float* rt32;          // [N,12] float(R(rvec)), float(t)
+    int* sample_xy;       // [N,8]
+    int* tries;           // [N]
+    float* fast_scores;   // [N]
+    double* scores;       // [N]
+    uint8_t* exact_flag;  // [N]
+    int* contenders;      // [N]
+    int* n_contenders;    // [1]
+    double* stats;        // [4] max, sum exp, entropy
+    float* errs;          // [P]
+    uint8_t* inlier_map;  // [P]
+    int* inlier_counts;   // [ESAC_MAX_REF_STEPS_K+1]
+    double* result;       // [32]
+};
+
+void launch_sample(const KArgs& a, hipStream_t s);
+void launch_hyps_to_rt32(const KArgs& a, hipStream_t s);
+void launch_score_fast(const KArgs& a, hipStream_t s);
+void launch_select(const KArgs& a, hipStream_t s);
+void launch_rescore(const KArgs& a, int all, hipStream_t s);
+void launch_refine(const KArgs& a, hipStream_t s);
+
+}  // namespace esac

@@ -1,0 +1,100 @@
+"""Hypothesis sharding across GPUs + the single score all-reduce.
+
+The reference has no multi-device path (no NCCL/MPI anywhere); this is new design.
+Hypotheses are independent through sampling and scoring (esac_util.h:152-225 and
+esac.cpp:131-147 only touch slot [h]) and the output depends on non-winners only
+through the argmax, so each rank
+  1. scores its own shard and refines its LOCAL best (refining non-winners cannot
+     change the result, esac.cpp:167-177 refines the winner only),
+  2. contributes one zero-padded buffer  [ N_total scores | world x 32-double records ]
+     to ONE all-reduce(SUM) (RCCL over xGMI on GPUs, gloo in the CPU tests),
+  3. picks the global winner = max exact score, lowest GLOBAL hypothesis index on
+     ties (esac_util.h:519 "first max").
+RNG streams and tie-breaks use global hypothesis indices, so the result does not
+depend on the number of ranks.  The payload is (N_total + 32*world) * 8 bytes
+(<= 133 KB at N = 16384, 8 ranks): latency-bound, xGMI bandwidth is irrelevant.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+RES_SCORE, RES_HYP, RES_DOUBLES = 0, 1, 32
+
+
+def shard_range(n_total, rank, world):
+    """Contiguous index-range shard [lo, hi) of rank `rank`."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_by_expert(hyp_assign, rank, world):
+    """Global indices of the hypotheses whose expert this rank owns (expert e lives on rank e % world):
+    each rank then only needs its own experts' maps (and only runs those expert CNNs)."""
+    ha = np.asarray(hyp_assign)
+    return np.nonzero(ha % world == rank)[0].astype(np.int32)
+
+
+def pack_local(scores_local, record_local, n_total, global_index, rank, world):
+    """Zero-padded contribution of one rank.  scores_local [n_local] f64, record_local [32] f64 (same device)."""
+    buf = torch.zeros(n_total + world * RES_DOUBLES, dtype=torch.float64, device=scores_local.device)
+    if scores_local.numel():
+        buf[global_index.to(scores_local.device, torch.long)] = scores_local
+        rec = record_local.to(torch.float64)
+        # +1 marker in the last slot: a rank with an empty shard contributes an all-zero record
+        rec = rec.clone()
+        rec[RES_DOUBLES - 1] = 1.0
+        buf[n_total + rank * RES_DOUBLES: n_total + (rank + 1) * RES_DOUBLES] = rec
+    return buf
+
+
+def pick_global(buf, n_total, world):
+    """(scores_global [n_total], winning record [32]) from the all-reduced buffer."""
+    scores = buf[:n_total]
+    recs = buf[n_total:].view(world, RES_DOUBLES).cpu().numpy()
+    best = None
+    for r in range(world):
+        rec = recs[r]
+        if rec[RES_DOUBLES - 1] != 1.0:
+            continue  # empty shard
+        if best is None or rec[RES_SCORE] > best[RES_SCORE] or (rec[RES_SCORE] == best[RES_SCORE] and rec[RES_HYP] < best[RES_HYP]):
+            best = rec
+    if best is None:
+        raise RuntimeError("esac: no rank produced a hypothesis")
+    return scores, best.copy()
+
+
+def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None, policy="range"):
+    """Multi-GPU esac_forward: every rank holds `scene_coords` (or at least its experts' maps) and
+    the full assignment vector; returns (scores_global [N] f64 device tensor, winning record np[32]).
+
+    `params_kw` are the keyword arguments of Engine.make_params except N / hyp_offset."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    ha_full = hyp_assign_full
+    n_total = int(ha_full.shape[0])
+    E, _, H, W = scene_coords.shape
+    if policy == "range":
+        lo, hi = shard_range(n_total, rank, world)
+        gidx = torch.arange(lo, hi, dtype=torch.int32)
+    elif policy == "expert":
+        gidx = torch.from_numpy(shard_by_expert(ha_full.cpu().numpy(), rank, world))
+    else:
+        raise ValueError(policy)
+    n_local = int(gidx.numel())
+    dev = engine.device
+    if n_local > 0:
+        ha_local = ha_full.to(dev)[gidx.to(dev, torch.long)].contiguous()
+        p = engine.make_params(E, H, W, n_local, **params_kw)
+        gidx_dev = gidx.to(dev).contiguous()
+        engine.set_hyp_index(p, gidx_dev)
+        scores_local = torch.empty(n_local, dtype=torch.float64, device=dev)
+        record = torch.empty(RES_DOUBLES, dtype=torch.float64, device=dev)
+        engine.forward_device(scene_coords, ha_local, p, scores_out=scores_local, result_out=record, want_host=False)
+    else:
+        scores_local = torch.empty(0, dtype=torch.float64, device=dev)
+        record = torch.zeros(RES_DOUBLES, dtype=torch.float64, device=dev)
+    buf = pack_local(scores_local, record, n_total, gidx, rank, world)
+    if world > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)  # the one collective of this path
+    return pick_global(buf, n_total, world)

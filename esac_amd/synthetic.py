@@ -92,5 +92,7 @@ def pose_errors(out_pose, gt_pose):
     gt_pose = np.asarray(gt_pose, np.float64)
     t_err = float(np.linalg.norm(gt_pose[:3, 3] - out_pose[:3, 3]))
     Rr = out_pose[:3, :3] @ gt_pose[:3, :3].T
-    c = min(1.0, max(-1.0, (np.trace(Rr) - 1.0) / 2.0))
-    return float(math.acos(c)), t_err
+    # |Rodrigues(Rr)| as cv2.Rodrigues gives it, but via atan2(sin, cos): acos alone loses half the
+    # digits near 0 (float32 poses would read ~3e-4 rad for identical rotations)
+    sk = 0.5 * np.array([Rr[2, 1] - Rr[1, 2], Rr[0, 2] - Rr[2, 0], Rr[1, 0] - Rr[0, 1]])
+    return float(math.atan2(np.linalg.norm(sk), (np.trace(Rr) - 1.0) / 2.0)), t_err

@@ -1,0 +1,154 @@
+/*
+ * esac_hip.h -- C ABI of the MI355X-native ESAC hypothesis/inlier hot path.
+ *
+ * This is the drop-in boundary: a plain-C shared library (libesac_hip.so) with
+ * no torch / pybind types in any signature.  It replaces what the reference
+ * binds through pybind11 in code/esac/esac.cpp:513-516
+ *     m.def("forward",  &esac_forward)   // esac.cpp:64-190
+ *     m.def("backward", &esac_backward)  // esac.cpp:213-511 (row f1, not yet built)
+ * The Python module `esac` (esac.py -> esac_amd/api.py) binds these entry points
+ * with ctypes and keeps the reference's positional `esac.forward(...)` signature;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; esac_hip_last_error()
+ *     returns a thread-local message (the Python layer raises RuntimeError,
+ *     the exception type pybind11 turns the reference's c10::Error into).
+ *   - pointers named d_* are DEVICE pointers on the context's GPU, h_* are HOST.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - tensors are dense row-major: scene coordinates [E,3,H,W] float32
+ *     (esac_types.h:45 coord_t), hypothesis assignment [N] int64
+ *     (esac_types.h:46 hyp_assign_t).
+ *   - there is NO CPU fallback: without a HIP device every call fails.
+ */
+#ifndef ESAC_HIP_H
+#define ESAC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESAC_HIP_ABI_VERSION 1
+
+/* reference compile-time constants (esac.cpp:44-45) */
+#define ESAC_MAX_SAMPLING_TRIES 1000000
+#define ESAC_MAX_REF_STEPS 100
+
+/* Scalar arguments of esac_forward (esac.cpp:64-77) plus the knobs the
+ * reference hard-codes or hides (RNG key, limits, multi-GPU shard offset). */
+typedef struct esac_hip_params {
+    int32_t E, H, W;          /* sceneCoordinates.size(0,2,3)  esac.cpp:87-88      */
+    int32_t N;                /* hypAssignment.size(0)         esac.cpp:90         */
+    int32_t shift_x, shift_y; /* esac.cpp:67-68                                    */
+    float focal, ppx, ppy;    /* esac.cpp:69-71; camMat is float, esac.cpp:93-97   */
+    float inlier_thresh;      /* tau,   esac.cpp:72                                */
+    float inlier_alpha;       /* alpha, esac.cpp:73                                */
+    float inlier_beta;        /* beta,  esac.cpp:74                                */
+    float max_reproj;         /* esac.cpp:75                                       */
+    int32_t sub_sampling;     /* esac.cpp:76                                       */
+    uint64_t seed;            /* RNG key; reference: fixed 1305, thread_rand.h:103 */
+    uint64_t call;            /* call counter (reference RNG state persists across calls) */
+    int32_t max_tries;        /* <=0 -> ESAC_MAX_SAMPLING_TRIES                    */
+    int32_t max_ref_steps;    /* <0  -> ESAC_MAX_REF_STEPS                         */
+    int32_t hyp_offset;       /* global index of local hypothesis 0 (multi-GPU sharding; RNG and
+                                 tie-breaks use global indices so results do not depend on the
+                                 number of ranks) */
+    float rescore_margin;     /* fast-score band re-scored exactly; <=0 -> alpha*ESAC_DEFAULT_MARGIN */
+    const int32_t* d_hyp_index; /* optional DEVICE int32[N]: global index of each local hypothesis, for
+                                 shards that are not a contiguous range (expert-sharded multi-GPU);
+                                 NULL -> hyp_offset + i */
+} esac_hip_params;
+
+#define ESAC_DEFAULT_MARGIN 1e-3f
+
+/* Layout of the result record (doubles).  Written by the refinement kernel. */
+enum {
+    ESAC_RES_SCORE = 0,      /* exact soft-inlier score of the winner (esac_util.h:235-260)     */
+    ESAC_RES_HYP = 1,        /* winner hypothesis index (GLOBAL = hyp_offset + local)            */
+    ESAC_RES_EXPERT = 2,     /* hypAssignment[winner]  (esac.cpp:189, the return value)          */
+    ESAC_RES_RVEC = 3,       /* refined rvec[3], tvec[3] (scene->camera, OpenCV convention)      */
+    ESAC_RES_TVEC = 6,
+    ESAC_RES_POSE = 9,       /* 16 values: float(inverse([R t;0 1])) row-major (esac.cpp:182-187) */
+    ESAC_RES_REF_STEPS = 25, /* accepted re-fits in refineHyp (esac_util.h:396-452)              */
+    ESAC_RES_INLIERS = 26,   /* inlier count of the last accepted set                            */
+    ESAC_RES_PROB = 27,      /* softmax probability of the winner (esac.cpp:157)                 */
+    ESAC_RES_ENTROPY = 28,   /* entropy of the hypothesis distribution (esac.cpp:158)            */
+    ESAC_RES_CONTENDERS = 29,/* how many hypotheses were re-scored exactly                       */
+    ESAC_RES_LM_ITERS = 30,  /* total LM iterations spent in refinement                          */
+    ESAC_RES_DOUBLES = 32
+};
+
+/* Stage buffers that can be read back / written for stage-wise parity tests. */
+enum {
+    ESAC_BUF_HYPS = 0,       /* double[N][6]  rvec,tvec per hypothesis (esac_types.h:40 pose_t)  */
+    ESAC_BUF_SAMPLE_XY = 1,  /* int32[N][4][2] sampled cells (esac_util.h:187 sampledPoints)     */
+    ESAC_BUF_TRIES = 2,      /* int32[N] accepted try index, -1 = budget exhausted               */
+    ESAC_BUF_SCORES = 3,     /* double[N] scores (fp32-path value, exact for re-scored ones)     */
+    ESAC_BUF_RESULT = 4,     /* double[ESAC_RES_DOUBLES]                                          */
+    ESAC_BUF_INLIER_MAP = 5, /* uint8[H*W] last accepted inlier set (esac_util.h:440 inlierMap)  */
+    ESAC_BUF_INLIER_COUNTS = 6, /* int32[ESAC_MAX_REF_STEPS+1] inlier count seen at each step    */
+    ESAC_BUF_WINNER_ERRS = 7,   /* float[H*W] reprojection errors of the current pose            */
+    ESAC_BUF_EXACT_FLAGS = 8    /* uint8[N] 1 where ESAC_BUF_SCORES holds an exact re-score      */
+};
+
+typedef struct esac_hip_ctx esac_hip_ctx;
+
+/* library / device */
+int esac_hip_abi_version(void);
+const char* esac_hip_last_error(void);
+int esac_hip_device_count(void);
+
+/* A context owns the device workspaces for one GPU; not thread-safe, one call in
+ * flight per context (the reference extension is not re-entrant either:
+ * static RNG, thread_rand.cpp:4-5). */
+int esac_hip_create(esac_hip_ctx** ctx, int device);
+int esac_hip_destroy(esac_hip_ctx* ctx);
+
+/*
+ * The whole of esac_forward (esac.cpp:64-190) on the device:
+ *   sample+P3P -> soft-inlier scores -> select (+exact re-score of the contenders)
+ *   -> refine the winner -> pose.
+ * d_scene_coords  [E,3,H,W] float32, d_hyp_assign [N] int64 (device).
+ * d_scores_out    optional device double[N]  (the score vector; all-reduced across ranks by the caller)
+ * d_result_out    optional device double[ESAC_RES_DOUBLES]
+ * h_result_out    optional host   double[ESAC_RES_DOUBLES]; when non-NULL the call
+ *                 synchronises the stream before returning (the reference call is blocking).
+ */
+int esac_hip_forward(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
+                     const esac_hip_params* p, void* stream, double* d_scores_out,
+                     double* d_result_out, double* h_result_out);
+
+/* The same phases one at a time (asynchronous on `stream`), for stage-wise parity
+ * tests and for callers that interleave other work.  Order: sample, score, select, refine. */
+int esac_hip_sample(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
+                    const esac_hip_params* p, void* stream);   /* esac_util.h:129-225 */
+int esac_hip_score(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
+                   const esac_hip_params* p, void* stream);    /* esac.cpp:131-147   */
+int esac_hip_select(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
+                    const esac_hip_params* p, void* stream);   /* esac.cpp:153-155   */
+int esac_hip_refine(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
+                    const esac_hip_params* p, void* stream);   /* esac.cpp:167-187   */
+
+/* Exact (reference-arithmetic) scoring of every hypothesis; slow path used by tests
+ * and by callers that want scores identical to esac_util.h:235-260 for all N. */
+int esac_hip_score_exact(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
+                         const esac_hip_params* p, void* stream);
+
+/* Stage buffer access (synchronous). `bytes` must match the buffer size for (which, N, H, W). */
+int esac_hip_read(esac_hip_ctx* ctx, int which, void* h_dst, size_t bytes);
+int esac_hip_write_hyps(esac_hip_ctx* ctx, const double* h_hyps, int N);
+
+/* Time of the most recent launch of each phase on this context in milliseconds
+ * (hipEvents around each kernel; the StopWatch prints of esac.cpp:124,149,161,179).
+ * out[0..4] = sample, score, select+rescore, refine, total.  Synchronises. */
+int esac_hip_phase_ms(esac_hip_ctx* ctx, float out[5]);
+/* enable/disable the per-phase events (off by default: zero overhead) */
+int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESAC_HIP_H */

@@ -1,0 +1,107 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle on identical inputs + RNG key.
+
+Bars (BASELINE.json north_star): index work bit-exact (sampled cells, accepted try,
+winner, returned expert, inlier counts); pose within 1e-4 rad / 1e-3 m.
+"""
+import numpy as np
+import pytest
+import torch
+
+from esac_amd import api
+from esac_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL = 1e-4    # rad, north_star
+TRANS_TOL = 1e-3  # m,   north_star
+FAST_SCORE_TOL = 2e-3   # fp32 streaming score vs fp64 reference arithmetic, alpha = 100
+EXACT_SCORE_TOL = 1e-9  # fp64 "exact" kernel vs oracle
+
+
+def _run_both(engine, oracle, frame, ha, seed=1305, call=0, **kw):
+    sc = torch.from_numpy(frame["coords"]).cuda()
+    hat = torch.from_numpy(ha).cuda()
+    E, _, H, W = frame["coords"].shape
+    p = engine.make_params(E, H, W, len(ha), shift_x=frame["shift"][0], shift_y=frame["shift"][1],
+                           focal=frame["focal"], ppx=frame["ppx"], ppy=frame["ppy"], sub_sampling=frame["sub"],
+                           seed=seed, call=call, **kw)
+    res = engine.forward_device(sc, hat, p)
+    ref = oracle.forward(frame["coords"], ha, shift_x=frame["shift"][0], shift_y=frame["shift"][1],
+                         focal=frame["focal"], ppx=frame["ppx"], ppy=frame["ppy"], sub_sampling=frame["sub"],
+                         seed=seed, call=call, max_tries=kw.get("max_tries", 0), max_ref_steps=kw.get("max_ref_steps", -1))
+    return res, ref
+
+
+def _check_full(engine, res, ref):
+    # stage 1: sampling -- index work, bit-exact
+    np.testing.assert_array_equal(engine.read(api.BUF_TRIES), ref["tries"])
+    np.testing.assert_array_equal(engine.read(api.BUF_SAMPLE_XY), ref["sample_xy"])
+    hyps = engine.read(api.BUF_HYPS)
+    np.testing.assert_allclose(hyps, ref["hyps"], rtol=0, atol=1e-6)
+    # stage 2: scores
+    scores = engine.read(api.BUF_SCORES)
+    flags = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
+    np.testing.assert_allclose(scores[~flags], ref["scores"][~flags], rtol=0, atol=FAST_SCORE_TOL)
+    np.testing.assert_allclose(scores[flags], ref["scores"][flags], rtol=0, atol=EXACT_SCORE_TOL * 100)
+    # stage 3: winner -- index work
+    assert int(res[api.RES_HYP]) == ref["winner"]
+    assert int(res[api.RES_EXPERT]) == ref["expert"]
+    assert flags[ref["winner"]]
+    # stage 4: refinement -- discrete trace, then pose
+    assert int(res[api.RES_REF_STEPS]) == ref["ref_steps"]
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_MAP), ref["inlier_map"])
+    pose = res[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4)
+    r_err, t_err = S.pose_errors(pose, ref["pose"])
+    assert r_err <= ROT_TOL and t_err <= TRANS_TOL, (r_err, t_err)
+    np.testing.assert_allclose(res[api.RES_RVEC:api.RES_RVEC + 6], ref["refined"], rtol=0, atol=1e-6)
+    return r_err, t_err
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_config1_and_2_full_parity(engine, oracle, k):
+    """configs[0] (N=64) and configs[1] (N=256): 1 expert, 60x80 grid."""
+    f = S.make_frame(k)
+    for N in (64, 256):
+        ha = S.gating_assignment(f, N)
+        res, ref = _run_both(engine, oracle, f, ha, call=k)
+        _check_full(engine, res, ref)
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_config3_gating(engine, oracle, k):
+    """configs[2]: 10 experts, gating active, 1024 hypotheses (wrong-expert hypotheses need many tries)."""
+    f = S.make_frame(100 + k, E=10, true_expert=k)
+    ha = S.gating_assignment(f, 1024, mode="gating")
+    res, ref = _run_both(engine, oracle, f, ha, call=k)
+    _check_full(engine, res, ref)
+
+
+def test_exact_scores_all(engine, oracle):
+    f = S.make_frame(7)
+    ha = S.gating_assignment(f, 128)
+    res, ref = _run_both(engine, oracle, f, ha)
+    sc = torch.from_numpy(f["coords"]).cuda()
+    E, _, H, W = f["coords"].shape
+    p = engine.make_params(E, H, W, 128)
+    engine.write_hyps(ref["hyps"])
+    engine.score_exact(sc, torch.from_numpy(ha).cuda(), p)
+    np.testing.assert_allclose(engine.read(api.BUF_SCORES), ref["scores"], rtol=1e-12, atol=1e-10)
+
+
+def test_drop_in_module(oracle):
+    """`import esac; esac.forward(...)` with the reference's positional signature, CPU tensors in, in-place pose out."""
+    import esac
+    f = S.make_frame(11)
+    ha = S.gating_assignment(f, 256)
+    out_pose = torch.zeros(4, 4)
+    esac.set_seed(1305, 5)
+    expert = esac.forward(torch.from_numpy(f["coords"]), torch.from_numpy(ha), out_pose, 0, 0, f["focal"], f["ppx"],
+                          f["ppy"], 10.0, 100.0, 0.5, 100.0, 8)
+    ref = oracle.forward(f["coords"], ha, seed=1305, call=5)
+    assert isinstance(expert, int) and expert == ref["expert"]
+    r_err, t_err = S.pose_errors(out_pose.numpy(), ref["pose"])
+    assert r_err <= ROT_TOL and t_err <= TRANS_TOL
+    g_r, g_t = S.pose_errors(out_pose.numpy(), f["gt_pose"])
+    assert g_r < np.radians(5) and g_t < 0.05  # the 5cm/5deg criterion of test_esac.py:259
+    assert esac.get_rng_state() == (1305, 6)

@@ -121,11 +121,14 @@ def main():
     for i in range(args.warmup):
         step(i)
     phase = np.zeros(5, np.float64)
+    lm_iters = ref_steps = 0.0
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        r = step(args.warmup + i)
         phase += eng.phase_ms()
+        lm_iters += r[api.RES_LM_ITERS]
+        ref_steps += r[api.RES_REF_STEPS]
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -159,7 +162,8 @@ def main():
                        "grid": [H, W], "frames_cycled": n_frames,
                        "parallelism": "hypotheses sharded over %d GPU(s); 1 all-reduce(SUM) of N+32*world doubles" % world},
             "phase_ms": {"sample_p3p": float(phase[0]), "score": score_ms, "select_rescore": float(phase[2]),
-                         "refine": float(phase[3]), "gpu_total": float(phase[4])},
+                         "refine": float(phase[3]), "gpu_total": float(phase[4]),
+                         "refine_steps_per_frame": ref_steps / args.steps, "lm_iters_per_frame": lm_iters / args.steps},
             "roofline": {"kernel": "k_score_fast", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": None,

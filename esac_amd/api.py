@@ -24,7 +24,7 @@ from . import build as _build
 RES_SCORE, RES_HYP, RES_EXPERT, RES_RVEC, RES_TVEC, RES_POSE = 0, 1, 2, 3, 6, 9
 RES_REF_STEPS, RES_INLIERS, RES_PROB, RES_ENTROPY, RES_CONTENDERS, RES_LM_ITERS, RES_DOUBLES = 25, 26, 27, 28, 29, 30, 32
 BUF_HYPS, BUF_SAMPLE_XY, BUF_TRIES, BUF_SCORES, BUF_RESULT = 0, 1, 2, 3, 4
-BUF_INLIER_MAP, BUF_INLIER_COUNTS, BUF_WINNER_ERRS, BUF_EXACT_FLAGS = 5, 6, 7, 8
+BUF_INLIER_MAP, BUF_INLIER_COUNTS, BUF_WINNER_ERRS, BUF_EXACT_FLAGS, BUF_CYCLES = 5, 6, 7, 8, 9
 MAX_REF_STEPS = 100
 
 ABI_SYMBOLS = [
@@ -59,7 +59,7 @@ def load_library():
     with _lib_lock:
         if _lib is not None:
             return _lib
-        path = _build.LIB_PATH
+        path = os.environ.get("ESAC_HIP_LIB", _build.LIB_PATH)  # override: A/B builds of the same ABI
         if not os.path.exists(path):
             raise RuntimeError(
                 "esac: HIP extension %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -195,6 +195,7 @@ class Engine:
             BUF_SCORES: ((N,), np.float64), BUF_RESULT: ((RES_DOUBLES,), np.float64),
             BUF_INLIER_MAP: ((H, W), np.uint8), BUF_INLIER_COUNTS: ((MAX_REF_STEPS + 1,), np.int32),
             BUF_WINNER_ERRS: ((H, W), np.float32), BUF_EXACT_FLAGS: ((N,), np.uint8),
+            BUF_CYCLES: ((32,), np.int64),
         }
         shape, dt = shapes[which]
         out = np.zeros(shape, dt)

@@ -1,0 +1,159 @@
+// device_common.hpp -- cross-lane reductions and small helpers shared by the kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "esac_kernels.hpp"
+#include "pose_math.hpp"
+
+namespace esac {
+
+// ---------------------------------------------------------------- cross-lane sums
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    int x = __float_as_int(v);
+    x = __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
+    return __int_as_float(x);
+}
+// all 64 lanes end up with the same (bitwise identical) total
+__device__ __forceinline__ double wave_sum(double v) {
+    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);  // row_half_mirror
+    v += dpp_move<0x140>(v);  // row_mirror
+    {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    {
+        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_move<0xB1>(v);
+    v += dpp_move<0x4E>(v);
+    v += dpp_move<0x141>(v);
+    v += dpp_move<0x140>(v);
+    {
+        const unsigned x = __float_as_uint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+    {
+        const unsigned x = __float_as_uint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+    return v;
+}
+
+// Sum NV doubles over a workgroup of B threads.  Fixed combination order ->
+// run-to-run deterministic.  s_part: NV*(B/64) doubles, s_tot: NV doubles.
+template <int NV, int B>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_part, double* s_tot) {
+    constexpr int NW = B / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        const double w = wave_sum(v[k]);
+        if (lane == 0) s_part[wave * NV + k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) t += s_part[w * NV + threadIdx.x];
+        s_tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = s_tot[k];
+}
+
+// ---- transposed reduction of 28 doubles per lane ------------------------------------------------
+// A dependent fp64 add has ~32 cycles of latency on gfx950 (issue: 4) and the pipeline is in-order,
+// so 27 separate 6-stage butterflies cost ~6k cycles.  v_permlane32_swap / v_permlane16_swap
+// exchange half-waves / odd-even rows between TWO registers in one instruction:
+//     swap32(a, b): a' = [a.lo | b.lo], b' = [a.hi | b.hi]   ->  a' + b' = [sum_halves(a) | sum_halves(b)]
+// i.e. one swap + one add reduces two values by one stage AND halves the number of live values.
+// 28 values -> 14 -> 7 registers, then four DPP stages inside the 16-lane rows: ~150 instructions
+// instead of ~600, every stage issued value-interleaved.  Afterwards row r of register q holds the
+// wavefront total of value 4q + ((r & 1) << 1 | (r >> 1)).
+__device__ __forceinline__ double swap32_pairsum(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ double swap16_pairsum(double a, double b) {
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// Sum up to 28 doubles per thread over a workgroup of B threads; every thread receives all totals.
+// s_part: 28*(B/64) doubles, s_tot: 28 doubles.  Deterministic (fixed combination order).
+template <int NV, int B>
+__device__ __forceinline__ void block_sum28(double (&v)[NV], double* s_part, double* s_tot) {
+    static_assert(NV <= 28, "block_sum28 handles at most 28 values");
+    constexpr int NW = B / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double w[14], u[7];
+#pragma unroll
+    for (int p = 0; p < 14; p++) {
+        const double a = (2 * p < NV) ? v[2 * p] : 0.0;
+        const double b = (2 * p + 1 < NV) ? v[2 * p + 1] : 0.0;
+        w[p] = swap32_pairsum(a, b);
+    }
+#pragma unroll
+    for (int q = 0; q < 7; q++) u[q] = swap16_pairsum(w[2 * q], w[2 * q + 1]);
+#pragma unroll
+    for (int q = 0; q < 7; q++) u[q] += dpp_move<0xB1>(u[q]);
+#pragma unroll
+    for (int q = 0; q < 7; q++) u[q] += dpp_move<0x4E>(u[q]);
+#pragma unroll
+    for (int q = 0; q < 7; q++) u[q] += dpp_move<0x141>(u[q]);
+#pragma unroll
+    for (int q = 0; q < 7; q++) u[q] += dpp_move<0x140>(u[q]);
+    if ((lane & 15) == 0) {
+        const int r = lane >> 4;
+        const int sub = ((r & 1) << 1) | (r >> 1);
+#pragma unroll
+        for (int q = 0; q < 7; q++) s_part[wave * 28 + 4 * q + sub] = u[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 28) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) t += s_part[k * 28 + threadIdx.x];
+        s_tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = s_tot[k];
+}
+
+__device__ __forceinline__ Cam make_cam(const KArgs& a) {
+    // camMat is a float matrix widened to double by the solver (esac.cpp:93-97)
+    return Cam{(double)a.focal, (double)a.focal, (double)a.ppx, (double)a.ppy};
+}
+// createSampling (esac_util.h:64-66): integer pixel centre of cell (x,y), then Point2f
+// global hypothesis index: keys the RNG stream and breaks ties, independent of the sharding
+__device__ __forceinline__ int global_hyp(const KArgs& a, int h) { return a.hyp_index ? a.hyp_index[h] : a.hyp_offset + h; }
+__device__ __forceinline__ float cell_px(const KArgs& a, int x) { return (float)(x * a.sub + a.sub / 2 - a.shift_x); }
+__device__ __forceinline__ float cell_py(const KArgs& a, int y) { return (float)(y * a.sub + a.sub / 2 - a.shift_y); }
+
+
+}  // namespace esac

@@ -58,7 +58,7 @@ extern "C" int esac_hip_device_count(void) {
 static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.contenders, c->ws.n_contenders, c->ws.stats,
-                    c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result};
+                    c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws = KArgs{};
@@ -114,9 +114,15 @@ static int ensure_ws(esac_hip_ctx* c, int N, int P) {
     rc |= alloc(&c->ws.n_contenders, 4);
     rc |= alloc(&c->ws.stats, 4);
     rc |= alloc(&c->ws.errs, (size_t)nP);
-    rc |= alloc(&c->ws.inlier_map, (size_t)nP);
+    rc |= alloc(&c->ws.inlier_map, (size_t)nP * 2);  // two buffers, see esac_refine.hip
+    {
+        char* cl = nullptr;
+        rc |= alloc(&cl, (size_t)nP * 16);
+        c->ws.corr_list = cl;
+    }
     rc |= alloc(&c->ws.inlier_counts, (size_t)ESAC_MAX_REF_STEPS + 1);
     rc |= alloc(&c->ws.result, (size_t)ESAC_RES_DOUBLES);
+    rc |= alloc(&c->ws.cycles, (size_t)32);
     if (rc) return rc;
     HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
     HIP_OK(hipMemset(c->ws.result, 0, ESAC_RES_DOUBLES * sizeof(double)));
@@ -251,10 +257,24 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
         case ESAC_BUF_TRIES: src = c->ws.tries; want = N * sizeof(int32_t); break;
         case ESAC_BUF_SCORES: src = c->ws.scores; want = N * sizeof(double); break;
         case ESAC_BUF_RESULT: src = c->ws.result; want = ESAC_RES_DOUBLES * sizeof(double); break;
-        case ESAC_BUF_INLIER_MAP: src = c->ws.inlier_map; want = P; break;
+        case ESAC_BUF_INLIER_MAP: {
+            // the refinement kernel alternates between two map buffers; result[31] names the one that
+            // holds the last ACCEPTED inlier set (-1: no re-fit was accepted -> all zeros)
+            if (bytes != P) return fail(-7, "esac_hip_read: inlier map holds %zu bytes, caller asked for %zu", P, bytes);
+            HIP_OK(hipDeviceSynchronize());
+            double which_buf = -1;
+            HIP_OK(hipMemcpy(&which_buf, c->ws.result + 31, sizeof(double), hipMemcpyDeviceToHost));
+            if (which_buf < 0) {
+                memset(h_dst, 0, P);
+                return 0;
+            }
+            HIP_OK(hipMemcpy(h_dst, c->ws.inlier_map + (which_buf > 0.5 ? P : 0), P, hipMemcpyDeviceToHost));
+            return 0;
+        }
         case ESAC_BUF_INLIER_COUNTS: src = c->ws.inlier_counts; want = (ESAC_MAX_REF_STEPS + 1) * sizeof(int32_t); break;
         case ESAC_BUF_WINNER_ERRS: src = c->ws.errs; want = P * sizeof(float); break;
         case ESAC_BUF_EXACT_FLAGS: src = c->ws.exact_flag; want = N; break;
+        case ESAC_BUF_CYCLES: src = c->ws.cycles; want = 32 * sizeof(long long); break;
         default: return fail(-5, "esac_hip_read: unknown buffer id %d", which);
     }
     if (!src || want == 0) return fail(-6, "esac_hip_read: buffer %d is empty (no call has run yet)", which);

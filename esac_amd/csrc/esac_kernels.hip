@@ -27,93 +27,9 @@
 #include "pose_math.hpp"
 #include "rng.hpp"
 #include "esac_kernels.hpp"
+#include "device_common.hpp"
 
 namespace esac {
-
-// ---------------------------------------------------------------- cross-lane sums
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v) {
-    int x = __float_as_int(v);
-    x = __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
-    return __int_as_float(x);
-}
-// all 64 lanes end up with the same (bitwise identical) total
-__device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_move<0x141>(v);  // row_half_mirror
-    v += dpp_move<0x140>(v);  // row_mirror
-    {
-        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-    }
-    {
-        const unsigned lo = __double2loint(v), hi = __double2hiint(v);
-        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
-    }
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_move<0xB1>(v);
-    v += dpp_move<0x4E>(v);
-    v += dpp_move<0x141>(v);
-    v += dpp_move<0x140>(v);
-    {
-        const unsigned x = __float_as_uint(v);
-        const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    }
-    {
-        const unsigned x = __float_as_uint(v);
-        const auto a = __builtin_amdgcn_permlane32_swap(x, x, false, false);
-        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-    }
-    return v;
-}
-
-// Sum NV doubles over a workgroup of B threads.  Fixed combination order ->
-// run-to-run deterministic.  s_part: NV*(B/64) doubles, s_tot: NV doubles.
-template <int NV, int B>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_part, double* s_tot) {
-    constexpr int NW = B / 64;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-        const double w = wave_sum(v[k]);
-        if (lane == 0) s_part[wave * NV + k] = w;
-    }
-    __syncthreads();
-    if (threadIdx.x < NV) {
-        double t = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) t += s_part[w * NV + threadIdx.x];
-        s_tot[threadIdx.x] = t;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = s_tot[k];
-}
-
-__device__ __forceinline__ Cam make_cam(const KArgs& a) {
-    // camMat is a float matrix widened to double by the solver (esac.cpp:93-97)
-    return Cam{(double)a.focal, (double)a.focal, (double)a.ppx, (double)a.ppy};
-}
-// createSampling (esac_util.h:64-66): integer pixel centre of cell (x,y), then Point2f
-// global hypothesis index: keys the RNG stream and breaks ties, independent of the sharding
-__device__ __forceinline__ int global_hyp(const KArgs& a, int h) { return a.hyp_index ? a.hyp_index[h] : a.hyp_offset + h; }
-__device__ __forceinline__ float cell_px(const KArgs& a, int x) { return (float)(x * a.sub + a.sub / 2 - a.shift_x); }
-__device__ __forceinline__ float cell_py(const KArgs& a, int y) { return (float)(y * a.sub + a.sub / 2 - a.shift_y); }
 
 // ================================================================= K1: sample + P3P
 __global__ __launch_bounds__(64) void k_sample(KArgs a) {
@@ -375,224 +291,6 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a, int all) {
     }
 }
 
-// ================================================================= K4: pick winner, refine, emit pose
-template <int B>
-__global__ __launch_bounds__(B) void k_refine(KArgs a) {
-    __shared__ double s_part[28 * (B / 64)];
-    __shared__ double s_tot[28];
-    __shared__ double s_best[B / 64];
-    __shared__ int s_besti[B / 64];
-    __shared__ int s_bestg[B / 64];
-    const int P = a.H * a.W;
-    const Cam cam = make_cam(a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    // ---- draw(probs, training=false): argmax, first index on ties (esac_util.h:512-529)
-    const int nc = a.n_contenders[0];
-    double bs = -INFINITY;
-    int bi = 0x7fffffff;  // local index of the best so far; ties go to the lowest GLOBAL index
-    int bg = 0x7fffffff;
-    for (int c = threadIdx.x; c < nc; c += B) {
-        const int h = a.contenders[c];
-        const int g = global_hyp(a, h);
-        const double s = a.scores[h];
-        if (s > bs || (s == bs && g < bg)) {
-            bs = s;
-            bi = h;
-            bg = g;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double os = __shfl_xor(bs, o);
-        const int oi = __shfl_xor(bi, o);
-        const int og = __shfl_xor(bg, o);
-        if (os > bs || (os == bs && og < bg)) {
-            bs = os;
-            bi = oi;
-            bg = og;
-        }
-    }
-    if (lane == 0) {
-        s_best[wave] = bs;
-        s_besti[wave] = bi;
-        s_bestg[wave] = bg;
-    }
-    __syncthreads();
-    bs = s_best[0];
-    bi = s_besti[0];
-    bg = s_bestg[0];
-#pragma unroll
-    for (int w = 1; w < B / 64; w++) {
-        const double os = s_best[w];
-        const int oi = s_besti[w];
-        const int og = s_bestg[w];
-        if (os > bs || (os == bs && og < bg)) {
-            bs = os;
-            bi = oi;
-            bg = og;
-        }
-    }
-    const int win = (bi == 0x7fffffff) ? 0 : bi;
-    const double win_score = a.scores[win];
-    const int e = (int)a.assign[win];
-    const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
-
-    double pose[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
-
-    // ---- refineHyp (esac_util.h:378-454)
-    double R[9];
-    rodrigues_vec2mat<false>(pose, R, nullptr);
-    int n_inl = 0;
-    {   // error image of the selected hypothesis (reproErrs[hypIdx], esac.cpp:169)
-        int c = 0;
-        for (int i = threadIdx.x; i < P; i += B) {
-            const int row = i / a.W, col = i - row * a.W;
-            float err = project_exact_err(R, pose + 3, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
-            err = err < a.max_reproj ? err : a.max_reproj;
-            a.errs[i] = err;
-            a.inlier_map[i] = 0;
-            c += (err < a.tau) ? 1 : 0;
-        }
-        // per-thread counts -> workgroup total (through the double path: exact for counts < 2^53)
-        double cc[1] = {(double)c};
-        block_sum<1, B>(cc, s_part, s_tot);
-        n_inl = (int)cc[0];
-    }
-    for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;
-    __syncthreads();
-
-    unsigned best_inliers = 4;
-    int accepted = 0, last_inliers = 0, lm_total = 0;
-    for (int rstep = 0; rstep < a.max_ref_steps; rstep++) {
-        if (threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
-        if ((unsigned)n_inl <= best_inliers) break;  // converged
-        best_inliers = (unsigned)n_inl;
-
-        // ---- solvePnP(ITERATIVE, useExtrinsicGuess) on the inliers: Levenberg-Marquardt,
-        //      6 parameters, <=20 iterations, eps = FLT_EPSILON, lambda = 10^k
-        double param[6], prev[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) param[k] = pose[k];
-        int lambda_lg10 = -3, iters = 0;
-        double prev_err_norm = 1.7976931348623157e308;
-        for (;;) {
-            double Rm[9], dRdr[27];
-            rodrigues_vec2mat<true>(param, Rm, dRdr);
-            double acc[28];
-#pragma unroll
-            for (int k = 0; k < 28; k++) acc[k] = 0;
-            for (int i = threadIdx.x; i < P; i += B) {
-                if (a.errs[i] < a.tau) {
-                    const int row = i / a.W, col = i - row * a.W;
-                    double ex, ey, Ju[6], Jv[6];
-                    pnp_point_terms(Rm, dRdr, param + 3, cam, (double)mx[i], (double)mx[P + i], (double)mx[2 * P + i],
-                                    (double)cell_px(a, col), (double)cell_py(a, row), ex, ey, Ju, Jv);
-                    int k = 0;
-#pragma unroll
-                    for (int r = 0; r < 6; r++)
-#pragma unroll
-                        for (int c = r; c < 6; c++) {
-                            acc[k] += Ju[r] * Ju[c] + Jv[r] * Jv[c];
-                            k++;
-                        }
-#pragma unroll
-                    for (int r = 0; r < 6; r++) acc[21 + r] += Ju[r] * ex + Jv[r] * ey;
-                    acc[27] += ex * ex + ey * ey;
-                }
-            }
-            block_sum<28, B>(acc, s_part, s_tot);
-#pragma unroll
-            for (int k = 0; k < 6; k++) prev[k] = param[k];
-            if (iters == 0) prev_err_norm = sqrt(acc[27]);
-            double err_norm;
-            for (;;) {
-                // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
-                const double lambda = exp(lambda_lg10 * 2.302585092994046);
-                double dx[6];
-                lm_solve6(acc, acc + 21, lambda, dx);
-#pragma unroll
-                for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
-                // CHECK_ERR: residual norm at the stepped parameters
-                double Rn[9];
-                rodrigues_vec2mat<false>(param, Rn, nullptr);
-                double e2[1] = {0};
-                for (int i = threadIdx.x; i < P; i += B) {
-                    if (a.errs[i] < a.tau) {
-                        const int row = i / a.W, col = i - row * a.W;
-                        double ex, ey;
-                        pnp_point_residual(Rn, param + 3, cam, (double)mx[i], (double)mx[P + i], (double)mx[2 * P + i],
-                                           (double)cell_px(a, col), (double)cell_py(a, row), ex, ey);
-                        e2[0] += ex * ex + ey * ey;
-                    }
-                }
-                block_sum<1, B>(e2, s_part, s_tot);
-                err_norm = sqrt(e2[0]);
-                if (err_norm > prev_err_norm) {
-                    if (++lambda_lg10 <= 16) continue;
-                }
-                break;
-            }
-            lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
-            double dn = 0, pn = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                dn += (param[k] - prev[k]) * (param[k] - prev[k]);
-                pn += prev[k] * prev[k];
-            }
-            const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
-            ++iters;
-            if (iters >= 20 || rel < (double)FLT_EPSILON) break;
-            prev_err_norm = err_norm;
-        }
-        lm_total += iters;
-#pragma unroll
-        for (int k = 0; k < 6; k++) pose[k] = param[k];
-        accepted++;
-        last_inliers = n_inl;
-
-        // accept: inlierMap = this step's inlier set (esac_util.h:440); new error image (esac_util.h:445-452)
-        rodrigues_vec2mat<false>(pose, R, nullptr);
-        int c = 0;
-        for (int i = threadIdx.x; i < P; i += B) {
-            const int row = i / a.W, col = i - row * a.W;
-            a.inlier_map[i] = (a.errs[i] < a.tau) ? 1 : 0;
-            float err = project_exact_err(R, pose + 3, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
-            err = err < a.max_reproj ? err : a.max_reproj;
-            a.errs[i] = err;
-            c += (err < a.tau) ? 1 : 0;
-        }
-        double cc[1] = {(double)c};
-        block_sum<1, B>(cc, s_part, s_tot);
-        n_inl = (int)cc[0];
-    }
-
-    // ---- pose2trans (esac_util.h:537-548) and the result record
-    if (threadIdx.x == 0) {
-        rodrigues_vec2mat<false>(pose, R, nullptr);
-        double T[16];
-        pose_to_inverse_transform(R, pose + 3, T);
-        double* r = a.result;
-        r[ESAC_RES_SCORE_K] = win_score;
-        r[ESAC_RES_HYP_K] = (double)global_hyp(a, win);
-        r[ESAC_RES_EXPERT_K] = (double)e;
-#pragma unroll
-        for (int k = 0; k < 6; k++) r[ESAC_RES_RVEC_K + k] = pose[k];
-#pragma unroll
-        for (int k = 0; k < 16; k++) r[ESAC_RES_POSE_K + k] = (double)(float)T[k];
-        r[ESAC_RES_REF_STEPS_K] = (double)accepted;
-        r[ESAC_RES_INLIERS_K] = (double)last_inliers;
-        const double smax = a.stats[0], ssum = a.stats[1];
-        r[ESAC_RES_PROB_K] = exp(win_score - smax) / ssum;
-        r[ESAC_RES_ENTROPY_K] = a.stats[2];
-        r[ESAC_RES_CONTENDERS_K] = (double)nc;
-        r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
-        r[31] = 0;
-    }
-}
-
 // ---------------------------------------------------------------- launchers
 void launch_sample(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_sample, dim3(a.N), dim3(64), 0, s, a); }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
@@ -606,6 +304,5 @@ void launch_rescore(const KArgs& a, int all, hipStream_t s) {
     const int grid = all ? (a.N < 4096 ? a.N : 4096) : (a.N < 256 ? a.N : 256);
     hipLaunchKernelGGL(k_rescore<256>, dim3(grid), dim3(256), 0, s, a, all);
 }
-void launch_refine(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_refine<512>, dim3(1), dim3(512), 0, s, a); }
 
 }  // namespace esac

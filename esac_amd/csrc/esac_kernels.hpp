@@ -35,9 +35,11 @@ struct KArgs {
     int* n_contenders;    // [1]
     double* stats;        // [4] max, sum exp, entropy
     float* errs;          // [P]
-    uint8_t* inlier_map;  // [P]
+    uint8_t* inlier_map;  // [2,P] two alternating buffers; result[31] names the accepted one
+    void* corr_list;      // [P] 16-byte correspondences: refinement fallback when the inliers exceed LDS
     int* inlier_counts;   // [ESAC_MAX_REF_STEPS_K+1]
     double* result;       // [32]
+    long long* cycles;    // [32] shader-cycle counters of the refinement kernel's sections (profiling aid)
 };
 
 void launch_sample(const KArgs& a, hipStream_t s);

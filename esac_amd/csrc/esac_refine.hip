@@ -1,0 +1,430 @@
+// esac_refine.hip -- K4: draw(argmax) + refineHyp + pose2trans in ONE workgroup, no host round trips.
+//
+// Reference: esac.cpp:153-187, refineHyp esac_util.h:378-454, draw esac_util.h:505-530,
+// pose2trans esac_util.h:537-548.  The reference runs this serially on one CPU thread
+// (esac.cpp:167 is outside every omp region); here it is the latency-critical tail of
+// the whole call.  On gfx950 a DEPENDENT fp64 op costs ~32 cycles (issue: 4) and the
+// pipeline is in-order, so everything below is organised to keep independent fp64
+// work adjacent in the instruction stream and the dependent chains short:
+//   * one fused pass computes the exact error image of the current pose, the inlier
+//     count AND the compacted inlier list of the next re-fit (16 B per correspondence in
+//     LDS: x,y,z + packed pixel), four points per lane in flight, loads issued up front;
+//   * per-point LM work is the twist-space Jacobian of lm_math.hpp (~80 fp64 ops), two
+//     correspondences per lane interleaved, Newton reciprocal instead of IEEE division;
+//   * the 27 fp64 sums of a pass are reduced with v_permlane32/16_swap pair-sums
+//     (halving the live values per stage) + DPP row stages (device_common.hpp);
+//   * every lane carries the 6-parameter LM state redundantly: all lanes take the same
+//     branches from the same reduced sums, so nothing is broadcast;
+//   * the pass at a trial point already accumulates the normal equations there
+//     (speculative Jacobian): an accepted step -- the common case -- costs one pass.
+// All discrete decisions (inlier test `err < tau`, stopping rule, argmax) use the
+// reference's exact arithmetic (project_exact_err, contraction off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "device_common.hpp"
+#include "esac_kernels.hpp"
+#include "lm_math.hpp"
+#include "pose_math.hpp"
+
+namespace esac {
+
+#ifndef ESAC_REFINE_B
+#define ESAC_REFINE_B 256
+#endif
+constexpr int REFINE_B = ESAC_REFINE_B;  // default 4 wavefronts = one per SIMD of the one CU this kernel occupies
+constexpr int LDS_CAP = 8192;            // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
+#ifndef ESAC_ERR_UNROLL
+#define ESAC_ERR_UNROLL 4
+#endif
+#ifndef ESAC_LM_NP
+#define ESAC_LM_NP 2
+#endif
+constexpr int ERR_UNROLL = ESAC_ERR_UNROLL;  // points per lane in flight in the exact error pass
+constexpr int LM_NP = ESAC_LM_NP;            // correspondences per lane in flight in an LM pass
+
+// Section cycle counters (clock64 = shader clock), enabled with -DESAC_PROFILE_CYCLES; index:
+// 0 total, 1 argmax, 2 error image + compaction, 3 unused, 4 rodrigues+chain, 5 point loop, 6 block_sum,
+// 7 transform, 8 solve, 9 number of passes
+#ifdef ESAC_PROFILE_CYCLES
+#define CYC_DECL long long cyc_t0_
+#define CYC_BEGIN() cyc_t0_ = clock64()
+#define CYC_END(idx) g_cyc[idx] += clock64() - cyc_t0_
+#define CYC_ADD(idx, v) g_cyc[idx] += (v)
+#else
+#define CYC_DECL
+#define CYC_BEGIN()
+#define CYC_END(idx)
+#define CYC_ADD(idx, v)
+#endif
+
+struct __attribute__((aligned(16))) Corr {
+    float x, y, z;
+    uint32_t px_py;  // pixel position of the cell, two signed 16-bit integers: py << 16 | (px & 0xffff)
+};
+
+__device__ __forceinline__ int cell_pxi(const KArgs& a, int col) { return col * a.sub + a.sub / 2 - a.shift_x; }
+__device__ __forceinline__ int cell_pyi(const KArgs& a, int row) { return row * a.sub + a.sub / 2 - a.shift_y; }
+
+// 10^k, |k| <= 31, by binary exponentiation (the CPU library evaluates exp(k*log(10)))
+__device__ __forceinline__ double pow10_int(int k) {
+    double r = 1.0;
+    const int n = k < 0 ? -k : k;
+    double b = 10.0;
+#pragma unroll
+    for (int bit = 0; bit < 5; bit++) {
+        if (n & (1 << bit)) r *= b;
+        b *= b;
+    }
+    return k < 0 ? 1.0 / r : r;
+}
+
+// Fused pass over the whole grid at `pose`:
+//   a.errs[i]  = min(exact reprojection error, maxReproj)          (getReproErrs, esac_util.h:292-360)
+//   map_out[i] = err < tau                                         (localInlierMap, esac_util.h:401-414)
+//   list[...]  = the inliers, compacted in index order (deterministic), at most `cap`
+// Returns the inlier count (same value in every thread).
+template <int B, typename ListPtr>
+__device__ __forceinline__ int error_pass(const KArgs& a, const float* __restrict__ mx, int P, const double pose[6],
+                                          const Cam& cam, ListPtr list, int cap, uint8_t* __restrict__ map_out,
+                                          int* s_wcnt) {
+    constexpr int U = ERR_UNROLL, NW = B / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double R[9];
+    rodrigues_vec2mat<false>(pose, R, nullptr);
+    int base = 0;
+    for (int start = 0; start < P; start += B * U) {
+        float X[U], Y[U], Z[U];
+        int pxi[U], pyi[U];
+        bool flag[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {  // all loads first: one memory latency for the U points
+            const int i = start + u * B + threadIdx.x;
+            const int ic = i < P ? i : P - 1;
+            X[u] = mx[ic];
+            Y[u] = mx[P + ic];
+            Z[u] = mx[2 * P + ic];
+            const int row = ic / a.W, col = ic - row * a.W;
+            pxi[u] = cell_pxi(a, col);
+            pyi[u] = cell_pyi(a, row);
+        }
+        float pxf[U], pyf[U], errv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            pxf[u] = (float)pxi[u];
+            pyf[u] = (float)pyi[u];
+        }
+        project_exact_err_batch<U>(R, pose + 3, cam, X, Y, Z, pxf, pyf, errv);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = start + u * B + threadIdx.x;
+            float err = errv[u];
+            err = err < a.max_reproj ? err : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+            flag[u] = (i < P) && (err < a.tau);
+            if (i < P) {
+                a.errs[i] = err;
+                map_out[i] = flag[u] ? 1 : 0;
+            }
+        }
+        int within[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned long long m = __ballot(flag[u]);
+            within[u] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wcnt[u * NW + wave] = __popcll(m);
+        }
+        __syncthreads();
+        int off = base;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const int c = s_wcnt[u * NW + w];
+                woff += (w < wave) ? c : 0;
+                total += c;
+            }
+            if (flag[u]) {
+                const int slot = off + woff + within[u];
+                if (slot < cap)
+                    list[slot] = Corr{X[u], Y[u], Z[u], ((uint32_t)pyi[u] << 16) | ((uint32_t)pxi[u] & 0xffffu)};
+            }
+            off += total;
+        }
+        base = off;
+        __syncthreads();
+    }
+    return base;
+}
+
+// One pass over the compacted correspondences at `param`: residual norm^2 (returned) and the
+// (rvec,tvec)-space normal equations U21 / g6 at that point.
+template <int B, typename ListPtr>
+__device__ __forceinline__ double lm_pass(ListPtr list, int n, const double param[6], const Cam& cam, double U21[21],
+                                          double g6[6], double* s_part, double* s_tot, long long* g_cyc) {
+    CYC_DECL;
+    CYC_BEGIN();
+    double R[9];
+    LmChain ch;
+    {
+        double dRdr[27];
+        rodrigues_vec2mat<true>(param, R, dRdr);
+        lm_chain(R, dRdr, param + 3, ch);
+    }
+    CYC_END(4);
+    CYC_BEGIN();
+    double acc[LM_NACC];
+#pragma unroll
+    for (int k = 0; k < LM_NACC; k++) acc[k] = 0;
+    // LM_NP correspondences per lane per trip, evaluated stage by stage (lm_accumulate_points)
+    int j = threadIdx.x;
+    for (; j + (LM_NP - 1) * B < n; j += LM_NP * B) {
+        double X[LM_NP], Y[LM_NP], Z[LM_NP], mxp[LM_NP], myp[LM_NP], wgt[LM_NP];
+#pragma unroll
+        for (int p = 0; p < LM_NP; p++) {
+            const Corr c = list[j + p * B];
+            X[p] = (double)c.x; Y[p] = (double)c.y; Z[p] = (double)c.z;
+            mxp[p] = (double)(int)(short)(c.px_py & 0xffffu);
+            myp[p] = (double)((int)c.px_py >> 16);
+            wgt[p] = 1.0;
+        }
+        lm_accumulate_points<LM_NP, false>(R, param + 3, cam, X, Y, Z, mxp, myp, wgt, acc);
+    }
+    if (j < n) {  // ragged tail: same code with the missing correspondences weighted 0
+        double X[LM_NP], Y[LM_NP], Z[LM_NP], mxp[LM_NP], myp[LM_NP], wgt[LM_NP];
+#pragma unroll
+        for (int p = 0; p < LM_NP; p++) {
+            const int jj = j + p * B;
+            const Corr c = list[jj < n ? jj : j];
+            X[p] = (double)c.x; Y[p] = (double)c.y; Z[p] = (double)c.z;
+            mxp[p] = (double)(int)(short)(c.px_py & 0xffffu);
+            myp[p] = (double)((int)c.px_py >> 16);
+            wgt[p] = jj < n ? 1.0 : 0.0;
+        }
+        lm_accumulate_points<LM_NP, true>(R, param + 3, cam, X, Y, Z, mxp, myp, wgt, acc);
+    }
+    CYC_END(5);
+    CYC_BEGIN();
+    block_sum28<LM_NACC, B>(acc, s_part, s_tot);
+    CYC_END(6);
+    CYC_BEGIN();
+    lm_transform(acc, ch, U21, g6);
+    CYC_END(7);
+    CYC_ADD(9, 1);
+    return acc[26];
+}
+
+// cv::solvePnP(ITERATIVE, useExtrinsicGuess): CvLevMarq with 6 parameters, max_iter 20, eps FLT_EPSILON,
+// lambda = 10^k from k = -3, k++ while a step made the error worse (<= 16), k-- after an accepted step.
+template <int B, typename ListPtr>
+__device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], const Cam& cam, double* s_part,
+                                        double* s_tot, long long* g_cyc) {
+    CYC_DECL;
+    double param[6], prev[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) param[k] = pose[k];
+    double U21[21], g6[6];    // normal equations at `prev` (state CALC_J)
+    double U21t[21], g6t[6];  // ... at the trial point
+    double prev_err_norm = sqrt(lm_pass<B>(list, n, param, cam, U21, g6, s_part, s_tot, g_cyc));
+    int lambda_lg10 = -3, iters = 0;
+    for (;;) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) prev[k] = param[k];
+        double err_norm;
+        for (;;) {
+            // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
+            const double lambda = pow10_int(lambda_lg10);
+            double dx[6];
+            CYC_BEGIN();
+            lm_solve6(U21, g6, lambda, dx);
+            CYC_END(8);
+#pragma unroll
+            for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
+            // state CHECK_ERR at the trial point; the same pass gathers the normal equations there
+            err_norm = sqrt(lm_pass<B>(list, n, param, cam, U21t, g6t, s_part, s_tot, g_cyc));
+            if (err_norm > prev_err_norm) {
+                if (++lambda_lg10 <= 16) continue;
+            }
+            break;
+        }
+        lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
+        double dn = 0, pn = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            dn += (param[k] - prev[k]) * (param[k] - prev[k]);
+            pn += prev[k] * prev[k];
+        }
+        const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);  // cvNorm(param, prevParam, CV_RELATIVE_L2)
+        ++iters;
+        if (iters >= 20 || rel < (double)FLT_EPSILON) break;
+        prev_err_norm = err_norm;
+#pragma unroll
+        for (int k = 0; k < 21; k++) U21[k] = U21t[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) g6[k] = g6t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose[k] = param[k];
+    return iters;
+}
+
+// refineHyp (esac_util.h:378-454) with the correspondence list in LDS or in global memory
+template <int B, typename ListPtr>
+__device__ __forceinline__ void refine_loop(const KArgs& a, const float* __restrict__ mx, int P, const Cam& cam,
+                                            ListPtr list, int cap, double pose[6], int* s_wcnt, double* s_part,
+                                            double* s_tot, int& accepted, int& last_inliers, int& lm_total,
+                                            int& map_buf, long long* g_cyc) {
+    CYC_DECL;
+    CYC_BEGIN();
+    int cur = 0;  // map buffer the NEXT error pass writes
+    int n_inl = error_pass<B>(a, mx, P, pose, cam, list, cap, a.inlier_map, s_wcnt);  // reproErrs[hypIdx], esac.cpp:169
+    __syncthreads();
+    CYC_END(2);
+    unsigned best_inliers = 4;
+    for (int rstep = 0; rstep < a.max_ref_steps; rstep++) {
+        if (threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
+        if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
+        best_inliers = (unsigned)n_inl;
+        lm_total += lm_refit<B>(list, n_inl, pose, cam, s_part, s_tot, g_cyc);
+        accepted++;
+        last_inliers = n_inl;
+        map_buf = cur;  // inlierMap = this step's set (esac_util.h:440)
+        cur ^= 1;
+        CYC_BEGIN();
+        __syncthreads();  // every lane is done reading the list before it is rebuilt
+        n_inl = error_pass<B>(a, mx, P, pose, cam, list, cap, a.inlier_map + (size_t)cur * P, s_wcnt);  // esac_util.h:445-452
+        __syncthreads();
+        CYC_END(2);
+    }
+}
+
+template <int B>
+__global__ __launch_bounds__(B) void k_refine(KArgs a) {
+    __shared__ Corr s_list[LDS_CAP];
+    __shared__ double s_part[28 * (B / 64)];
+    __shared__ double s_tot[28];
+    __shared__ double s_best[B / 64];
+    __shared__ int s_besti[B / 64];
+    __shared__ int s_bestg[B / 64];
+    __shared__ int s_wcnt[ERR_UNROLL * (B / 64)];
+    const int P = a.H * a.W;
+    const Cam cam = make_cam(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long g_cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)g_cyc;
+    CYC_DECL;
+#ifdef ESAC_PROFILE_CYCLES
+    const long long cyc_start = clock64();
+#endif
+    CYC_BEGIN();
+
+    // ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties
+    //      (esac_util.h:512-529; softmax is monotone, so the argmax of the scores is the argmax of the probabilities)
+    const int nc = a.n_contenders[0];
+    double bs = -INFINITY;
+    int bi = 0x7fffffff, bg = 0x7fffffff;
+    for (int c = threadIdx.x; c < nc; c += B) {
+        const int h = a.contenders[c];
+        const int g = global_hyp(a, h);
+        const double s = a.scores[h];
+        if (s > bs || (s == bs && g < bg)) {
+            bs = s;
+            bi = h;
+            bg = g;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(bs, o);
+        const int oi = __shfl_xor(bi, o);
+        const int og = __shfl_xor(bg, o);
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    if (lane == 0) {
+        s_best[wave] = bs;
+        s_besti[wave] = bi;
+        s_bestg[wave] = bg;
+    }
+    __syncthreads();
+    bs = s_best[0];
+    bi = s_besti[0];
+    bg = s_bestg[0];
+#pragma unroll
+    for (int w = 1; w < B / 64; w++) {
+        const double os = s_best[w];
+        const int oi = s_besti[w];
+        const int og = s_bestg[w];
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    const int win = (bi == 0x7fffffff) ? 0 : bi;
+    const double win_score = a.scores[win];
+    const int e = (int)a.assign[win];
+    const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
+
+    double pose[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
+    for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;
+    __syncthreads();
+    CYC_END(1);
+
+    int accepted = 0, last_inliers = 0, lm_total = 0, map_buf = -1;
+    if (P <= LDS_CAP)
+        refine_loop<B>(a, mx, P, cam, (Corr*)s_list, LDS_CAP, pose, s_wcnt, s_part, s_tot, accepted, last_inliers,
+                       lm_total, map_buf, g_cyc);
+    else
+        refine_loop<B>(a, mx, P, cam, reinterpret_cast<Corr*>(a.corr_list), P, pose, s_wcnt, s_part, s_tot, accepted,
+                       last_inliers, lm_total, map_buf, g_cyc);
+
+    // ---- pose2trans (esac_util.h:537-548) and the result record
+    if (threadIdx.x == 0) {
+        double R[9];
+        rodrigues_vec2mat<false>(pose, R, nullptr);
+        double T[16];
+        pose_to_inverse_transform(R, pose + 3, T);
+        double* r = a.result;
+        r[ESAC_RES_SCORE_K] = win_score;
+        r[ESAC_RES_HYP_K] = (double)global_hyp(a, win);
+        r[ESAC_RES_EXPERT_K] = (double)e;
+#pragma unroll
+        for (int k = 0; k < 6; k++) r[ESAC_RES_RVEC_K + k] = pose[k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) r[ESAC_RES_POSE_K + k] = (double)(float)T[k];
+        r[ESAC_RES_REF_STEPS_K] = (double)accepted;
+        r[ESAC_RES_INLIERS_K] = (double)last_inliers;
+        const double smax = a.stats[0], ssum = a.stats[1];
+        r[ESAC_RES_PROB_K] = exp(win_score - smax) / ssum;
+        r[ESAC_RES_ENTROPY_K] = a.stats[2];
+        r[ESAC_RES_CONTENDERS_K] = (double)nc;
+        r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
+        r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
+#ifdef ESAC_PROFILE_CYCLES
+        g_cyc[0] = clock64() - cyc_start;
+        for (int k = 0; k < 10; k++) a.cycles[k] = g_cyc[k];
+#endif
+    }
+}
+
+void launch_refine(const KArgs& a, hipStream_t s) {
+    // ESAC_REFINE_B=512 selects the two-wavefronts-per-SIMD build (tuning knob, default REFINE_B)
+    static const int block = [] {
+        const char* e = getenv("ESAC_REFINE_B");
+        const int v = e ? atoi(e) : REFINE_B;
+        return v == 512 ? 512 : 256;
+    }();
+    if (block == 256)
+        hipLaunchKernelGGL(k_refine<256>, dim3(1), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_refine<512>, dim3(1), dim3(512), 0, s, a);
+}
+
+}  // namespace esac

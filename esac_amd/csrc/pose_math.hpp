@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 
+#define ESAC_HD __host__ __device__ __forceinline__
+
 namespace esac {
 
 struct Cam {
@@ -25,7 +27,7 @@ struct Cam {
 // ---------------------------------------------------------------- Rodrigues
 // vector -> matrix (row-major R[9]); optional d vec(R) / d r as J[i*9+k], i = r component.
 template <bool WITH_JAC>
-__device__ __forceinline__ void rodrigues_vec2mat(const double r[3], double R[9], double* J) {
+ESAC_HD void rodrigues_vec2mat(const double r[3], double R[9], double* J) {
     double rx = r[0], ry = r[1], rz = r[2];
     const double theta = sqrt(rx * rx + ry * ry + rz * rz);
     if (theta < DBL_EPSILON) {
@@ -74,7 +76,7 @@ __device__ __forceinline__ void rodrigues_vec2mat(const double r[3], double R[9]
 }
 
 // matrix -> vector (R orthonormal to rounding; see oracle/README.md on the omitted SVD clean-up)
-__device__ __forceinline__ void rodrigues_mat2vec(const double R[9], double r[3]) {
+ESAC_HD void rodrigues_mat2vec(const double R[9], double r[3]) {
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
     const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
@@ -102,11 +104,27 @@ __device__ __forceinline__ void rodrigues_mat2vec(const double R[9], double r[3]
     r[0] = rx; r[1] = ry; r[2] = rz;
 }
 
+// 1/d to full double precision without the IEEE division sequence: v_rcp_f64 + two Newton steps
+// (5 dependent ops instead of ~10; a dependent fp64 op costs ~32 cycles on gfx950).  Only used
+// where the result feeds an iterative solver, never in the reference-arithmetic ("exact") routines.
+ESAC_HD double fast_rcp(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double x = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    e = __builtin_fma(-d, x, 1.0);
+    x = __builtin_fma(x, e, x);
+    return x;
+#else
+    return 1.0 / d;
+#endif
+}
+
 // ---------------------------------------------------------------- projection
 // Reference arithmetic for one reprojection error: fp64 projection with the
 // `z ? 1/z : 1` guard and no cheirality test, float result, float pixel
 // difference, norm accumulated in double, cast to float (esac_util.h:355-358).
-__device__ __forceinline__ float project_exact_err(const double R[9], const double t[3], const Cam& cam,
+ESAC_HD float project_exact_err(const double R[9], const double t[3], const Cam& cam,
                                                    float X, float Y, float Z, float px, float py) {
     const double Xd = X, Yd = Y, Zd = Z;
     double x = R[0] * Xd + R[1] * Yd + R[2] * Zd + t[0];
@@ -121,8 +139,42 @@ __device__ __forceinline__ float project_exact_err(const double R[9], const doub
     return (float)sqrt((double)dx * dx + (double)dy * dy);
 }
 
+// The same arithmetic for U points at once, written stage by stage: gfx950 issues in order and a
+// dependent fp64 op has ~32 cycles of latency, so the U independent chains must be adjacent in the
+// instruction stream to overlap.  Element-wise identical to project_exact_err.
+template <int U>
+ESAC_HD void project_exact_err_batch(const double R[9], const double t[3], const Cam& cam, const float (&X)[U],
+                                     const float (&Y)[U], const float (&Z)[U], const float (&px)[U],
+                                     const float (&py)[U], float (&err)[U]) {
+    double x[U], y[U], z[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const double Xd = X[u], Yd = Y[u], Zd = Z[u];
+        x[u] = R[0] * Xd + R[1] * Yd + R[2] * Zd + t[0];
+        y[u] = R[3] * Xd + R[4] * Yd + R[5] * Zd + t[1];
+        z[u] = R[6] * Xd + R[7] * Yd + R[8] * Zd + t[2];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) z[u] = z[u] ? 1. / z[u] : 1;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        x[u] *= z[u];
+        y[u] *= z[u];
+    }
+    double n2[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const float uu = (float)(x[u] * cam.fx + cam.cx);
+        const float vv = (float)(y[u] * cam.fy + cam.cy);
+        const float dx = px[u] - uu, dy = py[u] - vv;
+        n2[u] = (double)dx * dx + (double)dy * dy;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) err[u] = (float)sqrt(n2[u]);
+}
+
 // one soft-inlier term, reference arithmetic (esac_util.h:248-250)
-__device__ __forceinline__ double soft_inlier_exact(float err, float tau, float beta) {
+ESAC_HD double soft_inlier_exact(float err, float tau, float beta) {
     double soft = beta * (err - tau);  // float ops, widened afterwards
     soft = 1 / (1 + exp(-soft));
     return 1 - soft;
@@ -132,7 +184,7 @@ __device__ __forceinline__ double soft_inlier_exact(float err, float tau, float 
 // Closed-form real roots (Ferrari through the first real root of the resolvent
 // cubic; MathWorld "Quartic Equation"/"Cubic Equation"), same branch structure
 // as the solver behind cv::solvePnP(P3P) so that both find the same root sets.
-__device__ __forceinline__ int cubic_first_roots(double a, double b, double c, double d, double& x0, double& x1,
+ESAC_HD int cubic_first_roots(double a, double b, double c, double d, double& x0, double& x1,
                                                  double& x2) {
     const double kPi = 3.1415926535897932384626433832795;
     if (a == 0) {
@@ -186,7 +238,7 @@ __device__ __forceinline__ int cubic_first_roots(double a, double b, double c, d
     return 1;
 }
 
-__device__ __forceinline__ int quartic_real_roots(double a, double b, double c, double d, double e, double& x0,
+ESAC_HD int quartic_real_roots(double a, double b, double c, double d, double e, double& x0,
                                                   double& x1, double& x2, double& x3) {
     if (a == 0) {
         x3 = 0;
@@ -244,15 +296,15 @@ __device__ __forceinline__ int quartic_real_roots(double a, double b, double c, 
 struct V3 {
     double x, y, z;
 };
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+ESAC_HD V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+ESAC_HD V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+ESAC_HD V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+ESAC_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+ESAC_HD V3 cross(V3 a, V3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ V3 unit(V3 a) { return (1. / sqrt(dot(a, a))) * a; }
-__device__ __forceinline__ V3 matvec(const double R[9], V3 p) {
+ESAC_HD V3 unit(V3 a) { return (1. / sqrt(dot(a, a))) * a; }
+ESAC_HD V3 matvec(const double R[9], V3 p) {
     return {R[0] * p.x + R[1] * p.y + R[2] * p.z, R[3] * p.x + R[4] * p.y + R[5] * p.z,
             R[6] * p.x + R[7] * p.y + R[8] * p.z};
 }
@@ -261,10 +313,10 @@ __device__ __forceinline__ V3 matvec(const double R[9], V3 p) {
 // library solves the least-squares absolute-orientation problem with Horn's
 // quaternion method (4x4 Jacobi eigen-solve); here the same optimum is reached
 // without an eigen-solve: orthonormal triads give the exact answer for congruent
-// triangles, and two Gauss-Newton steps on the Procrustes objective (Cayley
-// update, exactly orthonormal) remove the O(root error) difference that remains
-// when the quartic root is slightly off.
-__device__ __forceinline__ void align_triangles(V3 P0, V3 P1, V3 P2, V3 Q0, V3 Q1, V3 Q2, double R[9], double T[3]) {
+// triangles, and Newton steps on the Procrustes objective (Cayley update, exactly
+// orthonormal) remove the difference that remains when the quartic root is off
+// and the triangles are not congruent (1 step typically, a few on bad roots).
+ESAC_HD void align_triangles(V3 P0, V3 P1, V3 P2, V3 Q0, V3 Q1, V3 Q2, double R[9], double T[3]) {
     const V3 e1 = unit(P1 - P0);
     const V3 e3 = unit(cross(e1, P2 - P0));
     const V3 e2 = cross(e3, e1);
@@ -279,17 +331,17 @@ __device__ __forceinline__ void align_triangles(V3 P0, V3 P1, V3 P2, V3 Q0, V3 Q
     const V3 Pc = third * (P0 + P1 + P2), Qc = third * (Q0 + Q1 + Q2);
     const V3 p0 = P0 - Pc, p1 = P1 - Pc, p2 = P2 - Pc;
     const V3 q0 = Q0 - Qc, q1 = Q1 - Qc, q2 = Q2 - Qc;
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
+    // Newton on g(w) = sum q_k . exp([w]x) a_k (exact Hessian, so convergence stays quadratic when the
+    // triangles are not congruent): (sum (a.q) I - (a qT + q aT)/2) w = sum a x q
+    for (int it = 0; it < 8; it++) {
         const V3 a0 = matvec(R, p0), a1 = matvec(R, p1), a2 = matvec(R, p2);
-        // (sum |a|^2 I - a aT) w = sum a x q
-        const double s = dot(a0, a0) + dot(a1, a1) + dot(a2, a2);
-        const double m00 = s - (a0.x * a0.x + a1.x * a1.x + a2.x * a2.x);
-        const double m11 = s - (a0.y * a0.y + a1.y * a1.y + a2.y * a2.y);
-        const double m22 = s - (a0.z * a0.z + a1.z * a1.z + a2.z * a2.z);
-        const double m01 = -(a0.x * a0.y + a1.x * a1.y + a2.x * a2.y);
-        const double m02 = -(a0.x * a0.z + a1.x * a1.z + a2.x * a2.z);
-        const double m12 = -(a0.y * a0.z + a1.y * a1.z + a2.y * a2.z);
+        const double s = dot(a0, q0) + dot(a1, q1) + dot(a2, q2);
+        const double m00 = s - (a0.x * q0.x + a1.x * q1.x + a2.x * q2.x);
+        const double m11 = s - (a0.y * q0.y + a1.y * q1.y + a2.y * q2.y);
+        const double m22 = s - (a0.z * q0.z + a1.z * q1.z + a2.z * q2.z);
+        const double m01 = -0.5 * (a0.x * q0.y + a0.y * q0.x + a1.x * q1.y + a1.y * q1.x + a2.x * q2.y + a2.y * q2.x);
+        const double m02 = -0.5 * (a0.x * q0.z + a0.z * q0.x + a1.x * q1.z + a1.z * q1.x + a2.x * q2.z + a2.z * q2.x);
+        const double m12 = -0.5 * (a0.y * q0.z + a0.z * q0.y + a1.y * q1.z + a1.z * q1.y + a2.y * q2.z + a2.z * q2.y);
         const V3 g = cross(a0, q0) + cross(a1, q1) + cross(a2, q2);
         // symmetric 3x3 solve by cofactors
         const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
@@ -298,7 +350,10 @@ __device__ __forceinline__ void align_triangles(V3 P0, V3 P1, V3 P2, V3 Q0, V3 Q
         const double idet = 1. / det;
         V3 w = {idet * (c00 * g.x + c01 * g.y + c02 * g.z), idet * (c01 * g.x + c11 * g.y + c12 * g.z),
                 idet * (c02 * g.x + c12 * g.y + c22 * g.z)};
-        if (!(dot(w, w) < 1e-2)) break;  // triads were not close (degenerate sample): keep them
+        const double ww = dot(w, w);
+        if (!(ww < 0.25)) break;   // no sensible step (degenerate sample): keep the current rotation
+        if (!(ww > 1e-30)) break;  // converged
+        const bool last = ww < 1e-14;  // quadratic convergence: the step after |w| < 1e-7 is below rounding
         // Cayley: exp([w]x) ~= ((1-|h|^2) I + 2 h hT + 2 [h]x) / (1+|h|^2), h = w/2
         const V3 h = 0.5 * w;
         const double hh = dot(h, h), k = 1. / (1. + hh);
@@ -313,6 +368,7 @@ __device__ __forceinline__ void align_triangles(V3 P0, V3 P1, V3 P2, V3 Q0, V3 Q
             for (int j = 0; j < 3; j++) Rn[i * 3 + j] = C[i * 3] * R[j] + C[i * 3 + 1] * R[3 + j] + C[i * 3 + 2] * R[6 + j];
 #pragma unroll
         for (int i = 0; i < 9; i++) R[i] = Rn[i];
+        if (last) break;
     }
     const V3 RPc = matvec(R, Pc);
     T[0] = Qc.x - RPc.x; T[1] = Qc.y - RPc.y; T[2] = Qc.z - RPc.z;
@@ -321,7 +377,7 @@ __device__ __forceinline__ void align_triangles(V3 P0, V3 P1, V3 P2, V3 Q0, V3 Q
 // 4-point P3P (Gao, Hou, Tang, Cheng, PAMI 2003; main branch): up to four poses
 // from points 0..2, the one with the smallest reprojection error of point 3 wins.
 // obj: 4 scene points, img: 4 pixel positions.  Returns false when there is no solution.
-__device__ __forceinline__ bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4], const Cam& cam,
+ESAC_HD bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4], const Cam& cam,
                                         double Rbest[9], double Tbest[3]) {
     const double inv_fx = 1. / cam.fx, inv_fy = 1. / cam.fy, cx_fx = cam.cx / cam.fx, cy_fy = cam.cy / cam.fy;
     double mu[3], mv[3], mk[3];
@@ -367,15 +423,6 @@ __device__ __forceinline__ bool p3p_4pt(const V3 P[4], const double mu_px[4], co
 
     const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
     const double inv_b0 = 1. / b0;
-    // coefficients of the b1 polynomial that do not depend on the root
-    const double k0 = 1 - a - b, k1 = q * a - q, k2 = 1 - a + b;
-    const double g3 = r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1);
-    const double g2 = r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2);
-    const double g1 = r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) +
-                      r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) + pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b);
-    const double g0 = 2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
-                      p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1));
-
     bool have = false;
     double min_reproj = 0;
 #pragma unroll
@@ -384,7 +431,19 @@ __device__ __forceinline__ bool p3p_4pt(const V3 P[4], const double mu_px[4], co
         const double x = (i == 0) ? x0 : (i == 1) ? x1 : (i == 2) ? x2r : x3;
         if (x <= 0) continue;
         const double xx = x * x;
-        const double b1 = (k0 * xx + k1 * x + k2) * ((g3 * x + g2) * xx + g1 * x + g0);
+        // same association order as the CPU solver: b1 suffers heavy cancellation, and the two
+        // sides only agree on ill-conditioned samples if they round the same way
+        const double b1 =
+            ((1 - a - b) * xx + (q * a - q) * x + 1 - a + b) *
+            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) +
+               pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * xx +
+             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) +
+              r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+             2 * r3q * (a_2 - b - a2 + ab - 1) +
+             pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
         if (b1 <= 0) continue;
         const double y = inv_b0 * b1;
         const double v = xx + y * y - x * y * r;
@@ -417,7 +476,7 @@ __device__ __forceinline__ bool p3p_4pt(const V3 P[4], const double mu_px[4], co
 // ---------------------------------------------------------------- LM terms
 // One correspondence of solvePnP(ITERATIVE): residual (ex,ey) = projection - pixel
 // in double, and the two Jacobian rows wrt (rvec, tvec).
-__device__ __forceinline__ void pnp_point_terms(const double R[9], const double dRdr[27], const double t[3],
+ESAC_HD void pnp_point_terms(const double R[9], const double dRdr[27], const double t[3],
                                                 const Cam& cam, double X, double Y, double Z, double mx, double my,
                                                 double& ex, double& ey, double Ju[6], double Jv[6]) {
     double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
@@ -441,7 +500,7 @@ __device__ __forceinline__ void pnp_point_terms(const double R[9], const double 
     }
 }
 
-__device__ __forceinline__ void pnp_point_residual(const double R[9], const double t[3], const Cam& cam, double X,
+ESAC_HD void pnp_point_residual(const double R[9], const double t[3], const Cam& cam, double X,
                                                    double Y, double Z, double mx, double my, double& ex, double& ey) {
     double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
     double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
@@ -454,10 +513,12 @@ __device__ __forceinline__ void pnp_point_residual(const double R[9], const doub
 }
 
 // Damped normal equations of one LM step: (JtJ with diag*(1+lambda)) dx = JtErr.
-// JtJ arrives as the 21 upper-triangle sums.  Cholesky (the matrix is SPD for any
-// non-degenerate inlier set); a non-positive pivot yields a zero step, which
-// ends the LM loop through its relative-change test.
-__device__ __forceinline__ void lm_solve6(const double U21[21], const double g[6], double lambda, double dx[6]) {
+// JtJ arrives as the 21 upper-triangle sums.  LDL^T (the matrix is SPD for any
+// non-degenerate inlier set; the CPU library uses an SVD solve, identical there);
+// a non-positive pivot yields a zero step, which ends the LM loop through its
+// relative-change test.
+ESAC_HD void lm_solve6(const double U21[21], const double g[6], double lambda, double dx[6]) {
+#pragma clang fp contract(fast)
     double A[6][6];
     int k = 0;
 #pragma unroll
@@ -470,22 +531,23 @@ __device__ __forceinline__ void lm_solve6(const double U21[21], const double g[6
         }
 #pragma unroll
     for (int i = 0; i < 6; i++) A[i][i] *= 1. + lambda;
-    double L[6][6];
+    // A = L D L^T (unit lower L): 6 reciprocals on the dependent chain, no square roots
+    double L[6][6], Dinv[6], W[6][6];  // W[i][m] = L[i][m] * D[m]
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         double d = A[j][j];
 #pragma unroll
-        for (int m = 0; m < j; m++) d -= L[j][m] * L[j][m];
+        for (int m = 0; m < j; m++) d -= W[j][m] * L[j][m];
         if (!(d > 0)) ok = false;
-        const double ljj = sqrt(d);
-        L[j][j] = ljj;
-        const double inv = 1. / ljj;
+        const double inv = 1. / d;
+        Dinv[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double s = A[i][j];
 #pragma unroll
-            for (int m = 0; m < j; m++) s -= L[i][m] * L[j][m];
+            for (int m = 0; m < j; m++) s -= W[i][m] * L[j][m];
+            W[i][j] = s;
             L[i][j] = s * inv;
         }
     }
@@ -495,14 +557,14 @@ __device__ __forceinline__ void lm_solve6(const double U21[21], const double g[6
         double s = g[i];
 #pragma unroll
         for (int m = 0; m < i; m++) s -= L[i][m] * y[m];
-        y[i] = s / L[i][i];
+        y[i] = s;
     }
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
-        double s = y[i];
+        double s = y[i] * Dinv[i];
 #pragma unroll
         for (int m = i + 1; m < 6; m++) s -= L[m][i] * dx[m];
-        dx[i] = s / L[i][i];
+        dx[i] = s;
     }
     if (!ok) {
 #pragma unroll
@@ -511,7 +573,7 @@ __device__ __forceinline__ void lm_solve6(const double U21[21], const double g[6
 }
 
 // camera transform = inverse of the scene pose (esac_util.h:537-548), rigid inverse
-__device__ __forceinline__ void pose_to_inverse_transform(const double R[9], const double t[3], double T[16]) {
+ESAC_HD void pose_to_inverse_transform(const double R[9], const double t[3], double T[16]) {
     T[0] = R[0]; T[1] = R[3]; T[2] = R[6];
     T[4] = R[1]; T[5] = R[4]; T[6] = R[7];
     T[8] = R[2]; T[9] = R[5]; T[10] = R[8];

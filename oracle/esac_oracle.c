@@ -933,7 +933,7 @@ static int draw_argmax(const double* probs, int n) {
 
 /* refineHyp, esac_util.h:378-454 */
 static int refine_hyp(const ctx_t* c, const float* reproErrs, int expert, int maxRefSteps, double pose[6],
-                      uint8_t* inlierMap, int32_t* counts) {
+                      uint8_t* inlierMap, int32_t* counts, int32_t* lm_iters) {
     const esac_oracle_args* a = c->a;
     const int P = a->H * a->W;
     float* localErrs = (float*)malloc(sizeof(float) * P);
@@ -961,7 +961,8 @@ static int refine_hyp(const ctx_t* c, const float* reproErrs, int expert, int ma
         if (n <= bestInliers) break; /* converged */
         bestInliers = n;
         /* n > 4 here, so the reference always takes SOLVEPNP_ITERATIVE; it returns true */
-        esac_oracle_lm_pnp(localObj, localImg, (int)n, c->fx, c->fy, c->cx, c->cy, pose);
+        int it = esac_oracle_lm_pnp(localObj, localImg, (int)n, c->fx, c->fy, c->cx, c->cy, pose);
+        if (lm_iters) *lm_iters += it;
         if (inlierMap) memcpy(inlierMap, localMap, P);
         accepted++;
         repro_errs(c, pose, expert, localErrs);
@@ -1062,7 +1063,9 @@ int esac_oracle_forward(esac_oracle_args* a) {
     if (a->out_winner_errs) memcpy(a->out_winner_errs, werrs, (size_t)P * sizeof(float));
     if (a->out_inlier_counts)
         for (int i = 0; i <= max_ref; i++) a->out_inlier_counts[i] = -1;
-    int acc = refine_hyp(&c, werrs, expertW, max_ref, hyps + 6 * hypIdx, a->out_inlier_map, a->out_inlier_counts);
+    if (a->out_lm_iters) *a->out_lm_iters = 0;
+    int acc = refine_hyp(&c, werrs, expertW, max_ref, hyps + 6 * hypIdx, a->out_inlier_map, a->out_inlier_counts,
+                         a->out_lm_iters);
     t1 = now_ms();
     if (a->out_phase_ms) a->out_phase_ms[3] = t1 - t0;
 

@@ -71,6 +71,7 @@ typedef struct esac_oracle_args {
     uint8_t* out_inlier_map;  /* [H*W] row-major (y,x), last accepted inlier set */
     float*   out_winner_errs; /* [H*W] reprojection error image of the winner (pre-refinement) */
     double*  out_phase_ms;    /* [4] sampling, scoring, selection, refinement   */
+    int32_t* out_lm_iters;    /* [1] total LM iterations spent in refinement    */
 } esac_oracle_args;
 
 /* returns winning expert (>=0) or <0 on argument error */

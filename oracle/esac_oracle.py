@@ -40,6 +40,7 @@ class _Args(C.Structure):
         ("out_ref_steps", C.c_void_p), ("out_inlier_counts", C.c_void_p),
         ("out_inlier_map", C.c_void_p), ("out_winner_errs", C.c_void_p),
         ("out_phase_ms", C.c_void_p),
+        ("out_lm_iters", C.c_void_p),
     ]
 
 
@@ -106,6 +107,7 @@ def forward(scene_coords, hyp_assign, shift_x=0, shift_y=0, focal=525.0, ppx=320
         refined=np.zeros(6, np.float64), ref_steps=np.zeros(1, np.int32),
         inlier_counts=np.zeros(nref + 1, np.int32), inlier_map=np.zeros((H, W), np.uint8),
         winner_errs=np.zeros((H, W), np.float32), phase_ms=np.zeros(4, np.float64),
+        lm_iters=np.zeros(1, np.int32),
     )
     a = _Args()
     a.scene_coords = _p(sc)
@@ -130,7 +132,7 @@ def forward(scene_coords, hyp_assign, shift_x=0, shift_y=0, focal=525.0, ppx=320
         a.rng_mode = 0
     a.max_tries, a.max_ref_steps, a.num_threads = int(max_tries), int(max_ref_steps), int(num_threads)
     for k in ("pose", "sample_xy", "tries", "hyps", "scores", "probs", "entropy", "winner", "refined",
-              "ref_steps", "inlier_counts", "inlier_map", "winner_errs", "phase_ms"):
+              "ref_steps", "inlier_counts", "inlier_map", "winner_errs", "phase_ms", "lm_iters"):
         setattr(a, "out_" + k, _p(out[k]))
     rc = lib().esac_oracle_forward(C.byref(a))
     if rc < 0:
@@ -139,6 +141,7 @@ def forward(scene_coords, hyp_assign, shift_x=0, shift_y=0, focal=525.0, ppx=320
     out["winner"] = int(out["winner"][0])
     out["entropy"] = float(out["entropy"][0])
     out["ref_steps"] = int(out["ref_steps"][0])
+    out["lm_iters"] = int(out["lm_iters"][0])
     return out
 
 

@@ -1,0 +1,41 @@
+// host_math_probe.cpp -- TEST-ONLY: compiles the device math header (pose_math.hpp) for the host so the
+// CPU test-suite (-m "not gpu") can exercise the exact source the kernels use against the oracle.
+// Built by tests/native/build.py with hipcc (host pass only is used). Not part of the product library.
+#include "../../esac_amd/csrc/pose_math.hpp"
+#include "../../esac_amd/csrc/lm_math.hpp"
+using namespace esac;
+extern "C" {
+int probe_p3p(const double* obj, const double* img, double fx, double fy, double cx, double cy, double* rvec, double* tvec, double* Rout) {
+    V3 P[4]; double mu[4], mv[4];
+    for (int j = 0; j < 4; j++) { P[j] = V3{obj[3*j], obj[3*j+1], obj[3*j+2]}; mu[j] = img[2*j]; mv[j] = img[2*j+1]; }
+    Cam cam{fx, fy, cx, cy};
+    double R[9], T[3];
+    if (!p3p_4pt(P, mu, mv, cam, R, T)) return 0;
+    rodrigues_mat2vec(R, rvec);
+    for (int i = 0; i < 3; i++) tvec[i] = T[i];
+    if (Rout) for (int i = 0; i < 9; i++) Rout[i] = R[i];
+    return 1;
+}
+int probe_quartic(double a, double b, double c, double d, double e, double* roots) {
+    return quartic_real_roots(a, b, c, d, e, roots[0], roots[1], roots[2], roots[3]);
+}
+void probe_rodrigues(const double* r, double* R, double* J) { rodrigues_vec2mat<true>(r, R, J); }
+void probe_mat2vec(const double* R, double* r) { rodrigues_mat2vec(R, r); }
+float probe_exact_err(const double* R, const double* t, double fx, double fy, double cx, double cy, float X, float Y, float Z, float px, float py) {
+    Cam cam{fx, fy, cx, cy};
+    return project_exact_err(R, t, cam, X, Y, Z, px, py);
+}
+void probe_lm_solve6(const double* U21, const double* g, double lambda, double* dx) { lm_solve6(U21, g, lambda, dx); }
+// normal equations of one LM iteration exactly as k_refine builds them (twist-space sums + chain rule)
+void probe_lm_normal(const float* obj, const float* img, int n, const double* pose, double fx, double fy, double cx, double cy,
+                     double* U21, double* g6, double* e2) {
+    Cam cam{fx, fy, cx, cy};
+    double R[9], dRdr[27], acc[LM_NACC];
+    rodrigues_vec2mat<true>(pose, R, dRdr);
+    for (int k = 0; k < LM_NACC; k++) acc[k] = 0;
+    for (int i = 0; i < n; i++)
+        lm_accumulate_point<true>(R, pose + 3, cam, obj[3*i], obj[3*i+1], obj[3*i+2], img[2*i], img[2*i+1], acc);
+    lm_to_rvec_space(acc, R, dRdr, pose + 3, U21, g6);
+    *e2 = acc[26];
+}
+}

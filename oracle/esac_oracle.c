@@ -874,7 +874,8 @@ static int sample_try(const ctx_t* c, int h, int expert, uint32_t t, int32_t xy[
             xy[2 * have] = x; xy[2 * have + 1] = y; have++;
         }
     } else {
-        esac_oracle_draw_cells(a->seed, a->call, (uint32_t)h, t, a->W, a->H, xy);
+        const uint32_t gh = a->hyp_index ? (uint32_t)a->hyp_index[h] : (uint32_t)h;
+        esac_oracle_draw_cells(a->seed, a->call, gh, t, a->W, a->H, xy);
     }
     double obj[12], img[8];
     for (int j = 0; j < 4; j++) {

@@ -72,6 +72,9 @@ typedef struct esac_oracle_args {
     float*   out_winner_errs; /* [H*W] reprojection error image of the winner (pre-refinement) */
     double*  out_phase_ms;    /* [4] sampling, scoring, selection, refinement   */
     int32_t* out_lm_iters;    /* [1] total LM iterations spent in refinement    */
+    /* optional [N]: global index of each hypothesis (keys its RNG stream); NULL -> 0..N-1.
+     * Lets a shard of a larger problem be evaluated on its own (multi-GPU tests). */
+    const int32_t* hyp_index;
 } esac_oracle_args;
 
 /* returns winning expert (>=0) or <0 on argument error */

@@ -1,0 +1,18 @@
+"""Builds the TEST-ONLY host probe of the device math headers (pose_math.hpp / lm_math.hpp compiled for the
+host with hipcc) so that the CPU suite can exercise the kernels' own source against the oracle."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_math_probe.cpp")
+LIB = os.path.join(HERE, "libhost_math_probe.so")
+CSRC = os.path.join(HERE, "..", "..", "esac_amd", "csrc")
+
+
+def build(force=False):
+    deps = [SRC] + [os.path.join(CSRC, h) for h in ("pose_math.hpp", "lm_math.hpp")]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC",
+                               "-shared", SRC, "-o", LIB])
+    return LIB

@@ -1,0 +1,166 @@
+"""GPU edge cases the reference's semantics imply (ragged widths, exhausted budgets, ties, strides, big grids)."""
+import numpy as np
+import pytest
+import torch
+
+from esac_amd import api
+from esac_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(engine, oracle, coords, ha, **kw):
+    E, _, H, W = coords.shape
+    p = engine.make_params(E, H, W, len(ha), **kw)
+    res = engine.forward_device(torch.from_numpy(np.ascontiguousarray(coords)).cuda(), torch.from_numpy(np.ascontiguousarray(ha)).cuda(), p)
+    okw = {k: v for k, v in kw.items() if k in ("shift_x", "shift_y", "focal", "ppx", "ppy", "inlier_thresh", "inlier_alpha",
+                                                "inlier_beta", "max_reproj", "sub_sampling", "seed", "call", "max_tries", "max_ref_steps")}
+    ref = oracle.forward(coords, ha, **okw)
+    return res, ref
+
+
+def _same(engine, res, ref):
+    np.testing.assert_array_equal(engine.read(api.BUF_TRIES), ref["tries"])
+    np.testing.assert_array_equal(engine.read(api.BUF_SAMPLE_XY), ref["sample_xy"])
+    assert int(res[api.RES_HYP]) == ref["winner"] and int(res[api.RES_EXPERT]) == ref["expert"]
+    assert int(res[api.RES_REF_STEPS]) == ref["ref_steps"]
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_MAP), ref["inlier_map"])
+    r_err, t_err = S.pose_errors(res[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
+    assert r_err <= 1e-4 and t_err <= 1e-3, (r_err, t_err)
+
+
+@pytest.mark.parametrize("H,W,sub", [(30, 41, 16), (24, 32, 20), (13, 17, 37), (120, 160, 4)])
+def test_odd_grid_shapes(engine, oracle, H, W, sub):
+    """W % 4 != 0 takes the scalar-load path of the score kernel; P not a multiple of the block sizes."""
+    f = S.make_frame(30, H=H, W=W, sub=sub)
+    ha = S.gating_assignment(f, 48)
+    res, ref = _both(engine, oracle, f["coords"], ha, sub_sampling=sub, call=9)
+    _same(engine, res, ref)
+
+
+def test_shift_and_parameters(engine, oracle):
+    f = S.make_frame(31, shift=(5, -3))
+    ha = S.gating_assignment(f, 64)
+    res, ref = _both(engine, oracle, f["coords"], ha, shift_x=5, shift_y=-3, inlier_thresh=6.0, inlier_alpha=50.0,
+                     inlier_beta=0.8, max_reproj=60.0, call=2)
+    _same(engine, res, ref)
+
+
+def test_budget_exhaustion_constant_map(engine, oracle):
+    """Every P3P fails on a constant map: zero pose kept, tries = -1 after max_tries (esac_util.h:107-111,154)."""
+    coords = np.ones((1, 3, 12, 16), np.float32)
+    ha = np.zeros(8, np.int64)
+    res, ref = _both(engine, oracle, coords, ha, max_tries=130)  # not a multiple of 64: partial last round
+    assert (engine.read(api.BUF_TRIES) == -1).all()
+    np.testing.assert_array_equal(engine.read(api.BUF_HYPS), 0.0)
+    np.testing.assert_array_equal(engine.read(api.BUF_SAMPLE_XY), ref["sample_xy"])  # state of the LAST try remains
+    assert int(res[api.RES_HYP]) == ref["winner"] == 0
+    assert int(res[api.RES_REF_STEPS]) == ref["ref_steps"]
+    assert np.isfinite(res[api.RES_POSE:api.RES_POSE + 16]).all()
+
+
+def test_small_try_budget_matches_oracle(engine, oracle):
+    f = S.make_frame(32)
+    ha = S.gating_assignment(f, 128)
+    res, ref = _both(engine, oracle, f["coords"], ha, max_tries=3, call=1)  # many hypotheses run out of tries
+    assert (ref["tries"] == -1).any() and (ref["tries"] >= 0).any()
+    np.testing.assert_allclose(engine.read(api.BUF_HYPS), ref["hyps"], atol=1e-6)
+    _same(engine, res, ref)
+
+
+def test_tie_goes_to_first_index(engine):
+    """Identical hypotheses -> identical exact scores -> argmax keeps the first (esac_util.h:519)."""
+    f = S.make_frame(33)
+    N = 40
+    ha = S.gating_assignment(f, N)
+    sc = torch.from_numpy(f["coords"]).cuda()
+    hat = torch.from_numpy(ha).cuda()
+    p = engine.make_params(1, 60, 80, N)
+    engine.forward_device(sc, hat, p)
+    hyps = engine.read(api.BUF_HYPS)
+    best = int(np.argmax(engine.read(api.BUF_SCORES)))
+    dup = np.tile(hyps[best], (N, 1))
+    dup[:7] = hyps[(best + 1) % N]  # a different (worse or equal) hypothesis in front
+    engine.write_hyps(dup)
+    engine.score(sc, hat, p)
+    engine.select(sc, hat, p)
+    engine.refine(sc, hat, p)
+    res = engine.read(api.BUF_RESULT)
+    scores = engine.read(api.BUF_SCORES)
+    assert len(set(scores[7:].tolist())) == 1
+    first = 7 if scores[7] >= scores[0] else 0
+    assert int(res[api.RES_HYP]) == first
+    assert int(res[api.RES_CONTENDERS]) >= N - 7
+
+
+def test_cpu_tensors_strides_and_expand(oracle):
+    """Drop-in call with CPU tensors, a non-contiguous coordinate tensor and the stride-0 expand()
+    assignment of --expertselection (test_esac.py:171-173)."""
+    import esac
+    f = S.make_frame(34, E=3, true_expert=1)
+    big = torch.zeros(3, 3, 60, 160)
+    big[..., ::2] = torch.from_numpy(f["coords"])
+    sc = big[..., ::2]
+    assert not sc.is_contiguous()
+    ha = torch.tensor([1]).expand(64)
+    assert ha.stride() == (0,)
+    out = torch.zeros(4, 4)
+    esac.set_seed(1305, 0)
+    e = esac.forward(sc, ha, out, 0, 0, 525.0, 320.0, 240.0, 10.0, 100.0, 0.5, 100.0, 8)
+    ref = oracle.forward(f["coords"], np.full(64, 1, np.int64))
+    assert e == 1 == ref["expert"]
+    r_err, t_err = S.pose_errors(out.numpy(), ref["pose"])
+    assert r_err <= 1e-4 and t_err <= 1e-3
+    with pytest.raises(RuntimeError):
+        esac.forward(sc, torch.tensor([5]).expand(8), out, 0, 0, 525.0, 320.0, 240.0, 10.0, 100.0, 0.5, 100.0, 8)
+
+
+def test_fast_score_band_is_wide_enough(engine, oracle):
+    """|fp32 streaming score - exact score| must stay well inside the re-score band (alpha * 1e-3)."""
+    worst = 0.0
+    for k in range(6):
+        f = S.make_frame(40 + k, E=2, true_expert=k % 2, grid_spacing=5.0)
+        ha = S.gating_assignment(f, 256, mode="gating")
+        sc = torch.from_numpy(f["coords"]).cuda()
+        hat = torch.from_numpy(ha).cuda()
+        p = engine.make_params(2, 60, 80, 256, call=k)
+        engine.sample(sc, hat, p)
+        engine.score(sc, hat, p)
+        engine.select(sc, hat, p)
+        fast = engine.read(api.BUF_SCORES).copy()
+        flags = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
+        engine.score_exact(sc, hat, p)
+        exact = engine.read(api.BUF_SCORES)
+        worst = max(worst, np.abs(fast[~flags] - exact[~flags]).max())
+    assert worst < 0.1 * 100.0 * 1e-3, worst  # 10x head-room inside the default band
+
+
+def test_large_grid_global_list_path(engine, oracle):
+    """P > 8192 cells: the refinement's correspondence list lives in global memory instead of LDS."""
+    f = S.make_frame(50, H=120, W=160, sub=4)
+    ha = S.gating_assignment(f, 32)
+    res, ref = _both(engine, oracle, f["coords"], ha, sub_sampling=4, call=3)
+    _same(engine, res, ref)
+
+
+def test_sharding_independence_on_device(engine):
+    """Shards evaluated with global hypothesis indices reproduce the unsharded stage outputs bit-exactly."""
+    f = S.make_frame(51, E=3, true_expert=0)
+    ha = S.gating_assignment(f, 96, mode="dirichlet")
+    sc = torch.from_numpy(f["coords"]).cuda()
+    p = engine.make_params(3, 60, 80, 96, call=6)
+    engine.forward_device(sc, torch.from_numpy(ha).cuda(), p)
+    xy_all, hyps_all = engine.read(api.BUF_SAMPLE_XY).copy(), engine.read(api.BUF_HYPS).copy()
+    scores_all = engine.read(api.BUF_SCORES).copy()
+    flags_all = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
+    for idx in (np.arange(40, 96), np.nonzero(ha % 2 == 1)[0]):
+        q = engine.make_params(3, 60, 80, len(idx), call=6)
+        gi = torch.from_numpy(idx.astype(np.int32)).cuda()
+        engine.set_hyp_index(q, gi)
+        engine.forward_device(sc, torch.from_numpy(ha[idx]).cuda(), q)
+        np.testing.assert_array_equal(engine.read(api.BUF_SAMPLE_XY), xy_all[idx])
+        np.testing.assert_array_equal(engine.read(api.BUF_HYPS), hyps_all[idx])
+        fl = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
+        both_fast = ~fl & ~flags_all[idx]
+        np.testing.assert_array_equal(engine.read(api.BUF_SCORES)[both_fast], scores_all[idx][both_fast])

@@ -206,7 +206,7 @@ class Engine:
         _check(self.lib.esac_hip_set_timing(self.ctx, 1 if on else 0), self.lib)
 
     def phase_ms(self):
-        out = np.zeros(5, np.float32)
+        out = np.zeros(7, np.float32)
         _check(self.lib.esac_hip_phase_ms(self.ctx, out.ctypes.data_as(C.c_void_p)), self.lib)
         return out
 

@@ -43,7 +43,7 @@ struct esac_hip_ctx {
     KArgs ws{};  // only the workspace pointers are kept here
     int lastN = 0, lastH = 0, lastW = 0;
     bool timing = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
 };
 
@@ -58,7 +58,7 @@ extern "C" int esac_hip_device_count(void) {
 static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.contenders, c->ws.n_contenders, c->ws.stats,
-                    c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles};
+                    c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws = KArgs{};
@@ -123,7 +123,10 @@ static int ensure_ws(esac_hip_ctx* c, int N, int P) {
     rc |= alloc(&c->ws.inlier_counts, (size_t)ESAC_MAX_REF_STEPS + 1);
     rc |= alloc(&c->ws.result, (size_t)ESAC_RES_DOUBLES);
     rc |= alloc(&c->ws.cycles, (size_t)32);
+    rc |= alloc(&c->ws.tstamps, (size_t)nN * 2);
+    rc |= alloc(&c->ws.span_acc, (size_t)2);
     if (rc) return rc;
+    HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
     HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
     HIP_OK(hipMemset(c->ws.result, 0, ESAC_RES_DOUBLES * sizeof(double)));
     HIP_OK(hipMemset(c->ws.n_contenders, 0, 4 * sizeof(int)));
@@ -160,6 +163,7 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
                                             : ESAC_MAX_REF_STEPS;
     a.hyp_offset = p->hyp_offset;
     a.hyp_index = p->d_hyp_index;
+    if (!c->timing) a.tstamps = nullptr;  // device-side span stamps only in timing mode
     a.margin = p->rescore_margin > 0 ? p->rescore_margin : fabsf(p->inlier_alpha) * ESAC_DEFAULT_MARGIN;
     c->lastN = p->N; c->lastH = p->H; c->lastW = p->W;
     *out = a;
@@ -233,6 +237,10 @@ extern "C" int esac_hip_forward(esac_hip_ctx* c, const float* d_sc, const int64_
     if ((rc = check_launch("k_refine"))) return rc;
     if (tm) {
         HIP_OK(hipEventRecord(c->ev[4], s));
+        // an EMPTY interval: what two adjacent hipEventRecord calls measure with nothing in between,
+        // i.e. the part of every bracketed phase that is not kernel time
+        HIP_OK(hipEventRecord(c->ev[5], s));
+        HIP_OK(hipEventRecord(c->ev[6], s));
         c->ev_valid = true;
     }
     if (d_scores_out) HIP_OK(hipMemcpyAsync(d_scores_out, a.scores, (size_t)a.N * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -303,14 +311,25 @@ extern "C" int esac_hip_set_timing(esac_hip_ctx* c, int enabled) {
     if (!c) return fail(-1, "null context");
     c->timing = enabled != 0;
     c->ev_valid = false;
+    if (c->ws.span_acc) {
+        HIP_OK(hipSetDevice(c->device));
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
+    }
     return 0;
 }
 
-extern "C" int esac_hip_phase_ms(esac_hip_ctx* c, float out[5]) {
+extern "C" int esac_hip_phase_ms(esac_hip_ctx* c, float out[7]) {
     if (!c || !out) return fail(-1, "esac_hip_phase_ms: null argument");
     if (!c->timing || !c->ev_valid) return fail(-8, "esac_hip_phase_ms: timing is off or no forward has run");
     HIP_OK(hipEventSynchronize(c->ev[4]));
     for (int i = 0; i < 4; i++) HIP_OK(hipEventElapsedTime(&out[i], c->ev[i], c->ev[i + 1]));
     HIP_OK(hipEventElapsedTime(&out[4], c->ev[0], c->ev[4]));
+    HIP_OK(hipEventSynchronize(c->ev[6]));
+    HIP_OK(hipEventElapsedTime(&out[5], c->ev[5], c->ev[6]));
+    // mean device-side span of the score kernel since timing was enabled (100 MHz wall clock -> ms)
+    long long acc[2] = {0, 0};
+    HIP_OK(hipMemcpy(acc, c->ws.span_acc, sizeof(acc), hipMemcpyDeviceToHost));
+    out[6] = acc[1] > 0 ? (float)((double)acc[0] / (double)acc[1] * 1e-5) : 0.0f;
     return 0;
 }

@@ -161,6 +161,10 @@ template <int B>
 __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
     __shared__ float s_w[B / 64];
     const int h = blockIdx.x;
+    // optional device-side span measurement (timing mode): the kernel's duration is
+    // max(end) - min(start) over its workgroups, on the constant 100 MHz wall clock
+    long long t_start = 0;
+    if (a.tstamps && threadIdx.x == 0) t_start = wall_clock64();
     const int e = (int)a.assign[h];
     const int P = a.H * a.W;
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
@@ -207,6 +211,10 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
         for (int k = 0; k < B / 64; k++) tot += (double)s_w[k];
         const float scale = a.alpha / a.W / a.H;  // float / int / int (esac_util.h:256)
         a.fast_scores[h] = (float)(tot * (double)scale);
+        if (a.tstamps) {
+            a.tstamps[2 * h] = t_start;
+            a.tstamps[2 * h + 1] = wall_clock64();
+        }
     }
 }
 
@@ -252,6 +260,34 @@ __global__ __launch_bounds__(B) void k_select(KArgs a) {
         a.stats[1] = acc[0];     // sum exp(s - max)
         // entropy = -sum p log2 p,  p = exp(d)/S  ->  log2(S) - (sum exp(d) d) / (S ln 2)
         a.stats[2] = log2(acc[0]) - acc[1] / (acc[0] * 0.6931471805599453);
+    }
+    if (a.tstamps) {  // timing mode: span of the score kernel that just ran = max(end) - min(start)
+        __shared__ long long s_lo[B / 64], s_hi[B / 64];
+        long long lo = 0x7fffffffffffffffLL, hi = 0;
+        for (int i = threadIdx.x; i < a.N; i += B) {
+            const long long t0 = a.tstamps[2 * i], t1 = a.tstamps[2 * i + 1];
+            lo = t0 < lo ? t0 : lo;
+            hi = t1 > hi ? t1 : hi;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long ol = __shfl_xor(lo, o), oh = __shfl_xor(hi, o);
+            lo = ol < lo ? ol : lo;
+            hi = oh > hi ? oh : hi;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_lo[threadIdx.x >> 6] = lo;
+            s_hi[threadIdx.x >> 6] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < B / 64; k++) {
+                lo = s_lo[k] < lo ? s_lo[k] : lo;
+                hi = s_hi[k] > hi ? s_hi[k] : hi;
+            }
+            a.span_acc[0] += hi - lo;
+            a.span_acc[1] += 1;
+        }
     }
 }
 
@@ -302,7 +338,11 @@ void launch_score_fast(const KArgs& a, hipStream_t s) {
 void launch_select(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_select<1024>, dim3(1), dim3(1024), 0, s, a); }
 void launch_rescore(const KArgs& a, int all, hipStream_t s) {
     const int grid = all ? (a.N < 4096 ? a.N : 4096) : (a.N < 256 ? a.N : 256);
-    hipLaunchKernelGGL(k_rescore<256>, dim3(grid), dim3(256), 0, s, a, all);
+    // few contenders, latency matters: 16 wavefronts per hypothesis; bulk exact scoring: 4 are enough
+    if (all)
+        hipLaunchKernelGGL(k_rescore<256>, dim3(grid), dim3(256), 0, s, a, all);
+    else
+        hipLaunchKernelGGL(k_rescore<1024>, dim3(grid), dim3(1024), 0, s, a, all);
 }
 
 }  // namespace esac

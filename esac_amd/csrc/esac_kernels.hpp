@@ -40,6 +40,8 @@ struct KArgs {
     int* inlier_counts;   // [ESAC_MAX_REF_STEPS_K+1]
     double* result;       // [32]
     long long* cycles;    // [32] shader-cycle counters of the refinement kernel's sections (profiling aid)
+    long long* tstamps;   // [2N] per-workgroup (start,end) wall-clock stamps of the score kernel, or nullptr
+    long long* span_acc;  // [2] accumulated score-kernel span (100 MHz ticks) and launch count
 };
 
 void launch_sample(const KArgs& a, hipStream_t s);

@@ -144,8 +144,12 @@ int esac_hip_write_hyps(esac_hip_ctx* ctx, const double* h_hyps, int N);
 
 /* Time of the most recent launch of each phase on this context in milliseconds
  * (hipEvents around each kernel; the StopWatch prints of esac.cpp:124,149,161,179).
- * out[0..4] = sample, score, select+rescore, refine, total.  Synchronises. */
-int esac_hip_phase_ms(esac_hip_ctx* ctx, float out[5]);
+ * out[0..4] = sample, score, select+rescore, refine, total; out[5] = an empty event interval (the
+ * bracketing overhead contained in each of the four phase figures); out[6] = mean duration of the
+ * score kernel itself since timing was enabled, measured on the device (max end - min start of its
+ * workgroups on the constant 100 MHz wall clock) -- the figure rocprofv3's kernel trace reports.
+ * Synchronises. */
+int esac_hip_phase_ms(esac_hip_ctx* ctx, float out[7]);
 /* enable/disable the per-phase events (off by default: zero overhead) */
 int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
 

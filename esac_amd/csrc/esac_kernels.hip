@@ -32,9 +32,12 @@
 namespace esac {
 
 // ================================================================= K1: sample + P3P
-__global__ __launch_bounds__(64) void k_sample(KArgs a) {
+constexpr int SAMPLE_B = 256;  // tries evaluated per round: 4 wavefronts per hypothesis
+
+__global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
+    __shared__ int s_first[2][SAMPLE_B / 64];
     const int h = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = (int)a.assign[h];
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
@@ -43,8 +46,9 @@ __global__ __launch_bounds__(64) void k_sample(KArgs a) {
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const double tau = (double)a.tau;
 
-    for (int base = 0; base < a.max_tries; base += 64) {
-        const int t = base + lane;
+    int parity = 0;
+    for (int base = 0; base < a.max_tries; base += SAMPLE_B, parity ^= 1) {
+        const int t = base + (int)threadIdx.x;
         const bool active = t < a.max_tries;
         int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
         double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
@@ -92,17 +96,23 @@ __global__ __launch_bounds__(64) void k_sample(KArgs a) {
             }
             // a failed solve leaves the zero pose (safeSolvePnP, esac_util.h:107-111)
         }
+        // lowest accepted try of the round = the try the reference's sequential loop stops at
         const unsigned long long m = __ballot(accepted);
-        const bool last_round = base + 64 >= a.max_tries;
+        if (lane == 0) s_first[parity][wave] = m ? base + wave * 64 + (__ffsll((long long)m) - 1) : 0x7fffffff;
+        __syncthreads();
+        int first = s_first[parity][0];
+#pragma unroll
+        for (int w = 1; w < SAMPLE_B / 64; w++) first = min(first, s_first[parity][w]);
+        const bool last_round = base + SAMPLE_B >= a.max_tries;
         int writer = -1, tries_val = -1;
-        if (m) {
-            writer = __ffsll((long long)m) - 1;
-            tries_val = base + writer;
+        if (first != 0x7fffffff) {
+            writer = first;
+            tries_val = first;
         } else if (last_round) {
-            writer = (a.max_tries - 1) - base;  // budget exhausted: state of the last try remains
+            writer = a.max_tries - 1;  // budget exhausted: state of the last try remains
         }
         if (writer >= 0) {
-            if (lane == writer) {
+            if (t == writer) {
                 double* hp = a.hyps + (size_t)h * 6;
                 hp[0] = rvec[0]; hp[1] = rvec[1]; hp[2] = rvec[2];
                 hp[3] = T[0]; hp[4] = T[1]; hp[5] = T[2];
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a, int all) {
 }
 
 // ---------------------------------------------------------------- launchers
-void launch_sample(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_sample, dim3(a.N), dim3(64), 0, s, a); }
+void launch_sample(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_sample, dim3(a.N), dim3(SAMPLE_B), 0, s, a); }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hyps_to_rt32, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
 }

@@ -36,7 +36,7 @@ namespace esac {
 constexpr int REFINE_B = ESAC_REFINE_B;  // default 4 wavefronts = one per SIMD of the one CU this kernel occupies
 constexpr int LDS_CAP = 8192;            // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
 #ifndef ESAC_ERR_UNROLL
-#define ESAC_ERR_UNROLL 4
+#define ESAC_ERR_UNROLL 8
 #endif
 #ifndef ESAC_LM_NP
 #define ESAC_LM_NP 2
@@ -81,60 +81,142 @@ __device__ __forceinline__ double pow10_int(int k) {
 }
 
 // Fused pass over the whole grid at `pose`:
-//   a.errs[i]  = min(exact reprojection error, maxReproj)          (getReproErrs, esac_util.h:292-360)
+//   a.errs[i]  = min(reprojection error, maxReproj)                (getReproErrs, esac_util.h:292-360);
+//                reference-exact near tau, fp32-accurate (~1e-3 px) elsewhere -- see the screening below
 //   map_out[i] = err < tau                                         (localInlierMap, esac_util.h:401-414)
 //   list[...]  = the inliers, compacted in index order (deterministic), at most `cap`
 // Returns the inlier count (same value in every thread).
-template <int B, typename ListPtr>
-__device__ __forceinline__ int error_pass(const KArgs& a, const float* __restrict__ mx, int P, const double pose[6],
-                                          const Cam& cam, ListPtr list, int cap, uint8_t* __restrict__ map_out,
-                                          int* s_wcnt) {
-    constexpr int U = ERR_UNROLL, NW = B / 64;
+template <int B, bool VEC, typename ListPtr>
+__device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __restrict__ mx, int P, const double pose[6],
+                                               const Cam& cam, ListPtr list, int cap, uint8_t* __restrict__ map_out,
+                                               int* s_wcnt, long long* g_cyc) {
+    CYC_DECL;
+    // VEC: every lane owns G groups of 4 CONSECUTIVE cells per trip (W % 4 == 0: a group never straddles a
+    // row, planes are 16-byte aligned) -> float4 loads, one float4 + one packed-byte store per group.
+    // Otherwise: U cells per lane strided by B, scalar accesses.
+    constexpr int G = VEC ? ERR_UNROLL / 4 : ERR_UNROLL;  // load groups per lane per trip
+    constexpr int L = VEC ? 4 : 1;                        // cells per group
+    constexpr int U = G * L, NW = B / 64;
+    static_assert(ERR_UNROLL % 4 == 0, "ERR_UNROLL must be a multiple of 4");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double R[9];
     rodrigues_vec2mat<false>(pose, R, nullptr);
+    float Rf[9], tf[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rf[k] = (float)R[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) tf[k] = (float)pose[3 + k];
+    // fp32 screening band (see below): first-order bound of the fp32 evaluation's error with 10 ulp of
+    // head-room on every term.  Camera-frame coordinates carry ~eps*(|Xc|+2|t|), amplified by
+    // f/zc*(1+|x/z|); the pixel-space terms are bounded by eps*(image extent + tau).
+    const float tmag2 = 2.0f * (fabsf(tf[0]) + fabsf(tf[1]) + fabsf(tf[2]));
+    const float kf = 1.2e-6f * a.focal;
+    const float kpix = 1.2e-6f * 4.0f * ((float)(a.W + a.H) * (float)a.sub + fabsf(a.ppx) + fabsf(a.ppy) + a.tau);
+    // a lane's groups advance by B*L cells per step: (row, col) kept incrementally, one division in total
+    const int stepR = (B * L) / a.W, stepC = B * L - stepR * a.W;
+    int row = ((int)threadIdx.x * L) / a.W, col = (int)threadIdx.x * L - row * a.W;
     int base = 0;
     for (int start = 0; start < P; start += B * U) {
-        float X[U], Y[U], Z[U];
-        int pxi[U], pyi[U];
+        const bool full = start + B * U <= P;  // wave-uniform: no bounds checks in full trips
+        float X[U], Y[U], Z[U], pxf[U], pyf[U], errv[U];
+        int pxi[U], pyi[U], cell[G];
         bool flag[U];
+        CYC_BEGIN();
 #pragma unroll
-        for (int u = 0; u < U; u++) {  // all loads first: one memory latency for the U points
-            const int i = start + u * B + threadIdx.x;
-            const int ic = i < P ? i : P - 1;
-            X[u] = mx[ic];
-            Y[u] = mx[P + ic];
-            Z[u] = mx[2 * P + ic];
-            const int row = ic / a.W, col = ic - row * a.W;
-            pxi[u] = cell_pxi(a, col);
-            pyi[u] = cell_pyi(a, row);
-        }
-        float pxf[U], pyf[U], errv[U];
+        for (int g = 0; g < G; g++) {  // all loads first: one memory latency for the U cells
+            const int i = start + (g * B + (int)threadIdx.x) * L;
+            cell[g] = i;
+            const int ic = full ? i : (i < P ? i : P - L);
+            if (VEC) {
+                const float4 vx = *reinterpret_cast<const float4*>(mx + ic);
+                const float4 vy = *reinterpret_cast<const float4*>(mx + P + ic);
+                const float4 vz = *reinterpret_cast<const float4*>(mx + 2 * P + ic);
+                X[4 * g] = vx.x; X[4 * g + 1] = vx.y; X[4 * g + 2] = vx.z; X[4 * g + 3] = vx.w;
+                Y[4 * g] = vy.x; Y[4 * g + 1] = vy.y; Y[4 * g + 2] = vy.z; Y[4 * g + 3] = vy.w;
+                Z[4 * g] = vz.x; Z[4 * g + 1] = vz.y; Z[4 * g + 2] = vz.z; Z[4 * g + 3] = vz.w;
+            } else {
+                X[g] = mx[ic];
+                Y[g] = mx[P + ic];
+                Z[g] = mx[2 * P + ic];
+            }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            pxf[u] = (float)pxi[u];
-            pyf[u] = (float)pyi[u];
-        }
-        project_exact_err_batch<U>(R, pose + 3, cam, X, Y, Z, pxf, pyf, errv);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int i = start + u * B + threadIdx.x;
-            float err = errv[u];
-            err = err < a.max_reproj ? err : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
-            flag[u] = (i < P) && (err < a.tau);
-            if (i < P) {
-                a.errs[i] = err;
-                map_out[i] = flag[u] ? 1 : 0;
+            for (int l = 0; l < L; l++) {
+                pxi[g * L + l] = cell_pxi(a, col + l);
+                pyi[g * L + l] = cell_pyi(a, row);
+                pxf[g * L + l] = (float)pxi[g * L + l];
+                pyf[g * L + l] = (float)pyi[g * L + l];
+            }
+            col += stepC;
+            row += stepR;
+            if (col >= a.W) {
+                col -= a.W;
+                row++;
             }
         }
+        CYC_END(10);
+        CYC_BEGIN();
+        // fp32 screening: a cell whose fp32 error is farther from tau than the bound above cannot change
+        // side under the reference arithmetic.  Only cells inside that band -- a few per ten thousand --
+        // pay for the exact fp64 evaluation, so `err < tau` is decided exactly everywhere.
+        bool need_exact = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const float xc = fmaf(Rf[0], X[u], fmaf(Rf[1], Y[u], fmaf(Rf[2], Z[u], tf[0])));
+            const float yc = fmaf(Rf[3], X[u], fmaf(Rf[4], Y[u], fmaf(Rf[5], Z[u], tf[1])));
+            const float zc = fmaf(Rf[6], X[u], fmaf(Rf[7], Y[u], fmaf(Rf[8], Z[u], tf[2])));
+            const float iz = (zc != 0.0f) ? __builtin_amdgcn_rcpf(zc) : 1.0f;
+            const float du = pxf[u] - fmaf(a.focal, xc * iz, a.ppx);
+            const float dv = pyf[u] - fmaf(a.focal, yc * iz, a.ppy);
+            errv[u] = __builtin_amdgcn_sqrtf(fmaf(du, du, dv * dv));
+            const float aiz = fabsf(iz), axy = fabsf(xc) + fabsf(yc);
+            const float guard = fmaf(kf * aiz * (axy + fabsf(zc) + tmag2), fmaf(axy, aiz, 1.0f), kpix);
+            // not finite, or within the band -> the reference-exact evaluation decides
+            need_exact |= !(fabsf(errv[u] - a.tau) > guard);
+        }
+        CYC_END(11);
+        CYC_BEGIN();
+        if (__any(need_exact)) {  // wave-uniform branch: the exact pass costs ~10x the screening
+            CYC_ADD(15, 1);
+            float exact[U];
+            project_exact_err_batch<U>(R, pose + 3, cam, X, Y, Z, pxf, pyf, exact);
+#pragma unroll
+            for (int u = 0; u < U; u++) errv[u] = exact[u];
+        }
+        CYC_END(12);
+        CYC_BEGIN();
         int within[U];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const bool in_range = full || cell[g] < P;
+#pragma unroll
+            for (int l = 0; l < L; l++) {
+                const int u = g * L + l;
+                errv[u] = errv[u] < a.max_reproj ? errv[u] : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+                flag[u] = in_range && (errv[u] < a.tau);
+            }
+            if (in_range) {
+                if (VEC) {
+                    *reinterpret_cast<float4*>(a.errs + cell[g]) = make_float4(errv[4 * g], errv[4 * g + 1], errv[4 * g + 2], errv[4 * g + 3]);
+                    *reinterpret_cast<uint32_t*>(map_out + cell[g]) = (flag[4 * g] ? 1u : 0u) | (flag[4 * g + 1] ? 0x100u : 0u) |
+                                                                        (flag[4 * g + 2] ? 0x10000u : 0u) | (flag[4 * g + 3] ? 0x1000000u : 0u);
+                } else {
+                    a.errs[cell[g]] = errv[g];
+                    map_out[cell[g]] = flag[g] ? 1 : 0;
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const unsigned long long m = __ballot(flag[u]);
             within[u] = __popcll(m & ((1ull << lane) - 1ull));
             if (lane == 0) s_wcnt[u * NW + wave] = __popcll(m);
         }
-        __syncthreads();
+        CYC_END(13);
+        CYC_BEGIN();
+        barrier_lds();
+        CYC_END(3);
+        CYC_BEGIN();
+        // deterministic compaction; the order (sub-step, wavefront, lane) is fixed, not the cell order
         int off = base;
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -153,7 +235,8 @@ __device__ __forceinline__ int error_pass(const KArgs& a, const float* __restric
             off += total;
         }
         base = off;
-        __syncthreads();
+        barrier_lds();
+        CYC_END(14);
     }
     return base;
 }
@@ -217,101 +300,82 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
 
 // cv::solvePnP(ITERATIVE, useExtrinsicGuess): CvLevMarq with 6 parameters, max_iter 20, eps FLT_EPSILON,
 // lambda = 10^k from k = -3, k++ while a step made the error worse (<= 16), k-- after an accepted step.
+// cv::solvePnP(ITERATIVE, useExtrinsicGuess): CvLevMarq with 6 parameters, max_iter 20, eps FLT_EPSILON,
+// lambda = 10^k from k = -3, k++ while a step made the error worse (<= 16), k-- after an accepted step.
+// Written as ONE loop around ONE lm_pass call site (the kernel must stay inside the instruction cache:
+// with the pass inlined at several sites the code grew to 170 KB and every phase ran from cold code).
 template <int B, typename ListPtr>
 __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], const Cam& cam, double* s_part,
                                         double* s_tot, long long* g_cyc) {
     CYC_DECL;
     double param[6], prev[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) param[k] = pose[k];
+    for (int k = 0; k < 6; k++) param[k] = prev[k] = pose[k];
     double U21[21], g6[6];    // normal equations at `prev` (state CALC_J)
-    double U21t[21], g6t[6];  // ... at the trial point
-    double prev_err_norm = sqrt(lm_pass<B>(list, n, param, cam, U21, g6, s_part, s_tot, g_cyc));
+    double U21t[21], g6t[6];  // ... at the point just evaluated
+    double prev_err_norm = 0;
     int lambda_lg10 = -3, iters = 0;
+    bool have_base = false;
     for (;;) {
+        // residual norm and (speculatively) the normal equations at `param`
+        const double err_norm = sqrt(lm_pass<B>(list, n, param, cam, U21t, g6t, s_part, s_tot, g_cyc));
+        bool accept;
+        if (!have_base) {
+            have_base = true;  // iters == 0: prevErrNorm = |err(initial pose)|
+            accept = true;
+        } else if (err_norm > prev_err_norm && ++lambda_lg10 <= 16) {
+            accept = false;  // state CHECK_ERR failed: retry from `prev` with a larger lambda
+        } else {
+            lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
+            double dn = 0, pn = 0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) prev[k] = param[k];
-        double err_norm;
-        for (;;) {
-            // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
-            const double lambda = pow10_int(lambda_lg10);
-            double dx[6];
-            CYC_BEGIN();
-            lm_solve6(U21, g6, lambda, dx);
-            CYC_END(8);
-#pragma unroll
-            for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
-            // state CHECK_ERR at the trial point; the same pass gathers the normal equations there
-            err_norm = sqrt(lm_pass<B>(list, n, param, cam, U21t, g6t, s_part, s_tot, g_cyc));
-            if (err_norm > prev_err_norm) {
-                if (++lambda_lg10 <= 16) continue;
+            for (int k = 0; k < 6; k++) {
+                dn += (param[k] - prev[k]) * (param[k] - prev[k]);
+                pn += prev[k] * prev[k];
             }
-            break;
+            const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);  // cvNorm(param, prevParam, CV_RELATIVE_L2)
+            ++iters;
+            if (iters >= 20 || rel < (double)FLT_EPSILON) break;
+            accept = true;
         }
-        lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
-        double dn = 0, pn = 0;
+        if (accept) {  // state CALC_J at the accepted point
+            prev_err_norm = err_norm;
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            dn += (param[k] - prev[k]) * (param[k] - prev[k]);
-            pn += prev[k] * prev[k];
+            for (int k = 0; k < 21; k++) U21[k] = U21t[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                g6[k] = g6t[k];
+                prev[k] = param[k];
+            }
         }
-        const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);  // cvNorm(param, prevParam, CV_RELATIVE_L2)
-        ++iters;
-        if (iters >= 20 || rel < (double)FLT_EPSILON) break;
-        prev_err_norm = err_norm;
+        // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
+        double dx[6];
+        CYC_BEGIN();
+        lm_solve6(U21, g6, pow10_int(lambda_lg10), dx);
+        CYC_END(8);
 #pragma unroll
-        for (int k = 0; k < 21; k++) U21[k] = U21t[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) g6[k] = g6t[k];
+        for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = param[k];
     return iters;
 }
 
-// refineHyp (esac_util.h:378-454) with the correspondence list in LDS or in global memory
-template <int B, typename ListPtr>
-__device__ __forceinline__ void refine_loop(const KArgs& a, const float* __restrict__ mx, int P, const Cam& cam,
-                                            ListPtr list, int cap, double pose[6], int* s_wcnt, double* s_part,
-                                            double* s_tot, int& accepted, int& last_inliers, int& lm_total,
-                                            int& map_buf, long long* g_cyc) {
-    CYC_DECL;
-    CYC_BEGIN();
-    int cur = 0;  // map buffer the NEXT error pass writes
-    int n_inl = error_pass<B>(a, mx, P, pose, cam, list, cap, a.inlier_map, s_wcnt);  // reproErrs[hypIdx], esac.cpp:169
-    __syncthreads();
-    CYC_END(2);
-    unsigned best_inliers = 4;
-    for (int rstep = 0; rstep < a.max_ref_steps; rstep++) {
-        if (threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
-        if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
-        best_inliers = (unsigned)n_inl;
-        lm_total += lm_refit<B>(list, n_inl, pose, cam, s_part, s_tot, g_cyc);
-        accepted++;
-        last_inliers = n_inl;
-        map_buf = cur;  // inlierMap = this step's set (esac_util.h:440)
-        cur ^= 1;
-        CYC_BEGIN();
-        __syncthreads();  // every lane is done reading the list before it is rebuilt
-        n_inl = error_pass<B>(a, mx, P, pose, cam, list, cap, a.inlier_map + (size_t)cur * P, s_wcnt);  // esac_util.h:445-452
-        __syncthreads();
-        CYC_END(2);
-    }
-}
-
-template <int B>
+// GLOBAL_LIST: correspondence list in global memory (grids with more than LDS_CAP cells), else in LDS.
+// VEC: 16-byte accesses in the error pass (W % 4 == 0 and a 16-byte aligned coordinate tensor).
+template <int B, bool GLOBAL_LIST, bool VEC>
 __global__ __launch_bounds__(B) void k_refine(KArgs a) {
-    __shared__ Corr s_list[LDS_CAP];
+    __shared__ Corr s_list[GLOBAL_LIST ? 1 : LDS_CAP];
     __shared__ double s_part[28 * (B / 64)];
     __shared__ double s_tot[28];
     __shared__ double s_best[B / 64];
     __shared__ int s_besti[B / 64];
     __shared__ int s_bestg[B / 64];
-    __shared__ int s_wcnt[ERR_UNROLL * (B / 64)];
+    __shared__ int s_wcnt[ERR_UNROLL * (B / 64)];  // per (sub-step, wavefront) inlier counts
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long g_cyc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long g_cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)g_cyc;
     CYC_DECL;
 #ifdef ESAC_PROFILE_CYCLES
@@ -377,13 +441,30 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     __syncthreads();
     CYC_END(1);
 
+    // ---- refineHyp (esac_util.h:378-454): one error-pass site, one re-fit site
+    Corr* const list = GLOBAL_LIST ? reinterpret_cast<Corr*>(a.corr_list) : s_list;
+    const int cap = GLOBAL_LIST ? P : LDS_CAP;
     int accepted = 0, last_inliers = 0, lm_total = 0, map_buf = -1;
-    if (P <= LDS_CAP)
-        refine_loop<B>(a, mx, P, cam, (Corr*)s_list, LDS_CAP, pose, s_wcnt, s_part, s_tot, accepted, last_inliers,
-                       lm_total, map_buf, g_cyc);
-    else
-        refine_loop<B>(a, mx, P, cam, reinterpret_cast<Corr*>(a.corr_list), P, pose, s_wcnt, s_part, s_tot, accepted,
-                       last_inliers, lm_total, map_buf, g_cyc);
+    int cur = 0;  // map buffer the next error pass writes
+    unsigned best_inliers = 4;
+    for (int rstep = 0;; rstep++) {
+        // error image of the current pose (reproErrs[hypIdx], esac.cpp:169, then esac_util.h:445-452),
+        // this step's inlier set and its compacted correspondence list
+        CYC_BEGIN();
+        __syncthreads();  // every lane is done reading the list before it is rebuilt
+        const int n_inl = error_pass_impl<B, VEC>(a, mx, P, pose, cam, list, cap, a.inlier_map + (size_t)cur * P, s_wcnt, g_cyc);
+        __syncthreads();
+        CYC_END(2);
+        if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
+        if (threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
+        if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
+        best_inliers = (unsigned)n_inl;
+        lm_total += lm_refit<B>((const Corr*)list, n_inl, pose, cam, s_part, s_tot, g_cyc);
+        accepted++;
+        last_inliers = n_inl;
+        map_buf = cur;  // inlierMap = this step's set (esac_util.h:440)
+        cur ^= 1;
+    }
 
     // ---- pose2trans (esac_util.h:537-548) and the result record
     if (threadIdx.x == 0) {
@@ -409,22 +490,23 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
 #ifdef ESAC_PROFILE_CYCLES
         g_cyc[0] = clock64() - cyc_start;
-        for (int k = 0; k < 10; k++) a.cycles[k] = g_cyc[k];
+        for (int k = 0; k < 16; k++) a.cycles[k] = g_cyc[k];
 #endif
     }
 }
 
 void launch_refine(const KArgs& a, hipStream_t s) {
-    // ESAC_REFINE_B=512 selects the two-wavefronts-per-SIMD build (tuning knob, default REFINE_B)
-    static const int block = [] {
-        const char* e = getenv("ESAC_REFINE_B");
-        const int v = e ? atoi(e) : REFINE_B;
-        return v == 512 ? 512 : 256;
-    }();
-    if (block == 256)
-        hipLaunchKernelGGL(k_refine<256>, dim3(1), dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL(k_refine<512>, dim3(1), dim3(512), 0, s, a);
+    constexpr int B = REFINE_B;
+    const bool global_list = a.H * a.W > LDS_CAP;
+    // 16-byte accesses: W % 4 == 0 keeps every row, plane (P % 4 == 0) and expert map 16-byte aligned
+    const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
+    if (global_list) {
+        if (vec) hipLaunchKernelGGL((k_refine<B, true, true>), dim3(1), dim3(B), 0, s, a);
+        else     hipLaunchKernelGGL((k_refine<B, true, false>), dim3(1), dim3(B), 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_refine<B, false, true>), dim3(1), dim3(B), 0, s, a);
+        else     hipLaunchKernelGGL((k_refine<B, false, false>), dim3(1), dim3(B), 0, s, a);
+    }
 }
 
 }  // namespace esac

@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "esac_hip_abi_version", "esac_hip_last_error", "esac_hip_device_count", "esac_hip_create", "esac_hip_destroy",
     "esac_hip_forward", "esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine",
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
+    "esac_hip_score_span_ms",
 ]
 
 
@@ -79,6 +80,7 @@ def load_library():
         lib.esac_hip_write_hyps.argtypes = [vp, vp, i32]
         lib.esac_hip_phase_ms.argtypes = [vp, vp]
         lib.esac_hip_set_timing.argtypes = [vp, i32]
+        lib.esac_hip_score_span_ms.argtypes = [vp, vp, vp]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
                 getattr(lib, name).restype = i32
@@ -206,9 +208,15 @@ class Engine:
         _check(self.lib.esac_hip_set_timing(self.ctx, 1 if on else 0), self.lib)
 
     def phase_ms(self):
-        out = np.zeros(7, np.float32)
+        out = np.zeros(6, np.float32)
         _check(self.lib.esac_hip_phase_ms(self.ctx, out.ctypes.data_as(C.c_void_p)), self.lib)
         return out
+
+    def score_span_ms(self):
+        """(mean device-side duration of the score kernel in ms, number of launches averaged)."""
+        ms, n = C.c_float(0), C.c_int(0)
+        _check(self.lib.esac_hip_score_span_ms(self.ctx, C.byref(ms), C.byref(n)), self.lib)
+        return float(ms.value), int(n.value)
 
 
 # ---------------------------------------------------------------- module-level state

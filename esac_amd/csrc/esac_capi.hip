@@ -45,6 +45,9 @@ struct esac_hip_ctx {
     bool timing = false;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
+    double* h_pin = nullptr;  // pinned, device-visible host buffer: result record [32] + epoch word
+    double* d_pin = nullptr;  // its device address
+    double epoch = 0;
 };
 
 extern "C" int esac_hip_abi_version(void) { return ESAC_HIP_ABI_VERSION; }
@@ -77,6 +80,9 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
     esac_hip_ctx* c = new esac_hip_ctx();
     c->device = device;
     for (auto& ev : c->ev) HIP_OK(hipEventCreate(&ev));
+    HIP_OK(hipHostMalloc((void**)&c->h_pin, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_pin, 0, 64 * sizeof(double));
+    HIP_OK(hipHostGetDevicePointer((void**)&c->d_pin, c->h_pin, 0));
     *out = c;
     return 0;
 }
@@ -85,6 +91,7 @@ extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     free_ws(c);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     delete c;
@@ -220,6 +227,11 @@ extern "C" int esac_hip_forward(esac_hip_ctx* c, const float* d_sc, const int64_
     int rc = make_args(c, d_sc, d_assign, p, &a);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    a.scores_user = d_scores_out;
+    a.result_user = d_result_out;
+    a.result_pin = h_result_out ? c->d_pin : nullptr;
+    c->epoch += 1.0;
+    a.epoch = c->epoch;
     const bool tm = c->timing;
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
     launch_sample(a, s);
@@ -243,12 +255,27 @@ extern "C" int esac_hip_forward(esac_hip_ctx* c, const float* d_sc, const int64_
         HIP_OK(hipEventRecord(c->ev[6], s));
         c->ev_valid = true;
     }
-    if (d_scores_out) HIP_OK(hipMemcpyAsync(d_scores_out, a.scores, (size_t)a.N * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (d_result_out)
-        HIP_OK(hipMemcpyAsync(d_result_out, a.result, ESAC_RES_DOUBLES * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (h_result_out) {
-        HIP_OK(hipMemcpyAsync(h_result_out, a.result, ESAC_RES_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
+        // the refinement kernel stores the record and then the epoch word into pinned host memory
+        volatile double* flag = c->h_pin + 32;
+        const double want = c->epoch;
+        bool landed = false;
+        for (long spins = 0; spins < 200000000L; spins++) {
+            if (*flag == want) {
+                landed = true;
+                break;
+            }
+            if ((spins & 1023) == 1023 && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernel is done (or failed)
+                landed = (*flag == want);
+                break;
+            }
+        }
+        if (!landed) {
+            HIP_OK(hipStreamSynchronize(s));
+            if (*flag != want) return fail(-9, "esac_hip_forward: the refinement kernel did not deliver a result record");
+        }
+        __sync_synchronize();
+        memcpy(h_result_out, (const void*)c->h_pin, ESAC_RES_DOUBLES * sizeof(double));
     }
     return 0;
 }
@@ -319,7 +346,7 @@ extern "C" int esac_hip_set_timing(esac_hip_ctx* c, int enabled) {
     return 0;
 }
 
-extern "C" int esac_hip_phase_ms(esac_hip_ctx* c, float out[7]) {
+extern "C" int esac_hip_phase_ms(esac_hip_ctx* c, float out[6]) {
     if (!c || !out) return fail(-1, "esac_hip_phase_ms: null argument");
     if (!c->timing || !c->ev_valid) return fail(-8, "esac_hip_phase_ms: timing is off or no forward has run");
     HIP_OK(hipEventSynchronize(c->ev[4]));
@@ -327,9 +354,18 @@ extern "C" int esac_hip_phase_ms(esac_hip_ctx* c, float out[7]) {
     HIP_OK(hipEventElapsedTime(&out[4], c->ev[0], c->ev[4]));
     HIP_OK(hipEventSynchronize(c->ev[6]));
     HIP_OK(hipEventElapsedTime(&out[5], c->ev[5], c->ev[6]));
+    return 0;
+}
+
+extern "C" int esac_hip_score_span_ms(esac_hip_ctx* c, float* mean_ms, int* launches) {
+    if (!c || !mean_ms) return fail(-1, "esac_hip_score_span_ms: null argument");
+    if (!c->ws.span_acc) return fail(-8, "esac_hip_score_span_ms: no forward has run");
+    HIP_OK(hipSetDevice(c->device));
+    HIP_OK(hipDeviceSynchronize());
     // mean device-side span of the score kernel since timing was enabled (100 MHz wall clock -> ms)
     long long acc[2] = {0, 0};
     HIP_OK(hipMemcpy(acc, c->ws.span_acc, sizeof(acc), hipMemcpyDeviceToHost));
-    out[6] = acc[1] > 0 ? (float)((double)acc[0] / (double)acc[1] * 1e-5) : 0.0f;
+    *mean_ms = acc[1] > 0 ? (float)((double)acc[0] / (double)acc[1] * 1e-5) : 0.0f;
+    if (launches) *launches = (int)acc[1];
     return 0;
 }

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(B) void k_select(KArgs a) {
     for (int i = threadIdx.x; i < a.N; i += B) {
         const float s = a.fast_scores[i];
         a.scores[i] = (double)s;
+        if (a.scores_user) a.scores_user[i] = (double)s;
         a.exact_flag[i] = 0;
         const double d = (double)s - (double)m;
         const double ex = exp(d);
@@ -331,6 +332,7 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a, int all) {
             double s = acc[0];
             s *= scale;  // double *= float
             a.scores[h] = s;
+            if (a.scores_user) a.scores_user[h] = s;
             a.exact_flag[h] = 1;
         }
         __syncthreads();

@@ -42,6 +42,11 @@ struct KArgs {
     long long* cycles;    // [32] shader-cycle counters of the refinement kernel's sections (profiling aid)
     long long* tstamps;   // [2N] per-workgroup (start,end) wall-clock stamps of the score kernel, or nullptr
     long long* span_acc;  // [2] accumulated score-kernel span (100 MHz ticks) and launch count
+    // caller-visible outputs written by the kernels themselves (no copy kernels on the critical path)
+    double* scores_user;  // optional device [N]: the score vector
+    double* result_user;  // optional device [32]: the result record
+    double* result_pin;   // optional pinned HOST memory [33] (device-visible): result record + epoch word
+    double epoch;         // value stored into result_pin[32] after the record (the host polls it)
 };
 
 void launch_sample(const KArgs& a, hipStream_t s);

@@ -488,6 +488,18 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         r[ESAC_RES_CONTENDERS_K] = (double)nc;
         r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
         r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
+        if (a.result_user) {
+#pragma unroll
+            for (int k = 0; k < 32; k++) a.result_user[k] = r[k];
+        }
+        if (a.result_pin) {
+            // straight into pinned host memory: the host polls the epoch word instead of waiting for a
+            // copy kernel + stream-completion signal (saves ~15-20 us of the blocking call's latency)
+#pragma unroll
+            for (int k = 0; k < 32; k++) a.result_pin[k] = r[k];
+            __threadfence_system();
+            *reinterpret_cast<volatile double*>(a.result_pin + 32) = a.epoch;
+        }
 #ifdef ESAC_PROFILE_CYCLES
         g_cyc[0] = clock64() - cyc_start;
         for (int k = 0; k < 16; k++) a.cycles[k] = g_cyc[k];

@@ -115,8 +115,10 @@ int esac_hip_destroy(esac_hip_ctx* ctx);
  * d_scene_coords  [E,3,H,W] float32, d_hyp_assign [N] int64 (device).
  * d_scores_out    optional device double[N]  (the score vector; all-reduced across ranks by the caller)
  * d_result_out    optional device double[ESAC_RES_DOUBLES]
- * h_result_out    optional host   double[ESAC_RES_DOUBLES]; when non-NULL the call
- *                 synchronises the stream before returning (the reference call is blocking).
+ * h_result_out    optional host   double[ESAC_RES_DOUBLES]; when non-NULL the call blocks until the
+ *                 refinement kernel has delivered the record (it stores it into pinned host memory and
+ *                 the host polls an epoch word: no copy kernel, no completion-signal round trip);
+ *                 the reference call is blocking too.
  */
 int esac_hip_forward(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
                      const esac_hip_params* p, void* stream, double* d_scores_out,
@@ -145,11 +147,13 @@ int esac_hip_write_hyps(esac_hip_ctx* ctx, const double* h_hyps, int N);
 /* Time of the most recent launch of each phase on this context in milliseconds
  * (hipEvents around each kernel; the StopWatch prints of esac.cpp:124,149,161,179).
  * out[0..4] = sample, score, select+rescore, refine, total; out[5] = an empty event interval (the
- * bracketing overhead contained in each of the four phase figures); out[6] = mean duration of the
- * score kernel itself since timing was enabled, measured on the device (max end - min start of its
- * workgroups on the constant 100 MHz wall clock) -- the figure rocprofv3's kernel trace reports.
- * Synchronises. */
-int esac_hip_phase_ms(esac_hip_ctx* ctx, float out[7]);
+ * bracketing overhead contained in each of the four phase figures).  Synchronises on the last event. */
+int esac_hip_phase_ms(esac_hip_ctx* ctx, float out[6]);
+/* Mean duration of the score kernel itself over every launch since timing was enabled, measured on the
+ * device: max(end) - min(start) over its workgroups on the constant 100 MHz wall clock -- the figure
+ * rocprofv3's kernel trace reports (hipEvents around one ~3 us launch also contain the launch gap).
+ * Synchronises the device. */
+int esac_hip_score_span_ms(esac_hip_ctx* ctx, float* mean_ms, int* launches);
 /* enable/disable the per-phase events (off by default: zero overhead) */
 int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
 

@@ -61,9 +61,36 @@ def cpu_baseline(frames, assigns, n_hyp):
         if best is None or med < best[0]:
             best = (med, threads, len(times))
     med, threads, n = best
-    return {"value": n_hyp / med, "unit": "hypotheses/s", "cores": threads, "kind": "port",
-            "sample": "median of %d oracle esac_forward calls on the same workload (%d hyp, 60x80 grid), %d thread(s); "
-                      "host has %d hardware threads" % (n, n_hyp, threads, os.cpu_count())}
+    out = {"value": n_hyp / med, "unit": "hypotheses/s", "cores": threads, "kind": "port",
+           "sample": "median of %d oracle esac_forward calls on the same workload (%d hyp, 60x80 grid), %d thread(s); "
+                     "host has %d hardware threads" % (n, n_hyp, threads, os.cpu_count())}
+    # oracle/_ref = the reference's own esac_util.h code (OpenCV stand-in shim), its OpenMP pragmas on all threads
+    try:
+        from oracle import ref_binding
+        if os.path.exists(ref_binding.LIB_PATH):
+            import ctypes as C
+            L = ref_binding.lib()
+            times = []
+            f, ha = frames[0], np.ascontiguousarray(assigns[0], np.int64)
+            sc = np.ascontiguousarray(f["coords"], np.float32)
+            E, _, H, W = sc.shape
+            bufs = [np.zeros((4, 4), np.float32), np.zeros((n_hyp, 8), np.int32), np.zeros((n_hyp, 6)), np.zeros(n_hyp),
+                    np.zeros(1, np.int32), np.zeros(6), np.zeros((H, W), np.uint8), np.zeros(1)]
+            p = lambda a: a.ctypes.data_as(C.c_void_p)
+            for i in range(2 + 10):
+                t0 = time.time()
+                L.ref_forward(p(sc), E, H, W, p(ha), n_hyp, p(bufs[0]), 0, 0, f["focal"], f["ppx"], f["ppy"], 10.0, 100.0,
+                              0.5, 100.0, f["sub"], 1000000, 100, *[p(b) for b in bufs[1:]])
+                if i >= 2:
+                    times.append(time.time() - t0)
+            ref_rate = n_hyp / float(np.median(times))
+            out["reference_sources_value"] = ref_rate
+            out["sample"] += "; oracle/_ref (reference esac_util.h + OpenCV stand-in, all OpenMP threads): %.0f hypotheses/s" % ref_rate
+            if ref_rate > out["value"]:
+                out.update(value=ref_rate, kind="reference", cores=O.max_threads())
+    except Exception as exc:  # the baseline leg must never break the bench line
+        out["sample"] += "; oracle/_ref not timed (%s)" % type(exc).__name__
+    return out
 
 
 def main():

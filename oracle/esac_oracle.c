@@ -771,16 +771,11 @@ int esac_oracle_lm_pnp(const float* obj, const float* img, int n, double fx, dou
 /* pose2trans (esac_util.h:537-548): T = [R t; 0 1], returned INVERTED by a   */
 /* generic LU inverse (cv::Mat::inv default DECOMP_LU, partial pivoting).     */
 /* ------------------------------------------------------------------------- */
-void esac_oracle_pose2trans(const double pose[6], double Tinv[16]) {
-    double R[9], A[4][8];
-    esac_oracle_rodrigues_vec2mat(pose, R, NULL);
+/* generic 4x4 inverse: LU with partial pivoting on the augmented matrix (cv::Mat::inv, DECOMP_LU) */
+void esac_oracle_inv4(const double M[16], double Minv[16]) {
+    double A[4][8];
     for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 8; j++) A[i][j] = (j - 4 == i);
-    for (int i = 0; i < 3; i++) {
-        for (int j = 0; j < 3; j++) A[i][j] = R[3 * i + j];
-        A[i][3] = pose[3 + i];
-    }
-    A[3][0] = A[3][1] = A[3][2] = 0; A[3][3] = 1;
+        for (int j = 0; j < 8; j++) A[i][j] = j < 4 ? M[4 * i + j] : (j - 4 == i);
     for (int c = 0; c < 4; c++) {
         int piv = c;
         for (int r = c + 1; r < 4; r++)
@@ -802,7 +797,18 @@ void esac_oracle_pose2trans(const double pose[6], double Tinv[16]) {
         }
     }
     for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) Tinv[4 * i + j] = A[i][4 + j];
+        for (int j = 0; j < 4; j++) Minv[4 * i + j] = A[i][4 + j];
+}
+
+void esac_oracle_pose2trans(const double pose[6], double Tinv[16]) {
+    double R[9], T[16];
+    esac_oracle_rodrigues_vec2mat(pose, R, NULL);
+    for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0);
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[4 * i + j] = R[3 * i + j];
+        T[4 * i + 3] = pose[3 + i];
+    }
+    esac_oracle_inv4(T, Tinv);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -100,6 +100,7 @@ void esac_oracle_project(const double rvec[3], const double tvec[3], double fx, 
 int  esac_oracle_lm_pnp(const float* obj, const float* img, int n, double fx, double fy,
                         double cx, double cy, double pose[6]);
 void esac_oracle_pose2trans(const double pose[6], double T[16]);
+void esac_oracle_inv4(const double M[16], double Minv[16]);
 int  esac_oracle_max_threads(void);
 
 #ifdef __cplusplus

@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--experts", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid", type=str, default="60x80")
+    ap.add_argument("--batch", type=int, default=64, help="frames per launch set for the extra `batched` figure (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,12 +202,36 @@ def main():
                          "refine_steps_per_frame": ref_steps / args.steps, "lm_iters_per_frame": lm_iters / args.steps},
             "roofline": {"kernel": "k_score_fast", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None,
+                         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE 281.5 KB
+                         # doubled per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE 8 KB); only valid
+                         # for the default workload the profile was taken on, null otherwise
+                         "traffic": (2 * 281.52 + 8.0) * 1024 if (args.experts, n_local, H, W) == (1, 256, 60, 80) else None,
+                         "traffic_source": "profiles/r01_bench_cfg2_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": score_ms,
                          "note": "60x80 grid: 14.7 MB algorithmic per launch, map re-read from L2 by every "
                                  "hypothesis -> latency-bound, see DESIGN.md"},
         }
+        if args.batch > 0 and world == 1:
+            # extra figure (not `value`): B independent frames per launch set through esac_hip_forward_batch --
+            # the single call's tail is one CU of fp64 work, so frames in flight are what fills the chip
+            Bf = args.batch
+            eng.set_timing(False)
+            bc = torch.stack([d_coords[k % n_frames] for k in range(Bf)]).contiguous()
+            ba = torch.stack([d_assign[k % n_frames][:n_local] for k in range(Bf)]).contiguous()
+            bscores = torch.empty(Bf, n_local, dtype=torch.float64, device=dev)
+            nb = max(4, min(40, args.steps // 8))
+            for i in range(3):
+                eng.forward_batch(bc, ba, eng.make_params(args.experts, H, W, n_local, seed=1305, call=i * Bf, **kw), scores_out=bscores)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for i in range(nb):
+                eng.forward_batch(bc, ba, eng.make_params(args.experts, H, W, n_local, seed=1305, call=(3 + i) * Bf, **kw), scores_out=bscores)
+            torch.cuda.synchronize()
+            tb = time.perf_counter() - tb
+            out["batched"] = {"frames_per_launch": Bf, "launches_timed": nb, "ms_per_batch": tb / nb * 1e3,
+                              "value": Bf * n_local * nb / tb, "unit": "hypotheses/s",
+                              "note": "esac.forward_batch: frame b == the b-th of B sequential forward calls, bit for bit"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, [a[:n_local] for a in assigns], n_local)
         print(json.dumps(out))

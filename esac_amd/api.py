@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "esac_hip_abi_version", "esac_hip_last_error", "esac_hip_device_count", "esac_hip_create", "esac_hip_destroy",
     "esac_hip_forward", "esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine",
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
-    "esac_hip_score_span_ms",
+    "esac_hip_score_span_ms", "esac_hip_forward_batch",
 ]
 
 
@@ -74,6 +74,7 @@ def load_library():
         lib.esac_hip_create.argtypes = [C.POINTER(vp), i32]
         lib.esac_hip_destroy.argtypes = [vp]
         lib.esac_hip_forward.argtypes = [vp, vp, vp, pp, vp, vp, vp, vp]
+        lib.esac_hip_forward_batch.argtypes = [vp, i32, vp, C.c_int64, vp, pp, vp, vp, vp, vp]
         for name in ("esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine", "esac_hip_score_exact"):
             getattr(lib, name).argtypes = [vp, vp, vp, pp, vp]
         lib.esac_hip_read.argtypes = [vp, i32, vp, C.c_size_t]
@@ -161,6 +162,24 @@ class Engine:
                 result_out.data_ptr() if result_out is not None else None,
                 host.ctypes.data_as(C.c_void_p) if want_host else None), self.lib)
         self._keep = (sc, ha)  # keep inputs alive until the (possibly asynchronous) kernels have run
+        return host
+
+    def forward_batch(self, scene_coords, hyp_assign, params, scores_out=None, result_out=None, want_host=True):
+        """B frames per launch set. scene_coords [B,E,3,H,W] (or [E,3,H,W] shared by all frames), hyp_assign [B,N];
+        `params` describes one frame, frame b uses call + b. Returns np.float64 [B,32] (or None)."""
+        sc = scene_coords if scene_coords.is_cuda else scene_coords.to(self.device, non_blocking=True)
+        ha = hyp_assign if hyp_assign.is_cuda else hyp_assign.to(self.device, non_blocking=True)
+        sc, ha = sc.contiguous(), ha.contiguous()
+        B = int(ha.shape[0])
+        stride = int(sc.stride(0)) if sc.dim() == 5 else 0
+        host = np.zeros((B, RES_DOUBLES), np.float64) if want_host else None
+        with torch.cuda.device(self.device):
+            _check(self.lib.esac_hip_forward_batch(
+                self.ctx, B, sc.data_ptr(), stride, ha.data_ptr(), C.byref(params), self._stream(),
+                scores_out.data_ptr() if scores_out is not None else None,
+                result_out.data_ptr() if result_out is not None else None,
+                host.ctypes.data_as(C.c_void_p) if want_host else None), self.lib)
+        self._keep = (sc, ha)
         return host
 
     # -- single phases (stage-wise parity tests)
@@ -297,6 +316,33 @@ def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLengt
     outPose.copy_(pose)  # in place, caller-owned (esac.cpp:184-187)
     _state["last"] = {"scores": scores, "result": res, "winner": int(res[RES_HYP]), "expert": int(res[RES_EXPERT])}
     return int(res[RES_EXPERT])
+
+
+def forward_batch(sceneCoordinates, hypAssignment, outPoses, shiftX, shiftY, focalLength, ppointX, ppointY,
+                  inlierThreshold, inlierAlpha, inlierBeta, maxReproj, subSampling):
+    """Batched companion of `forward` (new API): sceneCoordinates [B,E,3,H,W] (or [E,3,H,W] shared),
+    hypAssignment [B,N] int64, outPoses [B,4,4] float32 written in place; returns the list of winning experts.
+    Frame b is exactly what the b-th of B consecutive `forward` calls would compute."""
+    if hypAssignment.dim() != 2 or hypAssignment.dtype != torch.int64:
+        raise RuntimeError("esac.forward_batch: hypAssignment must be int64 [B,N]")
+    if sceneCoordinates.dtype != torch.float32 or sceneCoordinates.dim() not in (4, 5) or sceneCoordinates.size(-3) != 3:
+        raise RuntimeError("esac.forward_batch: sceneCoordinates must be float32 [B,E,3,H,W] or [E,3,H,W]")
+    B, N = hypAssignment.shape
+    if outPoses.dtype != torch.float32 or tuple(outPoses.shape) != (B, 4, 4):
+        raise RuntimeError("esac.forward_batch: outPoses must be float32 [B,4,4]")
+    if sceneCoordinates.dim() == 5 and sceneCoordinates.size(0) != B:
+        raise RuntimeError("esac.forward_batch: batch sizes of sceneCoordinates and hypAssignment differ")
+    eng = engine(sceneCoordinates.device.index if sceneCoordinates.is_cuda else None)
+    E, H, W = sceneCoordinates.shape[-4], sceneCoordinates.shape[-2], sceneCoordinates.shape[-1]
+    p = eng.make_params(E, H, W, N, shiftX, shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha,
+                        inlierBeta, maxReproj, subSampling, seed=_state["seed"], call=_state["call"],
+                        max_tries=_state["max_tries"], max_ref_steps=_state["max_ref_steps"])
+    _state["call"] += B
+    scores = torch.empty(B, N, dtype=torch.float64, device=eng.device)
+    res = eng.forward_batch(sceneCoordinates, hypAssignment, p, scores_out=scores)
+    outPoses.copy_(torch.from_numpy(res[:, RES_POSE:RES_POSE + 16].astype(np.float32).reshape(B, 4, 4)))
+    _state["last"] = {"scores": scores, "result": res}
+    return [int(v) for v in res[:, RES_EXPERT]]
 
 
 def backward(*args, **kwargs):

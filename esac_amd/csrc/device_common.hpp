@@ -151,6 +151,37 @@ __device__ __forceinline__ void block_sum28(double (&v)[NV], double* s_part, dou
     for (int k = 0; k < NV; k++) v[k] = s_tot[k];
 }
 
+// Batched calls (esac_hip_forward_batch): workgroups with blockIdx.y = b serve frame b.  Every per-call
+// buffer is laid out frame-major, so a frame's view is the same KArgs with offset pointers; frame b draws
+// the RNG streams of call + b, which makes a batch bit-identical to B sequential calls.
+__device__ __forceinline__ void frame_view(KArgs& a) {
+    const int fr = blockIdx.y;
+    if (fr == 0) return;
+    const size_t N = (size_t)a.N, P = (size_t)a.H * a.W, f = (size_t)fr;
+    a.sc += f * a.sc_frame_stride;
+    a.assign += f * N;
+    a.call += (uint64_t)fr;
+    a.hyps += f * N * 6;
+    a.rt32 += f * N * 12;
+    a.sample_xy += f * N * 8;
+    a.tries += f * N;
+    a.fast_scores += f * N;
+    a.scores += f * N;
+    a.exact_flag += f * N;
+    a.contenders += f * N;
+    a.n_contenders += f * 4;
+    a.stats += f * 4;
+    a.errs += f * P;
+    a.inlier_map += f * 2 * P;
+    a.corr_list = static_cast<char*>(a.corr_list) + f * P * 16;
+    a.inlier_counts += f * (ESAC_MAX_REF_STEPS_K + 1);
+    a.result += f * 32;
+    a.tstamps = nullptr;  // the span measurement follows frame 0 only
+    if (a.scores_user) a.scores_user += f * N;
+    if (a.result_user) a.result_user += f * 32;
+    if (a.result_pin) a.result_pin += f * 33;
+}
+
 __device__ __forceinline__ Cam make_cam(const KArgs& a) {
     // camMat is a float matrix widened to double by the solver (esac.cpp:93-97)
     return Cam{(double)a.focal, (double)a.focal, (double)a.ppx, (double)a.ppy};

@@ -39,7 +39,7 @@ static int fail(int code, const char* fmt, ...) {
 
 struct esac_hip_ctx {
     int device = 0;
-    int capN = 0, capP = 0;
+    int capN = 0, capP = 0, capB = 0;  // capN / capP count elements over ALL frames of a batch
     KArgs ws{};  // only the workspace pointers are kept here
     int lastN = 0, lastH = 0, lastW = 0;
     bool timing = false;
@@ -65,7 +65,7 @@ static void free_ws(esac_hip_ctx* c) {
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws = KArgs{};
-    c->capN = c->capP = 0;
+    c->capN = c->capP = c->capB = 0;
 }
 
 extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
@@ -80,8 +80,8 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
     esac_hip_ctx* c = new esac_hip_ctx();
     c->device = device;
     for (auto& ev : c->ev) HIP_OK(hipEventCreate(&ev));
-    HIP_OK(hipHostMalloc((void**)&c->h_pin, 64 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(c->h_pin, 0, 64 * sizeof(double));
+    HIP_OK(hipHostMalloc((void**)&c->h_pin, (size_t)33 * ESAC_MAX_BATCH * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_pin, 0, (size_t)33 * ESAC_MAX_BATCH * sizeof(double));
     HIP_OK(hipHostGetDevicePointer((void**)&c->d_pin, c->h_pin, 0));
     *out = c;
     return 0;
@@ -104,10 +104,13 @@ static int alloc(T** p, size_t n) {
     return 0;
 }
 
-static int ensure_ws(esac_hip_ctx* c, int N, int P) {
-    if (N <= c->capN && P <= c->capP) return 0;
+static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
+    const long long N = (long long)N1 * B, P = (long long)P1 * B;
+    if (N <= c->capN && P <= c->capP && B <= c->capB) return 0;
+    if (N > 0x7fffffffLL || P > 0x7fffffffLL) return fail(-4, "batch too large");
     HIP_OK(hipDeviceSynchronize());
-    const int nN = N > c->capN ? N : c->capN, nP = P > c->capP ? P : c->capP;
+    const int nN = N > c->capN ? (int)N : c->capN, nP = P > c->capP ? (int)P : c->capP;
+    const int nB = B > c->capB ? B : c->capB;
     free_ws(c);
     int rc = 0;
     rc |= alloc(&c->ws.hyps, (size_t)nN * 6);
@@ -118,8 +121,8 @@ static int ensure_ws(esac_hip_ctx* c, int N, int P) {
     rc |= alloc(&c->ws.scores, (size_t)nN);
     rc |= alloc(&c->ws.exact_flag, (size_t)nN);
     rc |= alloc(&c->ws.contenders, (size_t)nN);
-    rc |= alloc(&c->ws.n_contenders, 4);
-    rc |= alloc(&c->ws.stats, 4);
+    rc |= alloc(&c->ws.n_contenders, (size_t)4 * nB);
+    rc |= alloc(&c->ws.stats, (size_t)4 * nB);
     rc |= alloc(&c->ws.errs, (size_t)nP);
     rc |= alloc(&c->ws.inlier_map, (size_t)nP * 2);  // two buffers, see esac_refine.hip
     {
@@ -127,23 +130,25 @@ static int ensure_ws(esac_hip_ctx* c, int N, int P) {
         rc |= alloc(&cl, (size_t)nP * 16);
         c->ws.corr_list = cl;
     }
-    rc |= alloc(&c->ws.inlier_counts, (size_t)ESAC_MAX_REF_STEPS + 1);
-    rc |= alloc(&c->ws.result, (size_t)ESAC_RES_DOUBLES);
+    rc |= alloc(&c->ws.inlier_counts, (size_t)(ESAC_MAX_REF_STEPS + 1) * nB);
+    rc |= alloc(&c->ws.result, (size_t)ESAC_RES_DOUBLES * nB);
     rc |= alloc(&c->ws.cycles, (size_t)32);
     rc |= alloc(&c->ws.tstamps, (size_t)nN * 2);
     rc |= alloc(&c->ws.span_acc, (size_t)2);
     if (rc) return rc;
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
     HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
-    HIP_OK(hipMemset(c->ws.result, 0, ESAC_RES_DOUBLES * sizeof(double)));
-    HIP_OK(hipMemset(c->ws.n_contenders, 0, 4 * sizeof(int)));
+    HIP_OK(hipMemset(c->ws.result, 0, (size_t)ESAC_RES_DOUBLES * nB * sizeof(double)));
+    HIP_OK(hipMemset(c->ws.n_contenders, 0, (size_t)4 * nB * sizeof(int)));
     c->capN = nN;
     c->capP = nP;
+    c->capB = nB;
     return 0;
 }
 
 // Validation: what the reference leaves to accessor<>() / OpenCV asserts.
-static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, KArgs* out) {
+static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, KArgs* out,
+                     int B = 1, long long sc_frame_stride = 0) {
     if (!c) return fail(-1, "null context");
     if (!p) return fail(-1, "null params");
     if (!d_sc || !d_assign) return fail(-1, "null scene-coordinate or assignment pointer");
@@ -155,9 +160,12 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     if (!(p->focal > 0)) return fail(-4, "focal length must be positive");
     HIP_OK(hipSetDevice(c->device));
     const int P = p->H * p->W;
-    int rc = ensure_ws(c, p->N, P);
+    if (B < 1 || B > ESAC_MAX_BATCH) return fail(-4, "batch size %d outside [1,%d]", B, ESAC_MAX_BATCH);
+    int rc = ensure_ws(c, p->N, P, B);
     if (rc) return rc;
     KArgs a = c->ws;
+    a.frames = B;
+    a.sc_frame_stride = sc_frame_stride;
     a.sc = d_sc;
     a.assign = d_assign;
     a.E = p->E; a.H = p->H; a.W = p->W; a.N = p->N;
@@ -221,10 +229,11 @@ extern "C" int esac_hip_score_exact(esac_hip_ctx* c, const float* d_sc, const in
     return check_launch("k_rescore(all)");
 }
 
-extern "C" int esac_hip_forward(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p,
-                                void* stream, double* d_scores_out, double* d_result_out, double* h_result_out) {
+static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_stride, const int64_t* d_assign,
+                        const esac_hip_params* p, int B, void* stream, double* d_scores_out, double* d_result_out,
+                        double* h_result_out) {
     KArgs a;
-    int rc = make_args(c, d_sc, d_assign, p, &a);
+    int rc = make_args(c, d_sc, d_assign, p, &a, B, sc_frame_stride);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     a.scores_user = d_scores_out;
@@ -257,27 +266,45 @@ extern "C" int esac_hip_forward(esac_hip_ctx* c, const float* d_sc, const int64_
     }
     if (h_result_out) {
         // the refinement kernel stores the record and then the epoch word into pinned host memory
-        volatile double* flag = c->h_pin + 32;
+        // (one 33-double slot per frame: record + epoch word)
         const double want = c->epoch;
+        auto all_landed = [&]() {
+            for (int b = 0; b < B; b++)
+                if (*(volatile double*)(c->h_pin + (size_t)b * 33 + 32) != want) return false;
+            return true;
+        };
         bool landed = false;
         for (long spins = 0; spins < 200000000L; spins++) {
-            if (*flag == want) {
+            if (all_landed()) {
                 landed = true;
                 break;
             }
-            if ((spins & 1023) == 1023 && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernel is done (or failed)
-                landed = (*flag == want);
+            if ((spins & 1023) == 1023 && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernels are done (or failed)
+                landed = all_landed();
                 break;
             }
         }
         if (!landed) {
             HIP_OK(hipStreamSynchronize(s));
-            if (*flag != want) return fail(-9, "esac_hip_forward: the refinement kernel did not deliver a result record");
+            if (!all_landed()) return fail(-9, "esac_hip_forward: the refinement kernel did not deliver a result record");
         }
         __sync_synchronize();
-        memcpy(h_result_out, (const void*)c->h_pin, ESAC_RES_DOUBLES * sizeof(double));
+        for (int b = 0; b < B; b++)
+            memcpy(h_result_out + (size_t)b * ESAC_RES_DOUBLES, (const void*)(c->h_pin + (size_t)b * 33),
+                   ESAC_RES_DOUBLES * sizeof(double));
     }
     return 0;
+}
+
+extern "C" int esac_hip_forward(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p,
+                                void* stream, double* d_scores_out, double* d_result_out, double* h_result_out) {
+    return forward_impl(c, d_sc, 0, d_assign, p, 1, stream, d_scores_out, d_result_out, h_result_out);
+}
+
+extern "C" int esac_hip_forward_batch(esac_hip_ctx* c, int B, const float* d_sc, int64_t sc_frame_stride,
+                                      const int64_t* d_assign, const esac_hip_params* p, void* stream,
+                                      double* d_scores_out, double* d_result_out, double* h_result_out) {
+    return forward_impl(c, d_sc, (long long)sc_frame_stride, d_assign, p, B, stream, d_scores_out, d_result_out, h_result_out);
 }
 
 extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t bytes) {

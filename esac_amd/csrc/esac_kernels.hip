@@ -32,10 +32,13 @@
 namespace esac {
 
 // ================================================================= K1: sample + P3P
-constexpr int SAMPLE_B = 256;  // tries evaluated per round: 4 wavefronts per hypothesis
-
+// SAMPLE_B = tries evaluated per round.  A single call wants latency (256 tries = 4 wavefronts per hypothesis:
+// nearly every hypothesis is accepted in round one, the other CUs are idle anyway); thousands of hypotheses
+// in flight (many experts, batched frames) want throughput (64 tries = one wavefront, no wasted solves).
+template <int SAMPLE_B>
 __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     __shared__ int s_first[2][SAMPLE_B / 64];
+    frame_view(a);
     const int h = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e = (int)a.assign[h];
@@ -170,6 +173,7 @@ __device__ __forceinline__ float soft_inlier_fast(const PoseF& p, float fx, floa
 template <int B>
 __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
     __shared__ float s_w[B / 64];
+    frame_view(a);
     const int h = blockIdx.x;
     // optional device-side span measurement (timing mode): the kernel's duration is
     // max(end) - min(start) over its workgroups, on the constant 100 MHz wall clock
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(B) void k_select(KArgs a) {
     __shared__ double s_tot[3];
     __shared__ float s_max[B / 64];
     __shared__ int s_count;
+    frame_view(a);
     // max (NaN-ignoring)
     float m = -INFINITY;
     for (int i = threadIdx.x; i < a.N; i += B) m = fmaxf(m, a.fast_scores[i]);
@@ -307,6 +312,7 @@ template <int B>
 __global__ __launch_bounds__(B) void k_rescore(KArgs a, int all) {
     __shared__ double s_part[B / 64];
     __shared__ double s_tot[1];
+    frame_view(a);
     const int n = all ? a.N : a.n_contenders[0];
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
@@ -340,21 +346,29 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a, int all) {
 }
 
 // ---------------------------------------------------------------- launchers
-void launch_sample(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_sample, dim3(a.N), dim3(SAMPLE_B), 0, s, a); }
+void launch_sample(const KArgs& a, hipStream_t s) {
+    const long long total = (long long)a.N * a.frames;
+    if (total <= 1024)
+        hipLaunchKernelGGL(k_sample<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
+    else if (total <= 4096)
+        hipLaunchKernelGGL(k_sample<128>, dim3(a.N, a.frames), dim3(128), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_sample<64>, dim3(a.N, a.frames), dim3(64), 0, s, a);
+}
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hyps_to_rt32, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_score_fast(const KArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
 }
-void launch_select(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_select<1024>, dim3(1), dim3(1024), 0, s, a); }
+void launch_select(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_select<1024>, dim3(1, a.frames), dim3(1024), 0, s, a); }
 void launch_rescore(const KArgs& a, int all, hipStream_t s) {
     const int grid = all ? (a.N < 4096 ? a.N : 4096) : (a.N < 256 ? a.N : 256);
     // few contenders, latency matters: 16 wavefronts per hypothesis; bulk exact scoring: 4 are enough
     if (all)
-        hipLaunchKernelGGL(k_rescore<256>, dim3(grid), dim3(256), 0, s, a, all);
+        hipLaunchKernelGGL(k_rescore<256>, dim3(grid, a.frames), dim3(256), 0, s, a, all);
     else
-        hipLaunchKernelGGL(k_rescore<1024>, dim3(grid), dim3(1024), 0, s, a, all);
+        hipLaunchKernelGGL(k_rescore<1024>, dim3(grid, a.frames), dim3(1024), 0, s, a, all);
 }
 
 }  // namespace esac

@@ -47,6 +47,9 @@ struct KArgs {
     double* result_user;  // optional device [32]: the result record
     double* result_pin;   // optional pinned HOST memory [33] (device-visible): result record + epoch word
     double epoch;         // value stored into result_pin[32] after the record (the host polls it)
+    // batched calls: frame b = blockIdx.y works on its own slice of every buffer (device_common.hpp:frame_view)
+    int frames;                 // B >= 1
+    long long sc_frame_stride;  // elements between the coordinate tensors of consecutive frames
 };
 
 void launch_sample(const KArgs& a, hipStream_t s);

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     __shared__ int s_besti[B / 64];
     __shared__ int s_bestg[B / 64];
     __shared__ int s_wcnt[ERR_UNROLL * (B / 64)];  // per (sub-step, wavefront) inlier counts
+    frame_view(a);
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -513,11 +514,11 @@ void launch_refine(const KArgs& a, hipStream_t s) {
     // 16-byte accesses: W % 4 == 0 keeps every row, plane (P % 4 == 0) and expert map 16-byte aligned
     const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
     if (global_list) {
-        if (vec) hipLaunchKernelGGL((k_refine<B, true, true>), dim3(1), dim3(B), 0, s, a);
-        else     hipLaunchKernelGGL((k_refine<B, true, false>), dim3(1), dim3(B), 0, s, a);
+        if (vec) hipLaunchKernelGGL((k_refine<B, true, true>), dim3(1, a.frames), dim3(B), 0, s, a);
+        else     hipLaunchKernelGGL((k_refine<B, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
     } else {
-        if (vec) hipLaunchKernelGGL((k_refine<B, false, true>), dim3(1), dim3(B), 0, s, a);
-        else     hipLaunchKernelGGL((k_refine<B, false, false>), dim3(1), dim3(B), 0, s, a);
+        if (vec) hipLaunchKernelGGL((k_refine<B, false, true>), dim3(1, a.frames), dim3(B), 0, s, a);
+        else     hipLaunchKernelGGL((k_refine<B, false, false>), dim3(1, a.frames), dim3(B), 0, s, a);
     }
 }
 

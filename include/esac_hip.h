@@ -36,6 +36,7 @@ extern "C" {
 /* reference compile-time constants (esac.cpp:44-45) */
 #define ESAC_MAX_SAMPLING_TRIES 1000000
 #define ESAC_MAX_REF_STEPS 100
+#define ESAC_MAX_BATCH 1024 /* frames per esac_hip_forward_batch call */
 
 /* Scalar arguments of esac_forward (esac.cpp:64-77) plus the knobs the
  * reference hard-codes or hides (RNG key, limits, multi-GPU shard offset). */
@@ -123,6 +124,19 @@ int esac_hip_destroy(esac_hip_ctx* ctx);
 int esac_hip_forward(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
                      const esac_hip_params* p, void* stream, double* d_scores_out,
                      double* d_result_out, double* h_result_out);
+
+/*
+ * B frames in ONE set of launches (new, beside the drop-in call): one blocking call per frame
+ * occupies a single CU for its refinement tail, so independent frames are what fills the other 255.
+ * d_scene_coords  frame b at d_scene_coords + b * sc_frame_stride (elements; 0 = every frame uses the same maps),
+ *                 each [E,3,H,W]; d_hyp_assign [B,N]; p describes ONE frame (N = hypotheses per frame).
+ * Frame b draws the RNG streams of call p->call + b: the batch is bit-identical to B sequential
+ * esac_hip_forward calls with consecutive call counters.
+ * Outputs are frame-major: d_scores_out [B,N], d_result_out / h_result_out [B,ESAC_RES_DOUBLES].
+ */
+int esac_hip_forward_batch(esac_hip_ctx* ctx, int B, const float* d_scene_coords, int64_t sc_frame_stride,
+                           const int64_t* d_hyp_assign, const esac_hip_params* p, void* stream,
+                           double* d_scores_out, double* d_result_out, double* h_result_out);
 
 /* The same phases one at a time (asynchronous on `stream`), for stage-wise parity
  * tests and for callers that interleave other work.  Order: sample, score, select, refine. */

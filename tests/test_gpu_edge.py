@@ -164,3 +164,30 @@ def test_sharding_independence_on_device(engine):
         fl = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
         both_fast = ~fl & ~flags_all[idx]
         np.testing.assert_array_equal(engine.read(api.BUF_SCORES)[both_fast], scores_all[idx][both_fast])
+
+
+def test_batched_forward_equals_sequential_calls(engine):
+    """esac_hip_forward_batch: frame b == the b-th of B consecutive single calls, bit for bit."""
+    B, N = 12, 96
+    frames = [S.make_frame(70 + b, E=2, true_expert=b % 2) for b in range(B)]
+    assigns = np.stack([S.gating_assignment(f, N, mode="gating") for f in frames])
+    coords = torch.from_numpy(np.stack([f["coords"] for f in frames])).cuda()
+    ha = torch.from_numpy(assigns).cuda()
+    scores_b = torch.empty(B, N, dtype=torch.float64, device="cuda")
+    p = engine.make_params(2, 60, 80, N, call=40)
+    res_b = engine.forward_batch(coords, ha, p, scores_out=scores_b)
+    for b in range(B):
+        q = engine.make_params(2, 60, 80, N, call=40 + b)
+        s1 = torch.empty(N, dtype=torch.float64, device="cuda")
+        r1 = engine.forward_device(coords[b], ha[b], q, scores_out=s1)
+        np.testing.assert_array_equal(res_b[b][:31], r1[:31])
+        np.testing.assert_array_equal(scores_b[b].cpu().numpy(), s1.cpu().numpy())
+    # module-level API, shared maps for every frame
+    import esac
+    esac.set_seed(1305, 40)
+    poses = torch.zeros(3, 4, 4)
+    experts = esac.forward_batch(coords[0], ha[:3], poses, 0, 0, 525.0, 320.0, 240.0, 10.0, 100.0, 0.5, 100.0, 8)
+    q = engine.make_params(2, 60, 80, N, call=41)
+    r1 = engine.forward_device(coords[0], ha[1], q)
+    np.testing.assert_array_equal(poses[1].numpy().reshape(-1), r1[api.RES_POSE:api.RES_POSE + 16].astype(np.float32))
+    assert experts[1] == int(r1[api.RES_EXPERT]) and esac.get_rng_state() == (1305, 43)

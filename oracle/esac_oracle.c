@@ -1094,3 +1094,5 @@ int esac_oracle_forward(esac_oracle_args* a) {
     free(hyps); free(sxy); free(tries); free(scores); free(probs); free(errs); free(werrs);
     return expertW;
 }
+
+#include "esac_oracle_bwd.inc"

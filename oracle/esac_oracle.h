@@ -80,6 +80,30 @@ typedef struct esac_oracle_args {
 /* returns winning expert (>=0) or <0 on argument error */
 int esac_oracle_forward(esac_oracle_args* a);
 
+/* esac_backward (esac.cpp:213-511): expected pose loss + its gradient wrt the scene coordinates.
+ * `fwd` carries the inputs shared with the forward pass (its out_* members are ignored). */
+typedef struct esac_oracle_bwd_args {
+    esac_oracle_args fwd;
+    const float* gt_pose;      /* [16] row-major 4x4 camera pose (gtPose, esac.cpp:217)            */
+    float w_rot, w_trans, loss_cut;
+    float* out_gradients;      /* [E,3,H,W] accumulated with += (esac.cpp:501-506), strides below  */
+    int64_t grad_stride[4];
+    /* optional stage outputs */
+    double* out_probs;         /* [N] */
+    double* out_losses;        /* [N] */
+    double* out_init_hyps;     /* [N,6] */
+    double* out_ref_hyps;      /* [N,6] */
+    double* out_score_grads;   /* [N] scoreOutputGradients (esac_derivative.h:368-375) */
+    double* out_dloss;         /* [N,6] dLoss per refined hypothesis */
+    int32_t* out_sample_xy;    /* [N,4,2] */
+    double* out_entropy;       /* [1] */
+    double* out_grad_path1;    /* [N,H*W,3] gradients[h] before the probability weight (esac.cpp:456-463) */
+    double* out_grad_path2;    /* [N,H*W,3] dLoss_dScore_dObjs[h] (esac.cpp:472-486) */
+} esac_oracle_bwd_args;
+
+/* returns the expected loss (>= 0) or -1 on argument error */
+double esac_oracle_backward(esac_oracle_bwd_args* b);
+
 /* ---- building blocks exported for known-answer tests ---- */
 void esac_oracle_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void esac_oracle_draw_cells(uint64_t seed, uint64_t call, uint32_t hyp, uint32_t tr,
@@ -101,6 +125,9 @@ int  esac_oracle_lm_pnp(const float* obj, const float* img, int n, double fx, do
                         double cx, double cy, double pose[6]);
 void esac_oracle_pose2trans(const double pose[6], double T[16]);
 void esac_oracle_inv4(const double M[16], double Minv[16]);
+void esac_oracle_pinv_sym6(const double A[36], double Ainv[36]);
+void esac_oracle_project_jac(const double rvec[3], const double tvec[3], double fx, double fy, double cx, double cy,
+                             const float* pts3, int n, double* J12);
 int  esac_oracle_max_threads(void);
 
 #ifdef __cplusplus

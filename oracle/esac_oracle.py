@@ -48,7 +48,7 @@ class _Args(C.Structure):
 def build(force=False):
     """Compile the oracle's C restatement (gcc, seconds). Building the checker is not using it."""
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
-        os.path.getmtime(os.path.join(_HERE, f)) for f in ("esac_oracle.c", "esac_oracle.h")
+        os.path.getmtime(os.path.join(_HERE, f)) for f in ("esac_oracle.c", "esac_oracle.h", "esac_oracle_bwd.inc")
     ):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _LIB_PATH
@@ -148,6 +148,82 @@ def forward(scene_coords, hyp_assign, shift_x=0, shift_y=0, focal=525.0, ppx=320
     out["entropy"] = float(out["entropy"][0])
     out["ref_steps"] = int(out["ref_steps"][0])
     out["lm_iters"] = int(out["lm_iters"][0])
+    return out
+
+
+class _BwdArgs(C.Structure):
+    _fields_ = [
+        ("fwd", _Args),
+        ("gt_pose", C.c_void_p),
+        ("w_rot", C.c_float), ("w_trans", C.c_float), ("loss_cut", C.c_float),
+        ("out_gradients", C.c_void_p),
+        ("grad_stride", C.c_int64 * 4),
+        ("out_probs", C.c_void_p), ("out_losses", C.c_void_p), ("out_init_hyps", C.c_void_p),
+        ("out_ref_hyps", C.c_void_p), ("out_score_grads", C.c_void_p), ("out_dloss", C.c_void_p),
+        ("out_sample_xy", C.c_void_p), ("out_entropy", C.c_void_p), ("out_grad_path1", C.c_void_p),
+        ("out_grad_path2", C.c_void_p),
+    ]
+
+
+def backward(scene_coords, out_gradients, hyp_assign, gt_pose, w_rot=1.0, w_trans=100.0, loss_cut=100.0,
+             shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0, inlier_alpha=100.0,
+             inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0, max_tries=0, max_ref_steps=-1,
+             num_threads=0, irand=None, hyp_index=None, want_paths=False):
+    """Oracle restatement of esac.backward (esac.cpp:213-230): accumulates into `out_gradients` (float32 ndarray
+    [E,3,H,W], +=) and returns a dict with the expected loss and the stage outputs."""
+    sc = np.asarray(scene_coords)
+    ha = np.asarray(hyp_assign)
+    og = out_gradients
+    gt = np.ascontiguousarray(gt_pose, np.float32).reshape(16)
+    assert sc.dtype == np.float32 and sc.ndim == 4 and og.dtype == np.float32 and og.shape == sc.shape
+    assert ha.dtype == np.int64 and ha.ndim == 1
+    E, _, H, W = sc.shape
+    N = ha.shape[0]
+    out = dict(probs=np.zeros(N), losses=np.zeros(N), init_hyps=np.zeros((N, 6)), ref_hyps=np.zeros((N, 6)),
+               score_grads=np.zeros(N), dloss=np.zeros((N, 6)), sample_xy=np.zeros((N, 4, 2), np.int32),
+               entropy=np.zeros(1))
+    if want_paths:
+        out["grad_path1"] = np.zeros((N, H * W, 3))
+        out["grad_path2"] = np.zeros((N, H * W, 3))
+    b = _BwdArgs()
+    a = b.fwd
+    a.scene_coords = _p(sc)
+    for i in range(4):
+        a.sc_stride[i] = sc.strides[i] // 4
+        b.grad_stride[i] = og.strides[i] // 4
+    a.E, a.H, a.W = E, H, W
+    a.hyp_assign = _p(ha)
+    a.assign_stride = ha.strides[0] // 8
+    a.N = N
+    a.shift_x, a.shift_y = int(shift_x), int(shift_y)
+    a.focal, a.ppx, a.ppy = float(focal), float(ppx), float(ppy)
+    a.inlier_thresh, a.inlier_alpha = float(inlier_thresh), float(inlier_alpha)
+    a.inlier_beta, a.max_reproj = float(inlier_beta), float(max_reproj)
+    a.sub_sampling = int(sub_sampling)
+    a.seed, a.call = int(seed), int(call)
+    cb = None
+    if irand is not None:
+        cb = IRAND_FN(lambda lo, hi, _u: int(irand(lo, hi)))
+        a.rng_mode = 1
+        a.irand_cb = cb
+    a.max_tries, a.max_ref_steps, a.num_threads = int(max_tries), int(max_ref_steps), int(num_threads)
+    hi = None
+    if hyp_index is not None:
+        hi = np.ascontiguousarray(hyp_index, np.int32)
+        a.hyp_index = _p(hi)
+    b.gt_pose = _p(gt)
+    b.w_rot, b.w_trans, b.loss_cut = float(w_rot), float(w_trans), float(loss_cut)
+    b.out_gradients = _p(og)
+    for k in out:
+        setattr(b, "out_" + k, _p(out[k]))
+    L = lib()
+    L.esac_oracle_backward.argtypes = [C.POINTER(_BwdArgs)]
+    L.esac_oracle_backward.restype = C.c_double
+    loss = L.esac_oracle_backward(C.byref(b))
+    if loss < 0:
+        raise RuntimeError("esac_oracle_backward failed")
+    out["loss"] = float(loss)
+    out["entropy"] = float(out["entropy"][0])
     return out
 
 

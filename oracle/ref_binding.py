@@ -35,6 +35,10 @@ def lib():
         vp, i, f, u = C.c_void_p, C.c_int, C.c_float, C.c_uint
         _lib.ref_forward.argtypes = [vp, i, i, i, vp, i, vp, i, i, f, f, f, f, f, f, f, i, u, u, vp, vp, vp, vp, vp, vp, vp]
         _lib.ref_forward.restype = i
+        _lib.ref_esac_forward.argtypes = [vp, i, i, i, vp, i, vp, i, i, f, f, f, f, f, f, f, i]
+        _lib.ref_esac_forward.restype = i
+        _lib.ref_esac_backward.argtypes = [vp, vp, i, i, i, vp, i, vp, f, f, f, i, i, f, f, f, f, f, f, f, i]
+        _lib.ref_esac_backward.restype = C.c_double
         _lib.ref_rng_reset.argtypes = [u]
         _lib.ref_replay_irand.argtypes = [i, i, vp]
         _lib.ref_replay_irand.restype = i
@@ -68,6 +72,40 @@ def forward(coords, assign, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=24
     out["winner"] = int(out["winner"][0])
     out["entropy"] = float(out["entropy"][0])
     return out
+
+
+def esac_forward(coords, assign, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
+                 inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305):
+    """The reference's esac_forward (esac.cpp:64-190) itself, called the way pybind11 would call it."""
+    import threadpoolctl
+    sc = np.ascontiguousarray(coords, np.float32)
+    ha = np.ascontiguousarray(assign, np.int64)
+    E, _, H, W = sc.shape
+    pose = np.zeros((4, 4), np.float32)
+    L = lib()
+    with threadpoolctl.threadpool_limits(limits=1, user_api="openmp"):
+        L.ref_rng_reset(int(seed))
+        e = L.ref_esac_forward(_p(sc), E, H, W, _p(ha), len(ha), _p(pose), int(shift_x), int(shift_y), focal, ppx, ppy,
+                               inlier_thresh, inlier_alpha, inlier_beta, max_reproj, int(sub_sampling))
+    return e, pose
+
+
+def esac_backward(coords, out_gradients, assign, gt_pose, w_rot=1.0, w_trans=100.0, loss_cut=100.0, shift_x=0,
+                  shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0, inlier_alpha=100.0, inlier_beta=0.5,
+                  max_reproj=100.0, sub_sampling=8, seed=1305):
+    """The reference's esac_backward (esac.cpp:213-511) itself: accumulates into out_gradients, returns the loss."""
+    import threadpoolctl
+    sc = np.ascontiguousarray(coords, np.float32)
+    ha = np.ascontiguousarray(assign, np.int64)
+    gt = np.ascontiguousarray(gt_pose, np.float32).reshape(4, 4)
+    assert out_gradients.dtype == np.float32 and out_gradients.flags.c_contiguous and out_gradients.shape == sc.shape
+    E, _, H, W = sc.shape
+    L = lib()
+    with threadpoolctl.threadpool_limits(limits=1, user_api="openmp"):
+        L.ref_rng_reset(int(seed))
+        return L.ref_esac_backward(_p(sc), _p(out_gradients), E, H, W, _p(ha), len(ha), _p(gt), w_rot, w_trans, loss_cut,
+                                   int(shift_x), int(shift_y), focal, ppx, ppy, inlier_thresh, inlier_alpha, inlier_beta,
+                                   max_reproj, int(sub_sampling))
 
 
 def replay_irand(seed):

@@ -15,12 +15,11 @@
 #include <random>
 #include <vector>
 
-#include "aten_shim.h"
-#include <opencv2/opencv.hpp>  // the stand-in (oracle/ref_shim)
-
-#include "thread_rand.h"  // reference
-#include "esac_types.h"   // reference
-#include "esac_util.h"    // reference
+// The reference's extension source itself, UNMODIFIED, from /root/reference/code/esac (-I on the command line):
+// it includes <torch/torch.h> and <opencv2/opencv.hpp> (both resolve to the stand-ins in oracle/ref_shim) and its own
+// thread_rand.h, stop_watch.h, esac_types.h, esac_util.h, esac_loss.h, esac_derivative.h.
+#define TORCH_EXTENSION_NAME esac
+#include "esac.cpp"  // reference: esac_forward (esac.cpp:64-190), esac_backward (esac.cpp:213-511)
 
 // single-thread replay of the reference RNG for the oracle's callback mode: ThreadRand::irand(min, max) is
 // std::uniform_int_distribution<int>(min, max) on a std::mt19937 seeded 1305 + thread id (thread_rand.cpp:13-42)
@@ -111,5 +110,19 @@ int ref_forward(const float* sc, int E, int H, int W, const int64_t* assign, int
         for (unsigned y = 0; y < 4; y++) out_pose16[y * 4 + x] = estTrans(y, x);
 
     return hypAssignment[hypIdx];  // esac.cpp:189
+}
+
+// ---- the reference's real entry points, called exactly as pybind11 would ---------------------------------
+int ref_esac_forward(float* sc, int E, int H, int W, int64_t* assign, int N, float* out_pose16, int shiftX, int shiftY,
+                     float f, float ppx, float ppy, float thr, float alpha, float beta, float maxReproj, int sub) {
+    at::Tensor tsc(sc, {E, 3, H, W}), tas(assign, {N}), tpose(out_pose16, {4, 4});
+    return esac_forward(tsc, tas, tpose, shiftX, shiftY, f, ppx, ppy, thr, alpha, beta, maxReproj, sub);
+}
+
+double ref_esac_backward(float* sc, float* out_grads, int E, int H, int W, int64_t* assign, int N, float* gt_pose16,
+                         float wRot, float wTrans, float cut, int shiftX, int shiftY, float f, float ppx, float ppy,
+                         float thr, float alpha, float beta, float maxReproj, int sub) {
+    at::Tensor tsc(sc, {E, 3, H, W}), tg(out_grads, {E, 3, H, W}), tas(assign, {N}), tgt(gt_pose16, {4, 4});
+    return esac_backward(tsc, tg, tas, tgt, wRot, wTrans, cut, shiftX, shiftY, f, ppx, ppy, thr, alpha, beta, maxReproj, sub);
 }
 }

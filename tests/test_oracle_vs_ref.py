@@ -53,3 +53,44 @@ def test_budget_exhaustion_matches_reference(oracle):
     np.testing.assert_array_equal(ora["hyps"], ref["hyps"])
     np.testing.assert_array_equal(ora["scores"], ref["scores"])
     np.testing.assert_array_equal(ora["pose"], ref["pose"])
+
+
+def test_reference_esac_forward_itself(oracle):
+    """esac_forward compiled from the reference's esac.cpp (torch/OpenCV stand-ins) == oracle, same mt19937 stream."""
+    f = S.make_frame(6, E=2, true_expert=1)
+    ha = S.gating_assignment(f, 96, mode="gating")
+    e, pose = ref_binding.esac_forward(f["coords"], ha, seed=1305)
+    ora = oracle.forward(f["coords"], ha, irand=ref_binding.replay_irand(1305))
+    assert e == ora["expert"]
+    np.testing.assert_array_equal(pose, ora["pose"])
+
+
+BWD_CASES = [
+    dict(k=0, N=64),
+    dict(k=1, N=96, E=3, true_expert=2, mode="gating"),
+    dict(k=2, N=48, H=24, W=32, sub=20, shift=(3, -2)),
+    dict(k=3, N=64, loss=dict(w_rot=2.0, w_trans=50.0, loss_cut=0.5)),   # soft-clamped loss branch (esac_loss.h:79-80,133-137)
+    dict(k=4, N=64, params=dict(inlier_thresh=6.0, inlier_alpha=50.0, inlier_beta=0.8, max_reproj=60.0)),
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES, ids=lambda c: "k%d_N%d" % (c["k"], c["N"]))
+def test_oracle_backward_matches_reference_esac_backward(oracle, case):
+    """esac_backward compiled from the reference's esac.cpp + esac_loss.h + esac_derivative.h vs the oracle's
+    restatement: same expected loss, same gradient tensor (accumulated onto a non-zero start, as `+=` implies)."""
+    fkw = {k: v for k, v in case.items() if k in ("k", "E", "true_expert", "H", "W", "sub", "shift")}
+    f = S.make_frame(**fkw)
+    ha = S.gating_assignment(f, case["N"], mode=case.get("mode", "single"))
+    gt = f["gt_pose"].astype(np.float32)
+    gt[:3, 3] += np.float32(0.03)  # a ground truth that is not the optimum: non-trivial loss gradient
+    kw = dict(shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"],
+              sub_sampling=f["sub"], **case.get("params", {}), **case.get("loss", {}))
+    rng = np.random.default_rng(5)
+    g_ref = rng.normal(0, 1e-3, f["coords"].shape).astype(np.float32)
+    g_ora = g_ref.copy()
+    loss_ref = ref_binding.esac_backward(f["coords"], g_ref, ha, gt, seed=1305, **kw)
+    out = oracle.backward(f["coords"], g_ora, ha, gt, irand=ref_binding.replay_irand(1305), **kw)
+    assert (out["probs"] >= 1e-3).sum() >= 1
+    assert out["loss"] == pytest.approx(loss_ref, rel=1e-12, abs=1e-12)
+    assert np.abs(g_ref).max() > 1e-2  # a real gradient came out
+    np.testing.assert_allclose(g_ora, g_ref, rtol=1e-6, atol=1e-9)

@@ -25,13 +25,16 @@ RES_SCORE, RES_HYP, RES_EXPERT, RES_RVEC, RES_TVEC, RES_POSE = 0, 1, 2, 3, 6, 9
 RES_REF_STEPS, RES_INLIERS, RES_PROB, RES_ENTROPY, RES_CONTENDERS, RES_LM_ITERS, RES_DOUBLES = 25, 26, 27, 28, 29, 30, 32
 BUF_HYPS, BUF_SAMPLE_XY, BUF_TRIES, BUF_SCORES, BUF_RESULT = 0, 1, 2, 3, 4
 BUF_INLIER_MAP, BUF_INLIER_COUNTS, BUF_WINNER_ERRS, BUF_EXACT_FLAGS, BUF_CYCLES = 5, 6, 7, 8, 9
+BUF_BWD_PROBS, BUF_BWD_LOSSES, BUF_BWD_REF_HYPS, BUF_BWD_SCORE_GRADS, BUF_BWD_SLOTS, BUF_BWD_SLOT_INFO, BUF_BWD_DLOSS = \
+    10, 11, 12, 13, 14, 15, 16
 MAX_REF_STEPS = 100
+BWD_MAX_SLOTS = 1000
 
 ABI_SYMBOLS = [
     "esac_hip_abi_version", "esac_hip_last_error", "esac_hip_device_count", "esac_hip_create", "esac_hip_destroy",
     "esac_hip_forward", "esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine",
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
-    "esac_hip_score_span_ms", "esac_hip_forward_batch",
+    "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward",
 ]
 
 
@@ -77,6 +80,7 @@ def load_library():
         lib.esac_hip_forward_batch.argtypes = [vp, i32, vp, C.c_int64, vp, pp, vp, vp, vp, vp]
         for name in ("esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine", "esac_hip_score_exact"):
             getattr(lib, name).argtypes = [vp, vp, vp, pp, vp]
+        lib.esac_hip_backward.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, pp, vp, vp]
         lib.esac_hip_read.argtypes = [vp, i32, vp, C.c_size_t]
         lib.esac_hip_write_hyps.argtypes = [vp, vp, i32]
         lib.esac_hip_phase_ms.argtypes = [vp, vp]
@@ -182,6 +186,24 @@ class Engine:
         self._keep = (sc, ha)
         return host
 
+    def backward_device(self, scene_coords, out_gradients, hyp_assign, gt_pose, w_rot, w_trans, loss_cut, params,
+                        want_host=True):
+        """Training path on this device. out_gradients: float32 [E,3,H,W] on this device, contiguous, accumulated into.
+        gt_pose: 16 floats (4x4 camera pose). Returns np.float64[4] = expected loss, #refined hypotheses, entropy, 0."""
+        sc, ha = self._dev_inputs(scene_coords, hyp_assign)
+        if not (out_gradients.is_cuda and out_gradients.is_contiguous() and out_gradients.dtype == torch.float32
+                and tuple(out_gradients.shape) == tuple(sc.shape)):
+            raise RuntimeError("esac.backward: the gradient tensor must be a dense float32 device tensor shaped like sceneCoordinates")
+        gt = np.ascontiguousarray(np.asarray(gt_pose, np.float32).reshape(16))
+        host = np.zeros(4, np.float64) if want_host else None
+        with torch.cuda.device(self.device):
+            _check(self.lib.esac_hip_backward(
+                self.ctx, sc.data_ptr(), out_gradients.data_ptr(), ha.data_ptr(), gt.ctypes.data_as(C.c_void_p),
+                float(w_rot), float(w_trans), float(loss_cut), C.byref(params), self._stream(),
+                host.ctypes.data_as(C.c_void_p) if want_host else None), self.lib)
+        self._keep = (sc, ha, out_gradients)
+        return host
+
     # -- single phases (stage-wise parity tests)
     def _phase(self, fn, scene_coords, hyp_assign, params):
         sc, ha = self._dev_inputs(scene_coords, hyp_assign)
@@ -217,6 +239,9 @@ class Engine:
             BUF_INLIER_MAP: ((H, W), np.uint8), BUF_INLIER_COUNTS: ((MAX_REF_STEPS + 1,), np.int32),
             BUF_WINNER_ERRS: ((H, W), np.float32), BUF_EXACT_FLAGS: ((N,), np.uint8),
             BUF_CYCLES: ((32,), np.int64),
+            BUF_BWD_PROBS: ((N,), np.float64), BUF_BWD_LOSSES: ((N,), np.float64), BUF_BWD_REF_HYPS: ((N, 6), np.float64),
+            BUF_BWD_SCORE_GRADS: ((N,), np.float64), BUF_BWD_SLOTS: ((N,), np.int32),
+            BUF_BWD_SLOT_INFO: ((min(N, BWD_MAX_SLOTS), 4), np.int32), BUF_BWD_DLOSS: ((min(N, BWD_MAX_SLOTS), 6), np.float64),
         }
         shape, dt = shapes[which]
         out = np.zeros(shape, dt)
@@ -345,6 +370,39 @@ def forward_batch(sceneCoordinates, hypAssignment, outPoses, shiftX, shiftY, foc
     return [int(v) for v in res[:, RES_EXPERT]]
 
 
-def backward(*args, **kwargs):
-    """`esac.backward` (esac.cpp:213-230) -- training path, SURVEY.md row f1: not built yet."""
-    raise NotImplementedError("esac.backward (esac.cpp:213-511) is scheduled after the forward hot path (SURVEY.md 8 f1)")
+def backward(sceneCoordinates, outGradients, hypAssignment, gtPose, wLossRot, wLossTrans, lossCut, shiftX, shiftY,
+             focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha, inlierBeta, maxReproj, subSampling):
+    """Drop-in for `esac.backward` (esac.cpp:213-230): expected pose loss over the hypothesis distribution; its
+    gradient wrt the scene coordinates is ADDED to `outGradients` in place (esac.cpp:491-508, the caller passes
+    zeros: train_esac.py:148). Returns the expected loss as a Python float.
+
+    Tensors may live on the CPU (as train_esac.py:152-155 passes them) or on the GPU; with device tensors nothing
+    but the ground-truth pose and the loss value crosses PCIe."""
+    if sceneCoordinates.dtype != torch.float32 or sceneCoordinates.dim() != 4 or sceneCoordinates.size(1) != 3:
+        raise RuntimeError("esac.backward: sceneCoordinates must be float32 [E,3,H,W]")
+    if outGradients.dtype != torch.float32 or tuple(outGradients.shape) != tuple(sceneCoordinates.shape):
+        raise RuntimeError("esac.backward: outGradients must be float32 and shaped like sceneCoordinates")
+    if hypAssignment.dtype != torch.int64 or hypAssignment.dim() != 1 or hypAssignment.numel() == 0:
+        raise RuntimeError("esac.backward: hypAssignment must be a non-empty int64 [N]")
+    if gtPose.dtype != torch.float32 or tuple(gtPose.shape) != (4, 4):
+        raise RuntimeError("esac.backward: gtPose must be float32 [4,4]")
+    dev = sceneCoordinates.device.index if sceneCoordinates.is_cuda else None
+    eng = engine(dev)
+    E, _, H, W = sceneCoordinates.shape
+    N = hypAssignment.shape[0]
+    if not hypAssignment.is_cuda:
+        lo, hi = int(hypAssignment.min()), int(hypAssignment.max())
+        if lo < 0 or hi >= E:
+            raise RuntimeError("esac.backward: hypAssignment values must lie in [0,%d), found [%d,%d]" % (E, lo, hi))
+    p = eng.make_params(E, H, W, N, shiftX, shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha,
+                        inlierBeta, maxReproj, subSampling, seed=_state["seed"], call=_state["call"],
+                        max_tries=_state["max_tries"], max_ref_steps=_state["max_ref_steps"])
+    _state["call"] += 1
+    in_place = outGradients.is_cuda and outGradients.is_contiguous() and outGradients.device == eng.device
+    grads = outGradients if in_place else outGradients.to(eng.device).contiguous()
+    out = eng.backward_device(sceneCoordinates, grads, hypAssignment, gtPose.detach().cpu().numpy(), wLossRot, wLossTrans,
+                              lossCut, p)
+    if not in_place:
+        outGradients.copy_(grads)  # the accumulated tensor back into the caller's (CPU or strided) storage
+    _state["last"] = {"backward": out}
+    return float(out[0])

@@ -11,6 +11,7 @@
 
 #include "../../include/esac_hip.h"
 #include "esac_kernels.hpp"
+#include "pose_math.hpp"
 
 using namespace esac;
 
@@ -48,6 +49,9 @@ struct esac_hip_ctx {
     double* h_pin = nullptr;  // pinned, device-visible host buffer: result record [32] + epoch word
     double* d_pin = nullptr;  // its device address
     double epoch = 0;
+    BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
+    int bN = 0, bP = 0, bcap = 0;
+    bool b_lists = false;
 };
 
 extern "C" int esac_hip_abi_version(void) { return ESAC_HIP_ABI_VERSION; }
@@ -87,10 +91,21 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
     return 0;
 }
 
+static void free_bws(esac_hip_ctx* c) {
+    void* ptrs[] = {c->bws.sel,   c->bws.n_sel, c->bws.probs,    c->bws.losses,     c->bws.ref_hyps, c->bws.sgrad, c->bws.dloss,
+                    c->bws.maps,  c->bws.map_info, c->bws.corr_lists, c->bws.grad1, c->bws.grad2,   c->bws.out};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    c->bws = BwdArgs{};
+    c->bN = c->bP = c->bcap = 0;
+    c->b_lists = false;
+}
+
 extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     free_ws(c);
+    free_bws(c);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -307,6 +322,145 @@ extern "C" int esac_hip_forward_batch(esac_hip_ctx* c, int B, const float* d_sc,
     return forward_impl(c, d_sc, (long long)sc_frame_stride, d_assign, p, B, stream, d_scores_out, d_result_out, h_result_out);
 }
 
+// ---------------------------------------------------------------- training path
+static int ensure_bws(esac_hip_ctx* c, int N, int P) {
+    const int cap = N < ESAC_BWD_MAX_SLOTS ? N : ESAC_BWD_MAX_SLOTS;
+    const bool lists = P > ESAC_REFINE_LDS_CAP;
+    if (N <= c->bN && P <= c->bP && cap <= c->bcap && (!lists || c->b_lists)) return 0;
+    HIP_OK(hipDeviceSynchronize());
+    const int nN = N > c->bN ? N : c->bN, nP = P > c->bP ? P : c->bP, ncap = cap > c->bcap ? cap : c->bcap;
+    const bool nlists = lists || c->b_lists;
+    free_bws(c);
+    int rc = 0;
+    rc |= alloc(&c->bws.sel, (size_t)nN);
+    rc |= alloc(&c->bws.n_sel, (size_t)4);
+    rc |= alloc(&c->bws.probs, (size_t)nN);
+    rc |= alloc(&c->bws.losses, (size_t)nN);
+    rc |= alloc(&c->bws.ref_hyps, (size_t)nN * 6);
+    rc |= alloc(&c->bws.sgrad, (size_t)nN);
+    rc |= alloc(&c->bws.dloss, (size_t)ncap * 6);
+    rc |= alloc(&c->bws.maps, (size_t)ncap * 2 * nP);
+    rc |= alloc(&c->bws.map_info, (size_t)ncap * 4);
+    if (nlists) {
+        char* cl = nullptr;
+        rc |= alloc(&cl, (size_t)ncap * nP * 16);
+        c->bws.corr_lists = cl;
+    }
+    rc |= alloc(&c->bws.grad1, (size_t)ncap * nP * 3);
+    rc |= alloc(&c->bws.grad2, (size_t)ncap * nP * 3);
+    rc |= alloc(&c->bws.out, (size_t)4);
+    if (rc) {
+        free_bws(c);
+        return rc;
+    }
+    HIP_OK(hipMemset(c->bws.n_sel, 0, 4 * sizeof(int)));
+    c->bN = nN; c->bP = nP; c->bcap = ncap; c->b_lists = nlists;
+    return 0;
+}
+
+// general 4x4 inverse, Gauss-Jordan with partial pivoting (cv::Mat::inv() of trans2pose, esac_util.h:557)
+static bool inv4_host(const double A[16], double Ai[16]) {
+    double M[4][8];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            M[i][j] = A[4 * i + j];
+            M[i][4 + j] = i == j;
+        }
+    for (int col = 0; col < 4; col++) {
+        int piv = col;
+        for (int r = col + 1; r < 4; r++)
+            if (fabs(M[r][col]) > fabs(M[piv][col])) piv = r;
+        if (M[piv][col] == 0) return false;
+        if (piv != col)
+            for (int j = 0; j < 8; j++) {
+                const double t = M[piv][j];
+                M[piv][j] = M[col][j];
+                M[col][j] = t;
+            }
+        const double d = 1.0 / M[col][col];
+        for (int j = 0; j < 8; j++) M[col][j] *= d;
+        for (int r = 0; r < 4; r++) {
+            if (r == col) continue;
+            const double f = M[r][col];
+            if (f == 0) continue;
+            for (int j = 0; j < 8; j++) M[r][j] -= f * M[col][j];
+        }
+    }
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) Ai[4 * i + j] = M[i][4 + j];
+    return true;
+}
+
+// nearest rotation of a 3x3 (orthogonal polar factor = U*Vt of its SVD, what cv::Rodrigues applies to a matrix
+// input): Newton iteration X <- (X + X^-T) / 2, quadratic from the ~1e-7 non-orthonormality of a float pose
+static void nearest_rotation_host(double R[9]) {
+    for (int it = 0; it < 20; it++) {
+        const double* a = R;
+        const double c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+        const double c10 = a[2] * a[7] - a[1] * a[8], c11 = a[0] * a[8] - a[2] * a[6], c12 = a[1] * a[6] - a[0] * a[7];
+        const double c20 = a[1] * a[5] - a[2] * a[4], c21 = a[2] * a[3] - a[0] * a[5], c22 = a[0] * a[4] - a[1] * a[3];
+        const double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+        if (det == 0) return;
+        const double invT[9] = {c00 / det, c01 / det, c02 / det, c10 / det, c11 / det, c12 / det, c20 / det, c21 / det, c22 / det};
+        double delta = 0;
+        for (int k = 0; k < 9; k++) {
+            const double n = 0.5 * (R[k] + invT[k]);
+            delta += fabs(n - R[k]);
+            R[k] = n;
+        }
+        if (delta < 1e-15) break;
+    }
+}
+
+extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_out_gradients, const int64_t* d_assign,
+                                 const float* h_gt_pose, float w_loss_rot, float w_loss_trans, float loss_cut,
+                                 const esac_hip_params* p, void* stream, double* h_out) {
+    if (!d_out_gradients || !h_gt_pose) return fail(-1, "esac_hip_backward: null gradient tensor or ground-truth pose");
+    KArgs a;
+    int rc = make_args(c, d_sc, d_assign, p, &a);
+    if (rc) return rc;
+    if (p->d_hyp_index || p->hyp_offset)
+        return fail(-4, "esac_hip_backward: sharded calls are not supported (the expectation needs every hypothesis)");
+    const int P = p->H * p->W;
+    if ((rc = ensure_bws(c, p->N, P))) return rc;
+    a.bwd = c->bws;
+    a.bwd.cap = p->N < ESAC_BWD_MAX_SLOTS ? p->N : ESAC_BWD_MAX_SLOTS;
+    a.bwd.out_grad = d_out_gradients;
+    a.bwd.w_rot = (double)w_loss_rot;
+    a.bwd.w_trans = (double)w_loss_trans;
+    a.bwd.cut = (double)loss_cut;
+    double Ti[16];
+    for (int i = 0; i < 16; i++) a.bwd.gt[i] = (double)h_gt_pose[i];
+    if (!inv4_host(a.bwd.gt, Ti)) return fail(-4, "esac_hip_backward: the ground-truth pose is singular");
+    double Rg[9] = {Ti[0], Ti[1], Ti[2], Ti[4], Ti[5], Ti[6], Ti[8], Ti[9], Ti[10]};
+    nearest_rotation_host(Rg);
+    rodrigues_mat2vec(Rg, a.bwd.gt_pose);
+    a.bwd.gt_pose[3] = Ti[3]; a.bwd.gt_pose[4] = Ti[7]; a.bwd.gt_pose[5] = Ti[11];
+    a.tstamps = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    launch_sample(a, s);                                        // esac.cpp:276
+    if ((rc = check_launch("k_sample"))) return rc;
+    launch_rescore(a, 1, s);                                    // esac.cpp:295-316, reference arithmetic for every hypothesis
+    if ((rc = check_launch("k_rescore(all)"))) return rc;
+    launch_bwd_select(a, s);                                    // esac.cpp:319-331
+    if ((rc = check_launch("k_bwd_select"))) return rc;
+    launch_refine_slots(a, s);                                  // esac.cpp:328-347
+    if ((rc = check_launch("k_refine(slots)"))) return rc;
+    launch_bwd_loss(a, s);                                      // esac.cpp:354-362 + dLoss + softmax derivative
+    if ((rc = check_launch("k_bwd_loss"))) return rc;
+    launch_bwd_path1(a, s);                                     // esac.cpp:375-463
+    if ((rc = check_launch("k_bwd_path1"))) return rc;
+    launch_bwd_path2(a, s);                                     // esac.cpp:470-488
+    if ((rc = check_launch("k_bwd_path2"))) return rc;
+    launch_bwd_accumulate(a, s);                                // esac.cpp:491-508
+    if ((rc = check_launch("k_bwd_accumulate"))) return rc;
+    if (h_out) {
+        HIP_OK(hipMemcpyAsync(h_out, a.bwd.out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
 extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t bytes) {
     if (!c || !h_dst) return fail(-1, "esac_hip_read: null argument");
     HIP_OK(hipSetDevice(c->device));
@@ -337,6 +491,13 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
         case ESAC_BUF_WINNER_ERRS: src = c->ws.errs; want = P * sizeof(float); break;
         case ESAC_BUF_EXACT_FLAGS: src = c->ws.exact_flag; want = N; break;
         case ESAC_BUF_CYCLES: src = c->ws.cycles; want = 32 * sizeof(long long); break;
+        case ESAC_BUF_BWD_PROBS: src = c->bws.probs; want = N * sizeof(double); break;
+        case ESAC_BUF_BWD_LOSSES: src = c->bws.losses; want = N * sizeof(double); break;
+        case ESAC_BUF_BWD_REF_HYPS: src = c->bws.ref_hyps; want = N * 6 * sizeof(double); break;
+        case ESAC_BUF_BWD_SCORE_GRADS: src = c->bws.sgrad; want = N * sizeof(double); break;
+        case ESAC_BUF_BWD_SLOTS: src = c->bws.sel; want = N * sizeof(int32_t); break;
+        case ESAC_BUF_BWD_SLOT_INFO: src = c->bws.map_info; want = (size_t)(c->lastN < ESAC_BWD_MAX_SLOTS ? c->lastN : ESAC_BWD_MAX_SLOTS) * 4 * sizeof(int32_t); break;
+        case ESAC_BUF_BWD_DLOSS: src = c->bws.dloss; want = (size_t)(c->lastN < ESAC_BWD_MAX_SLOTS ? c->lastN : ESAC_BWD_MAX_SLOTS) * 6 * sizeof(double); break;
         default: return fail(-5, "esac_hip_read: unknown buffer id %d", which);
     }
     if (!src || want == 0) return fail(-6, "esac_hip_read: buffer %d is empty (no call has run yet)", which);

@@ -10,6 +10,30 @@ constexpr int ESAC_RES_SCORE_K = 0, ESAC_RES_HYP_K = 1, ESAC_RES_EXPERT_K = 2, E
               ESAC_RES_POSE_K = 9, ESAC_RES_REF_STEPS_K = 25, ESAC_RES_INLIERS_K = 26, ESAC_RES_PROB_K = 27,
               ESAC_RES_ENTROPY_K = 28, ESAC_RES_CONTENDERS_K = 29, ESAC_RES_LM_ITERS_K = 30;
 constexpr int ESAC_MAX_REF_STEPS_K = 100;
+constexpr int ESAC_REFINE_LDS_CAP = 8192;  // correspondences the refinement kernel stages in LDS (128 KiB of the CU's 160 KiB)
+
+// Training path (esac_hip_backward).  "slot" = position in the ordered list of hypotheses whose selection
+// probability reaches PROB_THRESH (esac_derivative.h:33) -- at most 1000 of them exist for any N.
+struct BwdArgs {
+    int* sel;             // [N] hypothesis index per slot, ascending
+    int* n_sel;           // [1]
+    double* probs;        // [N] softmax of the exact scores
+    double* losses;       // [N]
+    double* ref_hyps;     // [N,6] refined pose (initial pose for unselected hypotheses)
+    double* sgrad;        // [N] d expected loss / d score (esac_derivative.h:405-420)
+    double* dloss;        // [cap,6] d loss / d refined pose
+    uint8_t* maps;        // [cap,2,P] alternating inlier maps of the slot's refinement
+    int* map_info;        // [cap,4] accepted buffer (-1: none), inliers of the last accepted step, steps, LM iterations
+    void* corr_lists;     // [cap,P] 16-byte correspondences (only for grids above LDS_CAP)
+    double* grad1;        // [cap,P,3] path I: refined pose -> coordinates (unweighted, esac.cpp:375-463)
+    double* grad2;        // [cap,P,3] path II: score -> coordinates (esac_derivative.h:205-330)
+    double* out;          // [4] expected loss, number of slots, entropy, 0
+    float* out_grad;      // [E,3,H,W] accumulated into (+=)
+    double gt[16];        // ground-truth camera pose, row-major (double of the float input)
+    double gt_pose[6];    // trans2pose(gt) (esac_util.h:555-568)
+    double w_rot, w_trans, cut;
+    int cap;
+};
 
 struct KArgs {
     // inputs (device)
@@ -50,6 +74,7 @@ struct KArgs {
     // batched calls: frame b = blockIdx.y works on its own slice of every buffer (device_common.hpp:frame_view)
     int frames;                 // B >= 1
     long long sc_frame_stride;  // elements between the coordinate tensors of consecutive frames
+    BwdArgs bwd;                // training path only
 };
 
 void launch_sample(const KArgs& a, hipStream_t s);
@@ -58,5 +83,12 @@ void launch_score_fast(const KArgs& a, hipStream_t s);
 void launch_select(const KArgs& a, hipStream_t s);
 void launch_rescore(const KArgs& a, int all, hipStream_t s);
 void launch_refine(const KArgs& a, hipStream_t s);
+// training path (esac_backward.hip, esac_refine.hip)
+void launch_refine_slots(const KArgs& a, hipStream_t s);
+void launch_bwd_select(const KArgs& a, hipStream_t s);
+void launch_bwd_loss(const KArgs& a, hipStream_t s);
+void launch_bwd_path1(const KArgs& a, hipStream_t s);
+void launch_bwd_path2(const KArgs& a, hipStream_t s);
+void launch_bwd_accumulate(const KArgs& a, hipStream_t s);
 
 }  // namespace esac

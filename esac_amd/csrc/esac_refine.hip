@@ -34,7 +34,7 @@ namespace esac {
 #define ESAC_REFINE_B 256
 #endif
 constexpr int REFINE_B = ESAC_REFINE_B;  // default 4 wavefronts = one per SIMD of the one CU this kernel occupies
-constexpr int LDS_CAP = 8192;            // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
+constexpr int LDS_CAP = ESAC_REFINE_LDS_CAP;  // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
 #ifndef ESAC_ERR_UNROLL
 #define ESAC_ERR_UNROLL 8
 #endif
@@ -363,7 +363,9 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
 
 // GLOBAL_LIST: correspondence list in global memory (grids with more than LDS_CAP cells), else in LDS.
 // VEC: 16-byte accesses in the error pass (W % 4 == 0 and a 16-byte aligned coordinate tensor).
-template <int B, bool GLOBAL_LIST, bool VEC>
+// SLOTS: training path -- workgroup b refines the hypothesis of selection slot b (esac.cpp:328-347) and leaves
+// its refined pose and inlier maps in the BwdArgs buffers instead of picking the winner and writing the record.
+template <int B, bool GLOBAL_LIST, bool VEC, bool SLOTS>
 __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     __shared__ Corr s_list[GLOBAL_LIST ? 1 : LDS_CAP];
     __shared__ double s_part[28 * (B / 64)];
@@ -383,10 +385,11 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const long long cyc_start = clock64();
 #endif
     CYC_BEGIN();
+    if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
 
     // ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties
     //      (esac_util.h:512-529; softmax is monotone, so the argmax of the scores is the argmax of the probabilities)
-    const int nc = a.n_contenders[0];
+    const int nc = SLOTS ? 0 : a.n_contenders[0];
     double bs = -INFINITY;
     int bi = 0x7fffffff, bg = 0x7fffffff;
     for (int c = threadIdx.x; c < nc; c += B) {
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
             bg = og;
         }
     }
-    const int win = (bi == 0x7fffffff) ? 0 : bi;
+    const int win = SLOTS ? a.bwd.sel[blockIdx.x] : (bi == 0x7fffffff) ? 0 : bi;
     const double win_score = a.scores[win];
     const int e = (int)a.assign[win];
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
@@ -438,12 +441,16 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     double pose[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
-    for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;
+    if (!SLOTS)
+        for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;
     __syncthreads();
     CYC_END(1);
 
     // ---- refineHyp (esac_util.h:378-454): one error-pass site, one re-fit site
-    Corr* const list = GLOBAL_LIST ? reinterpret_cast<Corr*>(a.corr_list) : s_list;
+    Corr* const list = !GLOBAL_LIST ? s_list
+                       : SLOTS      ? reinterpret_cast<Corr*>(a.bwd.corr_lists) + (size_t)blockIdx.x * P
+                                    : reinterpret_cast<Corr*>(a.corr_list);
+    uint8_t* const maps = SLOTS ? a.bwd.maps + (size_t)blockIdx.x * 2 * P : a.inlier_map;
     const int cap = GLOBAL_LIST ? P : LDS_CAP;
     int accepted = 0, last_inliers = 0, lm_total = 0, map_buf = -1;
     int cur = 0;  // map buffer the next error pass writes
@@ -453,11 +460,11 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         // this step's inlier set and its compacted correspondence list
         CYC_BEGIN();
         __syncthreads();  // every lane is done reading the list before it is rebuilt
-        const int n_inl = error_pass_impl<B, VEC>(a, mx, P, pose, cam, list, cap, a.inlier_map + (size_t)cur * P, s_wcnt, g_cyc);
+        const int n_inl = error_pass_impl<B, VEC>(a, mx, P, pose, cam, list, cap, maps + (size_t)cur * P, s_wcnt, g_cyc);
         __syncthreads();
         CYC_END(2);
         if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
-        if (threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
+        if (!SLOTS && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
         if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
         best_inliers = (unsigned)n_inl;
         lm_total += lm_refit<B>((const Corr*)list, n_inl, pose, cam, s_part, s_tot, g_cyc);
@@ -467,6 +474,18 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         cur ^= 1;
     }
 
+    if (SLOTS) {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) a.bwd.ref_hyps[(size_t)win * 6 + k] = pose[k];
+            int* mi = a.bwd.map_info + 4 * blockIdx.x;
+            mi[0] = map_buf;
+            mi[1] = last_inliers;
+            mi[2] = accepted;
+            mi[3] = lm_total;
+        }
+        return;
+    }
     // ---- pose2trans (esac_util.h:537-548) and the result record
     if (threadIdx.x == 0) {
         double R[9];
@@ -514,11 +533,26 @@ void launch_refine(const KArgs& a, hipStream_t s) {
     // 16-byte accesses: W % 4 == 0 keeps every row, plane (P % 4 == 0) and expert map 16-byte aligned
     const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
     if (global_list) {
-        if (vec) hipLaunchKernelGGL((k_refine<B, true, true>), dim3(1, a.frames), dim3(B), 0, s, a);
-        else     hipLaunchKernelGGL((k_refine<B, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
+        if (vec) hipLaunchKernelGGL((k_refine<B, true, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
+        else     hipLaunchKernelGGL((k_refine<B, true, false, false>), dim3(1, a.frames), dim3(B), 0, s, a);
     } else {
-        if (vec) hipLaunchKernelGGL((k_refine<B, false, true>), dim3(1, a.frames), dim3(B), 0, s, a);
-        else     hipLaunchKernelGGL((k_refine<B, false, false>), dim3(1, a.frames), dim3(B), 0, s, a);
+        if (vec) hipLaunchKernelGGL((k_refine<B, false, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
+        else     hipLaunchKernelGGL((k_refine<B, false, false, false>), dim3(1, a.frames), dim3(B), 0, s, a);
+    }
+}
+
+// One workgroup per selection slot; slots beyond n_sel (known only on the device) return at once.
+void launch_refine_slots(const KArgs& a, hipStream_t s) {
+    constexpr int B = REFINE_B;
+    const bool global_list = a.H * a.W > LDS_CAP;
+    const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
+    const dim3 grid(a.N < a.bwd.cap ? a.N : a.bwd.cap);
+    if (global_list) {
+        if (vec) hipLaunchKernelGGL((k_refine<B, true, true, true>), grid, dim3(B), 0, s, a);
+        else     hipLaunchKernelGGL((k_refine<B, true, false, true>), grid, dim3(B), 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_refine<B, false, true, true>), grid, dim3(B), 0, s, a);
+        else     hipLaunchKernelGGL((k_refine<B, false, false, true>), grid, dim3(B), 0, s, a);
     }
 }
 

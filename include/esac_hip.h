@@ -93,8 +93,21 @@ enum {
     ESAC_BUF_INLIER_COUNTS = 6, /* int32[ESAC_MAX_REF_STEPS+1] inlier count seen at each step    */
     ESAC_BUF_WINNER_ERRS = 7,   /* float[H*W] reprojection errors of the current pose            */
     ESAC_BUF_EXACT_FLAGS = 8,   /* uint8[N] 1 where ESAC_BUF_SCORES holds an exact re-score      */
-    ESAC_BUF_CYCLES = 9         /* int64[32] shader-cycle counters of the refinement kernel (profiling) */
+    ESAC_BUF_CYCLES = 9,        /* int64[32] shader-cycle counters of the refinement kernel (profiling) */
+    /* stage outputs of the most recent esac_hip_backward */
+    ESAC_BUF_BWD_PROBS = 10,       /* double[N]   selection probabilities (softmax of the exact scores)      */
+    ESAC_BUF_BWD_LOSSES = 11,      /* double[N]   pose loss of every (refined) hypothesis                    */
+    ESAC_BUF_BWD_REF_HYPS = 12,    /* double[N,6] refined poses (initial pose where p < PROB_THRESH)          */
+    ESAC_BUF_BWD_SCORE_GRADS = 13, /* double[N]   d expected loss / d score                                  */
+    ESAC_BUF_BWD_SLOTS = 14,       /* int32[N]    hypothesis index per slot, first h_out[1] entries valid    */
+    ESAC_BUF_BWD_SLOT_INFO = 15,   /* int32[min(N,ESAC_BWD_MAX_SLOTS),4] per slot: accepted map buffer (-1 none),
+                                      inliers of the last accepted step, accepted steps, LM iterations        */
+    ESAC_BUF_BWD_DLOSS = 16        /* double[min(N,ESAC_BWD_MAX_SLOTS),6] d loss / d refined pose per slot    */
 };
+
+/* Hypotheses that take part in the training expectation: selection probability >= PROB_THRESH = 0.001
+ * (esac_derivative.h:33), so never more than 1000 whatever N is. */
+#define ESAC_BWD_MAX_SLOTS 1000
 
 typedef struct esac_hip_ctx esac_hip_ctx;
 
@@ -137,6 +150,24 @@ int esac_hip_forward(esac_hip_ctx* ctx, const float* d_scene_coords, const int64
 int esac_hip_forward_batch(esac_hip_ctx* ctx, int B, const float* d_scene_coords, int64_t sc_frame_stride,
                            const int64_t* d_hyp_assign, const esac_hip_params* p, void* stream,
                            double* d_scores_out, double* d_result_out, double* h_result_out);
+
+/*
+ * esac_backward (esac.cpp:213-520): expected pose loss over the hypothesis distribution and its gradient wrt the
+ * scene coordinates, everything on the device.
+ * d_out_gradients [E,3,H,W] float32 (device), ACCUMULATED into (`+=`, esac.cpp:491-508) -- the caller zeroes it,
+ *                 as train_esac.py:176 does.
+ * h_gt_pose       host float[16], the ground-truth camera pose (4x4 row-major; gtPose, esac.cpp:219).
+ * w_loss_rot / w_loss_trans / loss_cut: wLossRot, wLossTrans, lossCut (esac.cpp:220-222).
+ * h_out           optional host double[4]: expected loss (the return value of esac_backward), number of
+ *                 hypotheses with p >= PROB_THRESH, entropy of the distribution, 0.  When non-NULL the call
+ *                 blocks on `stream` (the reference call is blocking); otherwise it is asynchronous.
+ * Uses the same Philox streams as esac_hip_forward for (seed, call): the hypotheses of a backward call are the
+ * hypotheses of the forward call with the same counter.  Hypothesis sharding (hyp_offset / d_hyp_index) is
+ * rejected: the softmax expectation needs every hypothesis on one device.
+ */
+int esac_hip_backward(esac_hip_ctx* ctx, const float* d_scene_coords, float* d_out_gradients,
+                      const int64_t* d_hyp_assign, const float* h_gt_pose, float w_loss_rot, float w_loss_trans,
+                      float loss_cut, const esac_hip_params* p, void* stream, double* h_out);
 
 /* The same phases one at a time (asynchronous on `stream`), for stage-wise parity
  * tests and for callers that interleave other work.  Order: sample, score, select, refine. */

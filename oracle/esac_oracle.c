@@ -571,6 +571,36 @@ void esac_oracle_rodrigues_mat2vec(const double R[9], double r[3]) {
     r[0] = rx; r[1] = ry; r[2] = rz;
 }
 
+static void jacobi_sym(int n, double* A, double* w, double* V);
+
+/* cv::Rodrigues(matrix -> vector) the way OpenCV runs it on a general 3x3 input: R is first replaced by the
+ * nearest rotation U*Vt of its SVD, i.e. the orthogonal polar factor R (R^T R)^(-1/2).  Matters where the
+ * reference feeds a FLOAT matrix (trans2pose on the ground-truth pose, esac_util.h:555-568; the float entries
+ * are orthonormal to ~1e-7 only).  The P3P path keeps the plain routine above. */
+void esac_oracle_rodrigues_mat2vec_svd(const double R[9], double r[3]) {
+    double A[9], w[3], V[9], M[9], Ro[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += R[3 * k + i] * R[3 * k + j];
+            A[3 * i + j] = s;
+        }
+    jacobi_sym(3, A, w, V);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += V[3 * i + k] * V[3 * j + k] / sqrt(w[k]);
+            M[3 * i + j] = s;
+        }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += R[3 * i + k] * M[3 * k + j];
+            Ro[3 * i + j] = s;
+        }
+    esac_oracle_rodrigues_mat2vec(Ro, r);
+}
+
 /* ------------------------------------------------------------------------- */
 /* Pinhole projection  [OpenCV cvProjectPoints2 without distortion, from      */
 /* memory]: fp64 compute, `z = z ? 1/z : 1`, no cheirality test, float output */

@@ -117,6 +117,7 @@ int  esac_oracle_p3p_all(const double* obj3, const double* img3, double fx, doub
 int  esac_oracle_solve_deg4(double a, double b, double c, double d, double e, double roots[4]);
 void esac_oracle_rodrigues_vec2mat(const double r[3], double R[9], double dRdr[27]);
 void esac_oracle_rodrigues_mat2vec(const double R[9], double r[3]);
+void esac_oracle_rodrigues_mat2vec_svd(const double R[9], double r[3]); /* with OpenCV's U*Vt re-orthonormalisation */
 void esac_oracle_project(const double rvec[3], const double tvec[3], double fx, double fy,
                          double cx, double cy, const float* pts3, int n, float* uv);
 /* LM refit (cv::solvePnP ITERATIVE, useExtrinsicGuess=true). pose in/out (rvec,tvec).
@@ -126,6 +127,14 @@ int  esac_oracle_lm_pnp(const float* obj, const float* img, int n, double fx, do
 void esac_oracle_pose2trans(const double pose[6], double T[16]);
 void esac_oracle_inv4(const double M[16], double Minv[16]);
 void esac_oracle_pinv_sym6(const double A[36], double Ainv[36]);
+/* single routines of the training path (esac_loss.h, esac_derivative.h, esac_util.h:333-351,555-568) */
+double esac_oracle_pose_loss(const double pose[6], const double gt_trans[16], double wRot, double wTrans, double cut);
+void esac_oracle_pose_dloss(const double est[6], const double gt_pose[6], double wRot, double wTrans, double cut, double jac[6]);
+void esac_oracle_trans2pose(const double T[16], double pose[6]);
+void esac_oracle_dproject_dobj(float ptx, float pty, float ox, float oy, float oz, const double rvec[3], const double t[3],
+                               float focal, float ppx, float ppy, float maxReproj, double out[3]);
+int esac_oracle_norm_jac_row(const double rvec[3], const double t[3], float focal, float ppx, float ppy, float X, float Y,
+                             float Z, float px, float py, float maxReproj, double row[6]);
 void esac_oracle_project_jac(const double rvec[3], const double tvec[3], double fx, double fy, double cx, double cy,
                              const float* pts3, int n, double* J12);
 int  esac_oracle_max_threads(void);

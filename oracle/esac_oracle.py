@@ -76,6 +76,15 @@ def lib():
         _lib.esac_oracle_lm_pnp.restype = C.c_int
         _lib.esac_oracle_project.argtypes = [C.c_void_p, C.c_void_p, d, d, d, d, C.c_void_p, C.c_int, C.c_void_p]
         _lib.esac_oracle_draw_cells.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        f = C.c_float
+        _lib.esac_oracle_pose_loss.argtypes = [C.c_void_p, C.c_void_p, d, d, d]
+        _lib.esac_oracle_pose_loss.restype = d
+        _lib.esac_oracle_pose_dloss.argtypes = [C.c_void_p, C.c_void_p, d, d, d, C.c_void_p]
+        _lib.esac_oracle_trans2pose.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.esac_oracle_dproject_dobj.argtypes = [f, f, f, f, f, C.c_void_p, C.c_void_p, f, f, f, f, C.c_void_p]
+        _lib.esac_oracle_norm_jac_row.argtypes = [C.c_void_p, C.c_void_p, f, f, f, f, f, f, f, f, f, C.c_void_p]
+        _lib.esac_oracle_norm_jac_row.restype = C.c_int
+        _lib.esac_oracle_pinv_sym6.argtypes = [C.c_void_p, C.c_void_p]
     return _lib
 
 
@@ -264,6 +273,58 @@ def rodrigues_mat2vec(R):
     r = np.zeros(3)
     lib().esac_oracle_rodrigues_mat2vec(_p(R), _p(r))
     return r
+
+
+def rodrigues_mat2vec_svd(R):
+    """cv::Rodrigues on a matrix as OpenCV runs it (nearest rotation first)."""
+    R = np.ascontiguousarray(R, np.float64)
+    r = np.zeros(3)
+    lib().esac_oracle_rodrigues_mat2vec_svd(_p(R), _p(r))
+    return r
+
+
+def pose_loss(pose, gt_trans, w_rot, w_trans, cut):
+    pose = np.ascontiguousarray(pose, np.float64)
+    gt = np.ascontiguousarray(gt_trans, np.float64)
+    return lib().esac_oracle_pose_loss(_p(pose), _p(gt), w_rot, w_trans, cut)
+
+
+def pose_dloss(est, gt_pose, w_rot, w_trans, cut):
+    est = np.ascontiguousarray(est, np.float64)
+    gt = np.ascontiguousarray(gt_pose, np.float64)
+    j = np.zeros(6)
+    lib().esac_oracle_pose_dloss(_p(est), _p(gt), w_rot, w_trans, cut, _p(j))
+    return j
+
+
+def trans2pose(T):
+    T = np.ascontiguousarray(T, np.float64)
+    pose = np.zeros(6)
+    lib().esac_oracle_trans2pose(_p(T), _p(pose))
+    return pose
+
+
+def dproject_dobj(pt, obj, rvec, tvec, focal, ppx, ppy, max_reproj):
+    r = np.ascontiguousarray(rvec, np.float64)
+    t = np.ascontiguousarray(tvec, np.float64)
+    out = np.zeros(3)
+    lib().esac_oracle_dproject_dobj(pt[0], pt[1], obj[0], obj[1], obj[2], _p(r), _p(t), focal, ppx, ppy, max_reproj, _p(out))
+    return out
+
+
+def norm_jac_row(rvec, tvec, focal, ppx, ppy, obj, pt, max_reproj):
+    r = np.ascontiguousarray(rvec, np.float64)
+    t = np.ascontiguousarray(tvec, np.float64)
+    row = np.zeros(6)
+    ok = lib().esac_oracle_norm_jac_row(_p(r), _p(t), focal, ppx, ppy, obj[0], obj[1], obj[2], pt[0], pt[1], max_reproj, _p(row))
+    return ok, row
+
+
+def pinv_sym6(A):
+    A = np.ascontiguousarray(A, np.float64)
+    out = np.zeros((6, 6))
+    lib().esac_oracle_pinv_sym6(_p(A), _p(out))
+    return out
 
 
 def project(rvec, tvec, fx, fy, cx, cy, pts3):

@@ -296,7 +296,7 @@ inline void Rodrigues(const Mat& src, Mat& dst) {
         assert(src.rows == 3 && src.cols == 3);
         double R[9], r[3];
         for (int i = 0; i < 9; i++) R[i] = src.getd(i / 3, i % 3);
-        esac_oracle_rodrigues_mat2vec(R, r);
+        esac_oracle_rodrigues_mat2vec_svd(R, r);  // OpenCV re-orthonormalises a matrix input (U*Vt)
         Mat_<double> m(3, 1);
         for (int i = 0; i < 3; i++) m(i, 0) = r[i];
         dst = m;

@@ -3,6 +3,7 @@
 // Built by tests/native/build.py with hipcc (host pass only is used). Not part of the product library.
 #include "../../esac_amd/csrc/pose_math.hpp"
 #include "../../esac_amd/csrc/lm_math.hpp"
+#include "../../esac_amd/csrc/bwd_math.hpp"
 using namespace esac;
 extern "C" {
 int probe_p3p(const double* obj, const double* img, double fx, double fy, double cx, double cy, double* rvec, double* tvec, double* Rout) {
@@ -38,4 +39,21 @@ void probe_lm_normal(const float* obj, const float* img, int n, const double* po
     lm_to_rvec_space(acc, R, dRdr, pose + 3, U21, g6);
     *e2 = acc[26];
 }
+// ---- training-path routines (bwd_math.hpp)
+double probe_pose_loss(const double* pose, const double* gt16, double wR, double wT, double cut) { return pose_loss(pose, gt16, wR, wT, cut); }
+void probe_pose_dloss(const double* est, const double* gt6, double wR, double wT, double cut, double* jac) { pose_dloss(est, gt6, wR, wT, cut, jac); }
+void probe_dproject_dobj(float ptx, float pty, float ox, float oy, float oz, const double* rvec, const double* t, float focal,
+                         float ppx, float ppy, float max_reproj, double* out) {
+    double R[9];
+    rodrigues_vec2mat<false>(rvec, R, nullptr);
+    dproject_dobj(ptx, pty, ox, oy, oz, R, t, focal, ppx, ppy, max_reproj, out);
+}
+int probe_norm_jac_row(const double* rvec, const double* t, float focal, float ppx, float ppy, float X, float Y, float Z, float px,
+                       float py, float max_reproj, double* row) {
+    Cam cam{(double)focal, (double)focal, (double)ppx, (double)ppy};
+    double R[9], dRdr[27];
+    rodrigues_vec2mat<true>(rvec, R, dRdr);
+    return norm_jac_row(R, dRdr, t, cam, X, Y, Z, px, py, max_reproj, row) ? 1 : 0;
+}
+int probe_inv_spd6(const double* U21, double* Ainv) { return inv_spd6(U21, Ainv) ? 1 : 0; }
 }

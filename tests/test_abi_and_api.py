@@ -81,6 +81,43 @@ def test_forward_signature_matches_reference():
     assert callable(esac.backward)
 
 
+def test_backward_signature_matches_reference():
+    """esac_backward(sceneCoordinates, outGradients, hypAssignment, gtPose, wLossRot, wLossTrans, lossCut, shiftX,
+    shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha, inlierBeta, maxReproj, subSampling)
+    -- esac.cpp:213-230."""
+    import esac
+    params = list(inspect.signature(esac.backward).parameters)
+    assert params == ["sceneCoordinates", "outGradients", "hypAssignment", "gtPose", "wLossRot", "wLossTrans", "lossCut",
+                      "shiftX", "shiftY", "focalLength", "ppointX", "ppointY", "inlierThreshold", "inlierAlpha",
+                      "inlierBeta", "maxReproj", "subSampling"]
+
+
+@pytest.mark.parametrize("bad", ["sc_dtype", "grad_shape", "grad_dtype", "ha_dtype", "gt_shape", "gt_dtype", "empty", "no_gpu"])
+def test_backward_argument_validation(bad):
+    import esac
+    sc = torch.zeros(1, 3, 60, 80)
+    g = torch.zeros(1, 3, 60, 80)
+    ha = torch.zeros(8, dtype=torch.int64)
+    gt = torch.eye(4)
+    if bad == "sc_dtype":
+        sc = sc.double()
+    elif bad == "grad_shape":
+        g = torch.zeros(1, 3, 60, 79)
+    elif bad == "grad_dtype":
+        g = g.double()
+    elif bad == "ha_dtype":
+        ha = ha.int()
+    elif bad == "gt_shape":
+        gt = torch.eye(3)
+    elif bad == "gt_dtype":
+        gt = gt.double()
+    elif bad == "empty":
+        ha = ha[:0]
+    # "no_gpu": valid arguments, but this container has no device -> loud failure, no CPU fallback
+    with pytest.raises(RuntimeError):
+        esac.backward(sc, g, ha, gt, 1.0, 100.0, 100.0, 0, 0, 525.0, 320.0, 240.0, 10.0, 100.0, 0.5, 100.0, 8)
+
+
 @pytest.mark.parametrize("bad", ["sc_dtype", "sc_rank", "sc_chan", "ha_dtype", "ha_rank", "pose_shape", "pose_dtype", "empty"])
 def test_argument_validation_raises_runtime_error(bad):
     """accessor<float,4>() / accessor<long,1>() / accessor<float,2>() failures surface as RuntimeError (pybind11)."""

@@ -26,6 +26,13 @@ def probe():
     lib.probe_exact_err.restype = C.c_float
     lib.probe_lm_solve6.argtypes = [vp, vp, d, vp]
     lib.probe_lm_normal.argtypes = [vp, vp, C.c_int, vp, d, d, d, d, vp, vp, vp]
+    f = C.c_float
+    lib.probe_pose_loss.argtypes = [vp, vp, d, d, d]
+    lib.probe_pose_loss.restype = d
+    lib.probe_pose_dloss.argtypes = [vp, vp, d, d, d, vp]
+    lib.probe_dproject_dobj.argtypes = [f, f, f, f, f, vp, vp, f, f, f, f, vp]
+    lib.probe_norm_jac_row.argtypes = [vp, vp, f, f, f, f, f, f, f, f, f, vp]
+    lib.probe_inv_spd6.argtypes = [vp, vp]
     return lib
 
 
@@ -156,3 +163,109 @@ def test_lm_normal_equations_match_numeric_jacobian(oracle, probe):
             A = Um.copy()
             A[np.diag_indices(6)] *= 1 + lam
             np.testing.assert_allclose(dx, np.linalg.solve(A, g), rtol=1e-8, atol=1e-12)
+
+
+# ---------------------------------------------------------------- training path (bwd_math.hpp)
+def _random_pose(rng, scale=1.0):
+    return np.concatenate([rng.normal(size=3) * 0.6 * scale, rng.normal(size=3) * 2.0])
+
+
+def _gt_from_pose(oracle, pose, rng, noise=0.05):
+    """float32 camera transform near pose^-1, as the data loader hands it to esac_backward."""
+    p = pose + np.concatenate([rng.normal(size=3) * noise, rng.normal(size=3) * noise])
+    return oracle.pose2trans(p).astype(np.float32)
+
+
+def test_pose_loss_matches_oracle(oracle, probe):
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for it in range(200):
+        pose = _random_pose(rng)
+        gt = _gt_from_pose(oracle, pose, rng, noise=[1e-4, 0.05, 1.0][it % 3]).astype(np.float64)
+        for cut in (100.0, 0.5):  # with and without the soft clamp
+            a = probe.probe_pose_loss(_p(pose), _p(gt), 1.0, 100.0, cut)
+            b = oracle.pose_loss(pose, gt, 1.0, 100.0, cut)
+            worst = max(worst, abs(a - b) / max(abs(b), 1e-12))
+    # rigid inverse (device) vs LU inverse (reference): rounding-level differences, amplified by acos near 0 degrees
+    assert worst < 1e-8, worst
+
+
+def test_pose_dloss_matches_oracle_and_finite_differences(oracle, probe):
+    rng = np.random.default_rng(12)
+    for it in range(100):
+        pose = _random_pose(rng)
+        gt_T = _gt_from_pose(oracle, pose, rng, noise=0.05).astype(np.float64)
+        gt_pose = oracle.trans2pose(gt_T)
+        for cut in (1e9, 0.5):
+            a = np.zeros(6)
+            probe.probe_pose_dloss(_p(pose), _p(gt_pose), 1.0, 100.0, cut, _p(a))
+            b = oracle.pose_dloss(pose, gt_pose, 1.0, 100.0, cut)
+            np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11)
+        # without the clamp dLoss is the true gradient of loss() -- central differences agree
+        fd = np.zeros(6)
+        for k in range(6):
+            e = np.zeros(6)
+            e[k] = 1e-6
+            fd[k] = (oracle.pose_loss(pose + e, gt_T, 1.0, 100.0, 1e9) - oracle.pose_loss(pose - e, gt_T, 1.0, 100.0, 1e9)) / 2e-6
+        a = np.zeros(6)
+        probe.probe_pose_dloss(_p(pose), _p(gt_pose), 1.0, 100.0, 1e9, _p(a))
+        np.testing.assert_allclose(a, fd, rtol=2e-3, atol=2e-3)
+
+
+def test_trans2pose_orthonormalises_float_pose(oracle):
+    rng = np.random.default_rng(13)
+    for _ in range(20):
+        pose = _random_pose(rng)
+        T32 = oracle.pose2trans(pose).astype(np.float32).astype(np.float64)
+        back = oracle.trans2pose(T32)
+        # float32 rounding of the matrix moves the pose by ~1e-7; the re-orthonormalised result is a proper pose
+        np.testing.assert_allclose(back, pose, rtol=0, atol=5e-6)
+        R = oracle.rodrigues_vec2mat(back[:3])
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-14)
+        # and the SVD variant equals the plain one on an exactly orthonormal input
+        Rp = oracle.rodrigues_vec2mat(pose[:3])
+        np.testing.assert_allclose(oracle.rodrigues_mat2vec_svd(Rp), oracle.rodrigues_mat2vec(Rp), atol=1e-14)
+
+
+def test_cell_jacobians_match_oracle(oracle, probe):
+    rng = np.random.default_rng(14)
+    f32 = np.float32
+    n_skip = 0
+    for it in range(500):
+        pose = _random_pose(rng, 0.3)
+        obj = (rng.normal(size=3) * 1.5 + np.array([0, 0, 4.0])).astype(f32)
+        # pixel near the projection so that a good share falls inside maxReproj = 100
+        uv = oracle.project(pose[:3], pose[3:], FX, FY, CX, CY, obj[None])[0]
+        pt = (uv + rng.normal(size=2) * [1.0, 50.0, 200.0][it % 3]).astype(f32)
+        ok_a, row_b = oracle.norm_jac_row(pose[:3], pose[3:], 525.0, 320.0, 240.0, obj, pt, 100.0)
+        row_a = np.zeros(6)
+        ok_p = probe.probe_norm_jac_row(_p(pose[:3].copy()), _p(pose[3:].copy()), 525.0, 320.0, 240.0, obj[0], obj[1], obj[2],
+                                        pt[0], pt[1], 100.0, _p(row_a))
+        assert bool(ok_p) == bool(ok_a)
+        np.testing.assert_array_equal(row_a, row_b)  # same operations in the same order: bit-identical
+        n_skip += not ok_a
+        d_b = oracle.dproject_dobj(pt, obj, pose[:3], pose[3:], 525.0, 320.0, 240.0, 100.0)
+        d_a = np.zeros(3)
+        probe.probe_dproject_dobj(pt[0], pt[1], obj[0], obj[1], obj[2], _p(pose[:3].copy()), _p(pose[3:].copy()), 525.0, 320.0,
+                                  240.0, 100.0, _p(d_a))
+        np.testing.assert_array_equal(d_a, d_b)
+    assert 0 < n_skip < 500  # both branches of the maxReproj test were exercised
+
+
+def test_inv_spd6_equals_reference_pseudo_inverse_on_full_rank(oracle, probe):
+    rng = np.random.default_rng(15)
+    iu = np.triu_indices(6)
+    for it in range(50):
+        J = rng.normal(size=(40, 6)) * np.array([100, 100, 100, 30, 30, 10.0])
+        A = J.T @ J
+        out = np.zeros((6, 6))
+        assert probe.probe_inv_spd6(_p(np.ascontiguousarray(A[iu])), _p(out)) == 1
+        ref = oracle.pinv_sym6(A)
+        np.testing.assert_allclose(out, ref, rtol=1e-8, atol=1e-14)
+    # rank deficient -> reported, the caller then writes a zero gradient
+    J = rng.normal(size=(40, 5))
+    J = np.concatenate([J, J[:, :1]], axis=1)
+    A = J.T @ J
+    out = np.zeros((6, 6))
+    ok = probe.probe_inv_spd6(_p(np.ascontiguousarray(A[iu])), _p(out))
+    assert ok == 0 or np.abs(out).max() > 1e6

@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--grid", type=str, default="60x80")
     ap.add_argument("--batch", type=int, default=64, help="frames per launch set for the extra `batched` figure (0 = skip)")
+    ap.add_argument("--no-training", action="store_true", help="skip the extra `training` (esac.backward) figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -232,6 +233,40 @@ def main():
             out["batched"] = {"frames_per_launch": Bf, "launches_timed": nb, "ms_per_batch": tb / nb * 1e3,
                               "value": Bf * n_local * nb / tb, "unit": "hypotheses/s",
                               "note": "esac.forward_batch: frame b == the b-th of B sequential forward calls, bit for bit"}
+        if not args.no_training and world == 1:
+            # extra figure (not `value`): the training path, esac.backward = esac_hip_backward, same workload
+            eng.set_timing(False)
+            gts = [np.asarray(f["gt_pose"], np.float32) for f in frames]
+            grads = torch.zeros_like(d_coords[0])
+            nt = max(5, min(50, args.steps // 8))
+            slots = 0
+            for i in range(3 + nt):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    tt = time.perf_counter()
+                k = i % n_frames
+                grads.zero_()
+                o = eng.backward_device(d_coords[k], grads, d_assign[k][:n_local], gts[k], 1.0, 100.0, 100.0,
+                                        eng.make_params(args.experts, H, W, n_local, seed=1305, call=i, **kw))
+                slots += int(o[1]) if i >= 3 else 0
+            torch.cuda.synchronize()
+            tt = time.perf_counter() - tt
+            out["training"] = {"entry": "esac_hip_backward", "ms_per_call": tt / nt * 1e3, "value": n_local * nt / tt,
+                               "unit": "hypotheses/s", "refined_hypotheses_per_call": slots / nt,
+                               "note": "expected loss + gradient wrt the [E,3,H,W] coordinates, blocking call incl. the zeroing of the gradient tensor"}
+            if not args.no_cpu_baseline:
+                from oracle import esac_oracle as O
+                ts = []
+                for i in range(1 + 5):
+                    f, ha = frames[i % n_frames], assigns[i % n_frames][:n_local]
+                    g_ref = np.zeros_like(f["coords"])
+                    t0 = time.time()
+                    O.backward(f["coords"], g_ref, ha, gts[i % n_frames], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"],
+                               sub_sampling=f["sub"], seed=1305, call=i)
+                    if i >= 1:
+                        ts.append(time.time() - t0)
+                out["training"]["cpu_oracle_ms_per_call"] = float(np.median(ts)) * 1e3
+                out["training"]["cpu_threads"] = O.max_threads()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames, [a[:n_local] for a in assigns], n_local)
         print(json.dumps(out))

@@ -134,3 +134,83 @@ def evaluate(samples, gating, experts, trans_threshold_cm=5.0, rot_threshold_deg
                          median_rot_deg=median(scenes_r[s]), median_trans_cm=median(scenes_t[s])))
     return dict(scenes=rows, avg_active=avg_active / max(n, 1), max_active=max_active, avg_time_s=avg_time / max(n, 1),
                 images=n)
+
+
+# ---------------------------------------------------------------- training glue (train_esac.py:104-200)
+def random_shift(image, max_shift, rng=None):
+    """Zero-pad shift augmentation of util.py:4-11: returns (padX, padY, shifted image)."""
+    import random
+    r = rng if rng is not None else random
+    pad_x = r.randint(-int(max_shift), int(max_shift))
+    pad_y = r.randint(-int(max_shift), int(max_shift))
+    return pad_x, pad_y, torch.nn.functional.pad(image, (pad_x, -pad_x, pad_y, -pad_y))
+
+
+def clamp_probs(probs, n):
+    """Zero all but the n largest entries in place (util.py:38-47); one topk instead of a Python loop over E."""
+    if n < 0 or n >= probs.numel():
+        return
+    keep = torch.zeros_like(probs, dtype=torch.bool)
+    if n > 0:
+        keep[torch.topk(probs, n).indices] = True
+    probs.masked_fill_(~keep, 0)
+
+
+def train_step(image, gt_pose, gating, experts, focal_length, hypotheses=256, threshold=10.0, inlier_alpha=100.0,
+               inlier_beta=0.5, max_reprojection=100.0, subsample=8, weight_rot=1.0, weight_trans=100.0, loss_cut=100.0,
+               max_experts=-1, expert_selection=False, shift=None, generator=None):
+    """One iteration of the end-to-end training loop (train_esac.py:104-192) up to and including
+    `torch.autograd.backward`; the optimiser step stays with the caller (`ensemble.update`, train_esac.py:195).
+
+    Differences from the reference loop, all of them removals of host round trips:
+      * `prediction.cpu()` (train_esac.py:152) and `prediction_gradients.cuda()` (:185) are gone -- the coordinate
+        tensor and its gradient container stay in HBM and `esac.backward` accumulates into the latter in place;
+      * `torch.exp(gating_log_probs).cpu()` (:129) is gone -- clamp / multinomial / histc run on the device, only the
+        E activity flags and the loss value reach the host.
+    gating(image) -> log-probabilities [1,E] (with grad); experts[e](image) -> [1,3,H/s,W/s] (with grad).
+    Returns dict(loss, e_hyps, e_hist, prediction, prediction_gradients, gating_log_probs, pad)."""
+    dev = image.device
+    E = len(experts)
+    pp_x = float(image.size(3) / 2)
+    pp_y = float(image.size(2) / 2)
+    pred_w = math.ceil(image.size(3) / subsample)
+    pred_h = math.ceil(image.size(2) / subsample)
+    if shift is None:
+        pad_x, pad_y, image = random_shift(image, subsample / 2)
+    else:
+        pad_x, pad_y = int(shift[0]), int(shift[1])
+        image = torch.nn.functional.pad(image, (pad_x, -pad_x, pad_y, -pad_y))
+    gating_log_probs = gating(image)
+    with torch.no_grad():
+        gating_probs = torch.exp(gating_log_probs)[0].clone()
+        clamp_probs(gating_probs, max_experts)
+        if expert_selection:
+            expert = torch.multinomial(gating_probs, 1, replacement=True, generator=generator)
+            e_hyps = expert.expand((hypotheses,))
+        else:
+            e_hyps = torch.multinomial(gating_probs, hypotheses, replacement=True, generator=generator)
+        e_hist = torch.histc(e_hyps.float(), bins=E, min=0, max=E - 1)
+        active = (e_hist > 0).cpu().tolist()
+    outputs = [experts[e](image)[0] if on else torch.zeros((3, pred_h, pred_w), device=dev) for e, on in enumerate(active)]
+    prediction = torch.stack(outputs)  # [E,3,h,w]; rows of inactive experts are zeros and never read
+    prediction_gradients = torch.zeros_like(prediction)
+    loss = api.backward(prediction.detach(), prediction_gradients, e_hyps, torch.as_tensor(gt_pose, dtype=torch.float32).cpu(),
+                        weight_rot, weight_trans, loss_cut, pad_x, pad_y, float(focal_length), pp_x, pp_y, threshold,
+                        inlier_alpha, inlier_beta, max_reprojection, subsample)
+    # gating gradients: REINFORCE-style, loss per drawn hypothesis (train_esac.py:171-177)
+    if expert_selection:
+        gating_grads = torch.zeros_like(gating_log_probs)
+        gating_grads[0, int(expert)] = loss
+    else:
+        gating_grads = (loss * e_hist).unsqueeze(0).to(gating_log_probs.dtype)
+    tensors, grads = [], []
+    if prediction.requires_grad:
+        tensors.append(prediction)
+        grads.append(prediction_gradients)
+    if gating_log_probs.requires_grad:
+        tensors.append(gating_log_probs)
+        grads.append(gating_grads)
+    if tensors:
+        torch.autograd.backward(tensors, grads)
+    return dict(loss=loss, e_hyps=e_hyps, e_hist=e_hist, prediction=prediction, prediction_gradients=prediction_gradients,
+                gating_log_probs=gating_log_probs, pad=(pad_x, pad_y))

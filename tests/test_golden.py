@@ -10,7 +10,8 @@ import pytest
 
 from esac_amd import synthetic as S
 
-FIXTURES = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz")))
+FIXTURES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.npz"))
+                  if not os.path.basename(p).startswith("ref_"))  # ref_*.npz: tests/test_ref_golden.py
 
 
 def test_fixtures_exist():

@@ -94,3 +94,91 @@ def test_evaluation_loop_on_device():
     assert one["expert"] == 2 and one["active_experts"] == 1
     r, t = harness.pose_errors_deg_cm(one["pose"].numpy(), f["gt_pose"])
     assert r < 1.0 and t < 3.0
+
+
+# ---------------------------------------------------------------- training glue (train_esac.py:104-200)
+def test_clamp_probs_matches_reference_loop():
+    """util.py:38-47 keeps the n largest entries (sorted ascending, zero the first E-n)."""
+    rng = np.random.default_rng(1)
+    for n in (-1, 0, 1, 3, 7, 10, 12):
+        p = torch.from_numpy(rng.dirichlet(np.ones(10))).float()
+        want = p.clone()
+        if n >= 0:
+            s_prob, s_idx = want.sort(dim=0)
+            for i, idx in enumerate(s_idx):
+                if i < s_prob.size(0) - n:
+                    want[idx] = 0
+        got = p.clone()
+        harness.clamp_probs(got, n)
+        assert torch.equal(got, want)
+
+
+def test_random_shift_is_zero_padding():
+    import random
+    img = torch.arange(2 * 3 * 6 * 8, dtype=torch.float32).reshape(2, 3, 6, 8)
+    px, py, out = harness.random_shift(img, 2, rng=random.Random(3))
+    assert out.shape == img.shape and -2 <= px <= 2 and -2 <= py <= 2
+    ref = torch.nn.ZeroPad2d((px, -px, py, -py))(img)  # util.py:9
+    assert torch.equal(out, ref)
+
+
+class _LearnableExpert(torch.nn.Module):
+    def __init__(self, coords):
+        super().__init__()
+        self.map = torch.nn.Parameter(torch.from_numpy(coords[None].copy()).cuda())
+
+    def forward(self, image):
+        return self.map
+
+
+class _LearnableGating(torch.nn.Module):
+    def __init__(self, E):
+        super().__init__()
+        self.logits = torch.nn.Parameter(torch.tensor([[1.0] + [0.0] * (E - 1)]).cuda())
+
+    def forward(self, image):
+        return torch.log_softmax(self.logits, dim=1)
+
+
+@pytest.mark.gpu
+def test_end_to_end_training_reduces_expected_loss():
+    """train_esac.py's loop on learnable coordinate maps: esac.backward's gradients, pushed through
+    torch.autograd.backward into the parameters, lower the expected pose loss measured on a FIXED hypothesis key."""
+    import esac
+    E = 2
+    f = S.make_frame(400, E=E, true_expert=0, noise=0.05, outlier_frac=0.2)
+    experts = [_LearnableExpert(f["coords"][e]) for e in range(E)]
+    gating = _LearnableGating(E)
+    opt = torch.optim.Adam([e.map for e in experts] + [gating.logits], lr=2e-3)
+    img = torch.zeros(1, 3, 480, 640, device="cuda")
+    gt = f["gt_pose"].astype(np.float32)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+
+    def fixed_key_loss():
+        esac.set_seed(99, 0)
+        pred = torch.stack([e.map[0] for e in experts]).detach()
+        return esac.backward(pred, torch.zeros_like(pred), torch.zeros(128, dtype=torch.int64, device="cuda"),
+                             torch.from_numpy(gt), 1.0, 100.0, 100.0, 0, 0, f["focal"], 320.0, 240.0, 10.0, 100.0, 0.5, 100.0, 8)
+
+    before = fixed_key_loss()
+    esac.set_seed(7, 0)
+    for it in range(40):
+        opt.zero_grad()
+        out = harness.train_step(img, gt, gating, experts, f["focal"], hypotheses=128, shift=(0, 0), generator=gen)
+        assert math.isfinite(out["loss"]) and out["loss"] > 0
+        assert int(out["e_hist"].sum()) == 128
+        active = [e for e in range(E) if out["e_hist"][e] > 0]
+        for e in range(E):
+            has_grad = experts[e].map.grad is not None and float(experts[e].map.grad.abs().max()) > 0
+            assert has_grad == (e in active and float(out["prediction_gradients"][e].abs().max()) > 0)
+        # gating gradient = loss x hypothesis histogram on the log-probabilities (train_esac.py:176)
+        assert gating.logits.grad is not None
+        opt.step()
+    after = fixed_key_loss()
+    assert after < 0.85 * before, (before, after)
+    # --expertselection branch: one expert drawn, stride-0 assignment, loss on that expert's log-probability only
+    opt.zero_grad()
+    out = harness.train_step(img, gt, gating, experts, f["focal"], hypotheses=64, shift=(2, -3), expert_selection=True,
+                             generator=gen)
+    assert out["e_hyps"].stride(0) == 0 and out["pad"] == (2, -3)
+    assert int((out["e_hist"] > 0).sum()) == 1

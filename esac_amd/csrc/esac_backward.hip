@@ -25,7 +25,7 @@
 
 namespace esac {
 
-constexpr int BWD_B = 256;
+constexpr int BWD_B = 512;  // threads per slot in the gradient kernels: 8 wavefronts, 256-VGPR budget each
 
 // ================================================================= K5: softmax + ordered selection
 template <int B>
@@ -213,9 +213,9 @@ __global__ __launch_bounds__(B) void k_bwd_path1(KArgs a) {
                 o2 += dL[p] * (c6[p] * dNdO[2]);
             }
         }
-        g[3 * (size_t)i + 0] = o0;
-        g[3 * (size_t)i + 1] = o1;
-        g[3 * (size_t)i + 2] = o2;
+        g[i] = o0;
+        g[(size_t)P + i] = o1;
+        g[2 * (size_t)P + i] = o2;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -339,9 +339,9 @@ __global__ __launch_bounds__(B) void k_bwd_path2(KArgs a) {
         dRE *= scale;
         double dPdO[3], r6[6];
         dproject_dobj(px, py, X, Y, Z, R, t, a.focal, a.ppx, a.ppy, a.max_reproj, dPdO);
-        g[3 * (size_t)i + 0] = dPdO[0] * dRE;
-        g[3 * (size_t)i + 1] = dPdO[1] * dRE;
-        g[3 * (size_t)i + 2] = dPdO[2] * dRE;
+        g[i] = dPdO[0] * dRE;
+        g[(size_t)P + i] = dPdO[1] * dRE;
+        g[2 * (size_t)P + i] = dPdO[2] * dRE;
         norm_jac_row(R, dRdr, t, cam, X, Y, Z, px, py, a.max_reproj, r6);
 #pragma unroll
         for (int k = 0; k < 6; k++) S[k] += dRE * r6[k];
@@ -355,30 +355,62 @@ __global__ __launch_bounds__(B) void k_bwd_path2(KArgs a) {
         for (int k = 0; k < 6; k++) s += S[k] * s_J[k * 12 + m];
         const int j = m / 3, c = m - 3 * j;
         const int idx = sxy[2 * j + 1] * a.W + sxy[2 * j];
-        g[3 * (size_t)idx + c] += s;
+        g[(size_t)c * P + idx] += s;
     }
 }
 
 // ================================================================= K9: ordered accumulation into the float tensor
+// grid = (tiles of 3P elements, experts).  Wavefront 0 first compacts, in slot order, the slots whose hypothesis
+// belongs to this expert (ballot prefix) together with their probabilities into LDS; then one thread per tensor
+// element walks that list with unconditional, coalesced slab loads (slabs are planar like the tensor), U loads in
+// flight, while the float `+=` chain itself stays in slot order.
 __global__ __launch_bounds__(256) void k_bwd_accumulate(KArgs a) {
+    __shared__ int s_slot[ESAC_BWD_SLOTS_K];
+    __shared__ double s_prob[ESAC_BWD_SLOTS_K];
+    __shared__ int s_count;
     const int P = a.H * a.W;
-    const long long total = (long long)a.E * 3 * P;
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
-    const int e = (int)(o / (3 * P));
-    const int rem = (int)(o - (long long)e * 3 * P);
-    const int c = rem / P, cell = rem - c * P;
+    const int e = blockIdx.y;
     const int n_sel = a.bwd.n_sel[0];
-    float v = a.bwd.out_grad[o];
-    bool touched = false;
-    for (int slot = 0; slot < n_sel; slot++) {
-        const int h = a.bwd.sel[slot];
-        if ((int)a.assign[h] != e) continue;
-        const size_t k = ((size_t)slot * P + cell) * 3 + c;
-        v = (float)((double)v + (a.bwd.probs[h] * a.bwd.grad1[k] + a.bwd.grad2[k]));  // float += double
-        touched = true;
+    if (threadIdx.x < 64) {
+        int count = 0;
+        for (int base = 0; base < n_sel; base += 64) {
+            const int slot = base + (int)threadIdx.x;
+            int h = 0;
+            bool mine = false;
+            if (slot < n_sel) {
+                h = a.bwd.sel[slot];
+                mine = (int)a.assign[h] == e;
+            }
+            const unsigned long long bal = __ballot(mine);
+            if (mine) {
+                const int pos = count + __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+                s_slot[pos] = slot;
+                s_prob[pos] = a.bwd.probs[h];
+            }
+            count += __popcll(bal);
+        }
+        if (threadIdx.x == 0) s_count = count;
     }
-    if (touched) a.bwd.out_grad[o] = v;
+    __syncthreads();
+    const int n = s_count;
+    const int rem = blockIdx.x * blockDim.x + threadIdx.x;  // c * P + cell
+    if (n == 0 || rem >= 3 * P) return;
+    float* o = a.bwd.out_grad + (size_t)e * 3 * P + rem;
+    float v = *o;
+    constexpr int U = 8;
+    for (int base = 0; base < n; base += U) {
+        double t[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int q = base + u < n ? base + u : n - 1;  // clamped: the loads are unconditional
+            const size_t k = (size_t)s_slot[q] * 3 * P + rem;
+            t[u] = s_prob[q] * a.bwd.grad1[k] + a.bwd.grad2[k];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (base + u < n) v = (float)((double)v + t[u]);  // float += double (esac.cpp:501-506)
+    }
+    *o = v;
 }
 
 // ---------------------------------------------------------------- launchers
@@ -393,8 +425,8 @@ void launch_bwd_path2(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_path2<BWD_B>, dim3(slot_grid(a)), dim3(BWD_B), 0, s, a);
 }
 void launch_bwd_accumulate(const KArgs& a, hipStream_t s) {
-    const long long total = (long long)a.E * 3 * a.H * a.W;
-    hipLaunchKernelGGL(k_bwd_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    const int per_expert = 3 * a.H * a.W;
+    hipLaunchKernelGGL(k_bwd_accumulate, dim3((unsigned)((per_expert + 255) / 256), a.E), dim3(256), 0, s, a);
 }
 
 }  // namespace esac

@@ -20,7 +20,7 @@ static_assert(ESAC_RES_SCORE == ESAC_RES_SCORE_K && ESAC_RES_HYP == ESAC_RES_HYP
                   ESAC_RES_REF_STEPS == ESAC_RES_REF_STEPS_K && ESAC_RES_INLIERS == ESAC_RES_INLIERS_K &&
                   ESAC_RES_PROB == ESAC_RES_PROB_K && ESAC_RES_ENTROPY == ESAC_RES_ENTROPY_K &&
                   ESAC_RES_CONTENDERS == ESAC_RES_CONTENDERS_K && ESAC_RES_LM_ITERS == ESAC_RES_LM_ITERS_K &&
-                  ESAC_MAX_REF_STEPS == ESAC_MAX_REF_STEPS_K,
+                  ESAC_MAX_REF_STEPS == ESAC_MAX_REF_STEPS_K && ESAC_BWD_MAX_SLOTS == ESAC_BWD_SLOTS_K,
               "result layout drifted between include/esac_hip.h and esac_kernels.hpp");
 
 static thread_local char g_err[512] = "";
@@ -419,6 +419,7 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
     KArgs a;
     int rc = make_args(c, d_sc, d_assign, p, &a);
     if (rc) return rc;
+    if (p->E > 65535) return fail(-4, "esac_hip_backward: at most 65535 experts (one grid row per expert in the accumulation kernel)");
     if (p->d_hyp_index || p->hyp_offset)
         return fail(-4, "esac_hip_backward: sharded calls are not supported (the expectation needs every hypothesis)");
     const int P = p->H * p->W;

@@ -10,6 +10,7 @@ constexpr int ESAC_RES_SCORE_K = 0, ESAC_RES_HYP_K = 1, ESAC_RES_EXPERT_K = 2, E
               ESAC_RES_POSE_K = 9, ESAC_RES_REF_STEPS_K = 25, ESAC_RES_INLIERS_K = 26, ESAC_RES_PROB_K = 27,
               ESAC_RES_ENTROPY_K = 28, ESAC_RES_CONTENDERS_K = 29, ESAC_RES_LM_ITERS_K = 30;
 constexpr int ESAC_MAX_REF_STEPS_K = 100;
+constexpr int ESAC_BWD_SLOTS_K = 1000;     // = ESAC_BWD_MAX_SLOTS (include/esac_hip.h)
 constexpr int ESAC_REFINE_LDS_CAP = 8192;  // correspondences the refinement kernel stages in LDS (128 KiB of the CU's 160 KiB)
 
 // Training path (esac_hip_backward).  "slot" = position in the ordered list of hypotheses whose selection
@@ -25,8 +26,8 @@ struct BwdArgs {
     uint8_t* maps;        // [cap,2,P] alternating inlier maps of the slot's refinement
     int* map_info;        // [cap,4] accepted buffer (-1: none), inliers of the last accepted step, steps, LM iterations
     void* corr_lists;     // [cap,P] 16-byte correspondences (only for grids above LDS_CAP)
-    double* grad1;        // [cap,P,3] path I: refined pose -> coordinates (unweighted, esac.cpp:375-463)
-    double* grad2;        // [cap,P,3] path II: score -> coordinates (esac_derivative.h:205-330)
+    double* grad1;        // [cap,3,P] path I: refined pose -> coordinates (unweighted, esac.cpp:375-463)
+    double* grad2;        // [cap,3,P] path II: score -> coordinates (esac_derivative.h:205-330)
     double* out;          // [4] expected loss, number of slots, entropy, 0
     float* out_grad;      // [E,3,H,W] accumulated into (+=)
     double gt[16];        // ground-truth camera pose, row-major (double of the float input)

@@ -27,6 +27,7 @@ BUF_HYPS, BUF_SAMPLE_XY, BUF_TRIES, BUF_SCORES, BUF_RESULT = 0, 1, 2, 3, 4
 BUF_INLIER_MAP, BUF_INLIER_COUNTS, BUF_WINNER_ERRS, BUF_EXACT_FLAGS, BUF_CYCLES = 5, 6, 7, 8, 9
 BUF_BWD_PROBS, BUF_BWD_LOSSES, BUF_BWD_REF_HYPS, BUF_BWD_SCORE_GRADS, BUF_BWD_SLOTS, BUF_BWD_SLOT_INFO, BUF_BWD_DLOSS = \
     10, 11, 12, 13, 14, 15, 16
+BUF_BWD_PATH1, BUF_BWD_PATH2 = 17, 18
 MAX_REF_STEPS = 100
 BWD_MAX_SLOTS = 1000
 
@@ -230,6 +231,13 @@ class Engine:
         h = np.ascontiguousarray(hyps, np.float64)
         assert h.ndim == 2 and h.shape[1] == 6
         _check(self.lib.esac_hip_write_hyps(self.ctx, h.ctypes.data_as(C.c_void_p), h.shape[0]), self.lib)
+
+    def read_slabs(self, which, k):
+        """Gradient slabs [k,3,H,W] (float64) of the first k slots of the last backward call (BUF_BWD_PATH1 / _PATH2)."""
+        _, H, W = self._shape
+        out = np.zeros((int(k), 3, H, W), np.float64)
+        _check(self.lib.esac_hip_read(self.ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes), self.lib)
+        return out
 
     def read(self, which):
         N, H, W = self._shape

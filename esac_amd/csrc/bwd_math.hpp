@@ -163,8 +163,8 @@ ESAC_HD void pose_dloss(const double est[6], const double gt[6], double wRot, do
 
 // Inverse of the symmetric positive definite 6x6 J^T J (upper triangle row-major in U21) through LDL^T.
 // The reference takes the SVD pseudo-inverse (esac.cpp:434); the two coincide whenever J^T J has full rank,
-// which any non-degenerate inlier set of >= 4 cells gives.  Returns false on a non-positive pivot (then the
-// caller writes a zero gradient, as the reference's own stability clamp would in that regime).
+// which any non-degenerate inlier set gives.  Returns false when a pivot falls below 1e-7 of its diagonal entry
+// (rank deficient or badly conditioned): the caller then takes pinv_sym6_jacobi, the reference's own route.
 ESAC_HD bool inv_spd6(const double U21[21], double Ainv[36]) {
 #pragma clang fp contract(fast)
     double A[6][6];
@@ -184,7 +184,7 @@ ESAC_HD bool inv_spd6(const double U21[21], double Ainv[36]) {
         double d = A[j][j];
 #pragma unroll
         for (int m = 0; m < j; m++) d -= W[j][m] * L[j][m];
-        if (!(d > 0)) ok = false;
+        if (!(d > 1e-7 * A[j][j])) ok = false;
         Dinv[j] = 1. / d;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
@@ -217,6 +217,81 @@ ESAC_HD bool inv_spd6(const double U21[21], double Ainv[36]) {
         for (int i = 0; i < 6; i++) Ainv[i * 6 + c] = x[i];
     }
     return ok;
+}
+
+// Pseudo-inverse of a symmetric 6x6 the way the reference obtains it (cv::Mat::inv(DECOMP_SVD), esac.cpp:434): eigen-
+// decomposition by cyclic Jacobi rotations, eigenvalues below 2*eps*sum|w| dropped.  Used when inv_spd6 meets a
+// (numerically) rank-deficient or badly conditioned J^T J -- degenerate inlier sets of garbage hypotheses -- where
+// "the inverse" and the pseudo-inverse part ways.  Fully unrolled (static register indices); ~10k flops, rare.
+ESAC_HD void pinv_sym6_jacobi(const double U21[21], double Ainv[36]) {
+    double A[6][6], V[6][6];
+    {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) {
+                A[i][j] = U21[k];
+                A[j][i] = U21[k];
+                k++;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) V[i][j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i + 1; j < 6; j++) off += A[i][j] * A[i][j];
+        if (off == 0) break;
+#pragma unroll
+        for (int p = 0; p < 6; p++)
+#pragma unroll
+            for (int q = p + 1; q < 6; q++) {
+                const double apq = A[p][q];
+                const double theta = (A[q][q] - A[p][p]) / (2 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                if (!(fabs(theta) <= 1.7976931348623157e308)) t = 0;  // apq negligible (theta = inf / nan)
+                if (apq == 0) t = 0;                                   // identity rotation = the reference's `continue`
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    double thresh = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) thresh += fabs(A[i][i]);
+    thresh *= 2 * 2.220446049250313e-16;
+#pragma unroll
+    for (int i = 0; i < 36; i++) Ainv[i] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double w = A[k][k];
+        const double inv = fabs(w) > thresh ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) Ainv[i * 6 + j] += inv != 0.0 ? V[i][k] * V[j][k] / w : 0.0;
+    }
 }
 
 }  // namespace esac

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(B) void k_bwd_path1(KArgs a) {
     }
     block_sum28<21, B>(U, s_part, s_tot);
     double Ainv[36];
-    const bool ok = inv_spd6(U, Ainv);
+    if (!inv_spd6(U, Ainv)) pinv_sym6_jacobi(U, Ainv);  // workgroup-uniform: every lane holds the same sums
     double dL[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) dL[k] = a.bwd.dloss[(size_t)slot * 6 + k];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(B) void k_bwd_path1(KArgs a) {
     vmax = s_max[0];
 #pragma unroll
     for (int w = 1; w < B / 64; w++) vmax = s_max[w] > vmax ? s_max[w] : vmax;
-    if (!ok || vmax > 10) {  // "clamping for stability" (esac.cpp:436-437): the whole pseudo-inverse is dropped
+    if (vmax > 10) {  // "clamping for stability" (esac.cpp:436-437): the whole pseudo-inverse is dropped
         for (int i = threadIdx.x; i < 3 * P; i += B) g[i] = 0;
     }
 }
@@ -419,7 +419,9 @@ static inline int slot_grid(const KArgs& a) { return a.N < a.bwd.cap ? a.N : a.b
 void launch_bwd_select(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bwd_select<1024>, dim3(1), dim3(1024), 0, s, a); }
 void launch_bwd_loss(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bwd_loss<BWD_B>, dim3(1), dim3(BWD_B), 0, s, a); }
 void launch_bwd_path1(const KArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_bwd_path1<BWD_B>, dim3(slot_grid(a)), dim3(BWD_B), 0, s, a);
+    // 4 wavefronts: one per SIMD, so the rare Jacobi pseudo-inverse (~150 live registers on top of the pose state) fits
+    // the 512-register file instead of spilling onto the common path
+    hipLaunchKernelGGL(k_bwd_path1<256>, dim3(slot_grid(a)), dim3(256), 0, s, a);
 }
 void launch_bwd_path2(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_bwd_path2<BWD_B>, dim3(slot_grid(a)), dim3(BWD_B), 0, s, a);

@@ -499,6 +499,18 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
         case ESAC_BUF_BWD_SLOTS: src = c->bws.sel; want = N * sizeof(int32_t); break;
         case ESAC_BUF_BWD_SLOT_INFO: src = c->bws.map_info; want = (size_t)(c->lastN < ESAC_BWD_MAX_SLOTS ? c->lastN : ESAC_BWD_MAX_SLOTS) * 4 * sizeof(int32_t); break;
         case ESAC_BUF_BWD_DLOSS: src = c->bws.dloss; want = (size_t)(c->lastN < ESAC_BWD_MAX_SLOTS ? c->lastN : ESAC_BWD_MAX_SLOTS) * 6 * sizeof(double); break;
+        case ESAC_BUF_BWD_PATH1:
+        case ESAC_BUF_BWD_PATH2: {
+            // [slots,3,P] doubles; the caller asks for the first k slots (k = bytes / (3 P 8))
+            const size_t slab = 3 * P * sizeof(double);
+            const size_t cap = (size_t)(c->lastN < ESAC_BWD_MAX_SLOTS ? c->lastN : ESAC_BWD_MAX_SLOTS);
+            src = which == ESAC_BUF_BWD_PATH1 ? c->bws.grad1 : c->bws.grad2;
+            if (!src || slab == 0) return fail(-6, "esac_hip_read: buffer %d is empty (no backward call has run yet)", which);
+            if (bytes == 0 || bytes % slab || bytes / slab > cap)
+                return fail(-7, "esac_hip_read: buffer %d is read in whole slabs of %zu bytes, at most %zu", which, slab, cap);
+            want = bytes;
+            break;
+        }
         default: return fail(-5, "esac_hip_read: unknown buffer id %d", which);
     }
     if (!src || want == 0) return fail(-6, "esac_hip_read: buffer %d is empty (no call has run yet)", which);

@@ -102,7 +102,9 @@ enum {
     ESAC_BUF_BWD_SLOTS = 14,       /* int32[N]    hypothesis index per slot, first h_out[1] entries valid    */
     ESAC_BUF_BWD_SLOT_INFO = 15,   /* int32[min(N,ESAC_BWD_MAX_SLOTS),4] per slot: accepted map buffer (-1 none),
                                       inliers of the last accepted step, accepted steps, LM iterations        */
-    ESAC_BUF_BWD_DLOSS = 16        /* double[min(N,ESAC_BWD_MAX_SLOTS),6] d loss / d refined pose per slot    */
+    ESAC_BUF_BWD_DLOSS = 16,       /* double[min(N,ESAC_BWD_MAX_SLOTS),6] d loss / d refined pose per slot    */
+    ESAC_BUF_BWD_PATH1 = 17,       /* double[k,3,H,W] gradient slabs of the first k slots, path I (unweighted)  */
+    ESAC_BUF_BWD_PATH2 = 18        /* double[k,3,H,W] the same for path II; k = bytes / (3*H*W*8) <= #slots     */
 };
 
 /* Hypotheses that take part in the training expectation: selection probability >= PROB_THRESH = 0.001

@@ -56,4 +56,5 @@ int probe_norm_jac_row(const double* rvec, const double* t, float focal, float p
     return norm_jac_row(R, dRdr, t, cam, X, Y, Z, px, py, max_reproj, row) ? 1 : 0;
 }
 int probe_inv_spd6(const double* U21, double* Ainv) { return inv_spd6(U21, Ainv) ? 1 : 0; }
+void probe_pinv_sym6(const double* U21, double* Ainv) { pinv_sym6_jacobi(U21, Ainv); }
 }

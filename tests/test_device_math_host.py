@@ -33,6 +33,7 @@ def probe():
     lib.probe_dproject_dobj.argtypes = [f, f, f, f, f, vp, vp, f, f, f, f, vp]
     lib.probe_norm_jac_row.argtypes = [vp, vp, f, f, f, f, f, f, f, f, f, vp]
     lib.probe_inv_spd6.argtypes = [vp, vp]
+    lib.probe_pinv_sym6.argtypes = [vp, vp]
     return lib
 
 
@@ -262,10 +263,21 @@ def test_inv_spd6_equals_reference_pseudo_inverse_on_full_rank(oracle, probe):
         assert probe.probe_inv_spd6(_p(np.ascontiguousarray(A[iu])), _p(out)) == 1
         ref = oracle.pinv_sym6(A)
         np.testing.assert_allclose(out, ref, rtol=1e-8, atol=1e-14)
-    # rank deficient -> reported, the caller then writes a zero gradient
-    J = rng.normal(size=(40, 5))
-    J = np.concatenate([J, J[:, :1]], axis=1)
+    # rank deficient / badly conditioned -> reported; the caller then takes the reference's own route, the Jacobi
+    # pseudo-inverse, which is the oracle's routine operation for operation
+    for trial in range(20):
+        J = rng.normal(size=(40, 5)) * 30
+        J = np.concatenate([J, J[:, :1] * (1 + (1e-9 if trial % 2 else 0) * rng.normal(size=(40, 1)))], axis=1)
+        if trial % 5 == 4:
+            J = rng.normal(size=(4, 6)) * 30  # fewer rows than parameters
+        A = J.T @ J
+        out = np.zeros((6, 6))
+        assert probe.probe_inv_spd6(_p(np.ascontiguousarray(A[iu])), _p(out)) == 0
+        probe.probe_pinv_sym6(_p(np.ascontiguousarray(A[iu])), _p(out))
+        ref = oracle.pinv_sym6(A)
+        np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+    # and on a well-conditioned matrix it is simply the inverse
+    J = rng.normal(size=(40, 6))
     A = J.T @ J
-    out = np.zeros((6, 6))
-    ok = probe.probe_inv_spd6(_p(np.ascontiguousarray(A[iu])), _p(out))
-    assert ok == 0 or np.abs(out).max() > 1e6
+    probe.probe_pinv_sym6(_p(np.ascontiguousarray(A[iu])), _p(out))
+    np.testing.assert_allclose(out @ A, np.eye(6), atol=1e-10)

@@ -273,3 +273,70 @@ def test_backward_finite_difference_with_refinement(engine, oracle):
     (esac.cpp:417-434: only the radial component of each 2-D residual enters), so it cannot match finite
     differences closely; sign and order of magnitude must still agree."""
     _fd_check(engine, oracle, max_ref_steps=-1, rel_bar=3.0)
+
+
+# ---------------------------------------------------------------- edge cases
+def test_backward_single_hypothesis(engine, oracle):
+    """N = 1: probability 1, one slot."""
+    f = S.make_frame(101)
+    ha = S.gating_assignment(f, 1)
+    out, g, ref, g_ref = _run_both(engine, oracle, f, ha, _gt(f, np.random.default_rng(1), noise=0.05), call=0)
+    n_sel, _ = _check(engine, out, g, ref, g_ref, expect_slots=1)
+    assert n_sel == 1 and ref["probs"][0] == 1.0
+
+
+def test_backward_no_hypothesis_reaches_the_threshold(engine, oracle):
+    """N = 2048 with a flat distribution: every p = 1/2048 < PROB_THRESH, nothing is refined, the gradient stays as
+    it was, the loss is the plain mean of the initial hypotheses' losses."""
+    f = S.make_frame(102, H=24, W=32, sub=20)
+    ha = S.gating_assignment(f, 2048)
+    gt = _gt(f, np.random.default_rng(2), noise=0.05)
+    out, g, ref, g_ref = _run_both(engine, oracle, f, ha, gt, call=1, alpha=1e-4)
+    assert int(out[1]) == 0 and (ref["probs"] < 1e-3).all()
+    assert not g.any() and not g_ref.any()
+    assert abs(out[0] - ref["loss"]) <= LOSS_RTOL * abs(ref["loss"])
+    np.testing.assert_allclose(engine.read(api.BUF_BWD_REF_HYPS), ref["init_hyps"], rtol=0, atol=1e-6)
+
+
+def test_backward_more_hypotheses_than_slots_can_exist(engine, oracle):
+    """N = 1500 > 1000: the slot list is bounded by the threshold itself; a moderately flat distribution selects a subset."""
+    f = S.make_frame(103, H=24, W=32, sub=20)
+    ha = S.gating_assignment(f, 1500)
+    gt = _gt(f, np.random.default_rng(3), noise=0.05)
+    out, g, ref, g_ref = _run_both(engine, oracle, f, ha, gt, call=2, alpha=4.0)
+    n_sel, _ = _check(engine, out, g, ref, g_ref, expect_slots=10)
+    assert n_sel < 1000
+
+
+def test_backward_sampling_budget_exhausted(engine, oracle):
+    """A map of pure noise and 3 tries: most hypotheses keep the state of their last try (or the zero pose of a failed
+    solve, esac_util.h:107-111); losses, probabilities and gradients still follow the reference."""
+    f = S.make_frame(104, outlier_frac=1.0)
+    ha = S.gating_assignment(f, 48)
+    gt = _gt(f, np.random.default_rng(4), noise=0.05)
+    out, g, ref, g_ref = _run_both(engine, oracle, f, ha, gt, call=3, alpha=5.0, max_tries=3)
+    assert (engine.read(api.BUF_TRIES) == -1).any()
+    _check(engine, out, g, ref, g_ref)
+
+
+def test_backward_grid_larger_than_the_lds_list(engine, oracle):
+    """P = 100 x 120 = 12000 cells > 8192: the slot refinement keeps its correspondence lists in global memory."""
+    f = S.make_frame(105, H=100, W=120, sub=4)
+    ha = S.gating_assignment(f, 24)
+    gt = _gt(f, np.random.default_rng(5), noise=0.05)
+    out, g, ref, g_ref = _run_both(engine, oracle, f, ha, gt, call=4, alpha=3.0)
+    _check(engine, out, g, ref, g_ref, expect_slots=4)
+
+
+def test_backward_rejects_sharded_calls_and_bad_pointers(engine):
+    f = S.make_frame(106)
+    sc = torch.from_numpy(f["coords"]).cuda()
+    ha = torch.zeros(16, dtype=torch.int64, device="cuda")
+    p = engine.make_params(1, 60, 80, 16, hyp_offset=16)
+    with pytest.raises(RuntimeError, match="sharded"):
+        engine.backward_device(sc, torch.zeros_like(sc), ha, np.eye(4, dtype=np.float32), 1.0, 100.0, 100.0, p)
+    p = engine.make_params(1, 60, 80, 16)
+    with pytest.raises(RuntimeError, match="singular"):
+        engine.backward_device(sc, torch.zeros_like(sc), ha, np.zeros((4, 4), np.float32), 1.0, 100.0, 100.0, p)
+    with pytest.raises(RuntimeError):
+        engine.backward_device(sc, torch.zeros(1, 3, 60, 79, device="cuda"), ha, np.eye(4, dtype=np.float32), 1.0, 100.0, 100.0, p)

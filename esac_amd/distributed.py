@@ -64,25 +64,63 @@ def pick_global(buf, n_total, world):
     return scores, best.copy()
 
 
+_buffers = {}
+
+
+def _exchange_buffer(dev, n_total, world):
+    """Persistent all-reduce payload per (device, N, world): no allocation on the per-frame path."""
+    key = (str(dev), n_total, world)
+    buf = _buffers.get(key)
+    if buf is None:
+        buf = torch.zeros(n_total + world * RES_DOUBLES, dtype=torch.float64, device=dev)
+        _buffers[key] = buf
+    return buf
+
+
+def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, world, buf):
+    """Rank `rank`'s part of the exchange for contiguous-range sharding: zero `buf`, run the forward path on
+    hypotheses [lo, hi) with the kernels writing scores and record into this rank's slots of `buf`."""
+    n_total = int(hyp_assign_full.shape[0])
+    E, _, H, W = scene_coords.shape
+    lo, hi = shard_range(n_total, rank, world)
+    buf.zero_()
+    if hi > lo:
+        dev = engine.device
+        ha_dev = hyp_assign_full if hyp_assign_full.is_cuda else hyp_assign_full.to(dev)
+        if ha_dev.stride(0) != 1:
+            ha_dev = ha_dev.contiguous()  # stride-0 expand() of --expertselection
+        p = engine.make_params(E, H, W, hi - lo, hyp_offset=lo, **params_kw)
+        rec0 = n_total + rank * RES_DOUBLES
+        engine.forward_device(scene_coords, ha_dev[lo:hi], p, scores_out=buf[lo:hi], result_out=buf[rec0:rec0 + RES_DOUBLES],
+                              want_host=False)
+        buf[rec0 + RES_DOUBLES - 1:rec0 + RES_DOUBLES].fill_(1.0)  # "this rank contributed" marker (see pack_local)
+    return buf
+
+
 def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None, policy="range"):
     """Multi-GPU esac_forward: every rank holds `scene_coords` (or at least its experts' maps) and
     the full assignment vector; returns (scores_global [N] f64 device tensor, winning record np[32]).
 
-    `params_kw` are the keyword arguments of Engine.make_params except N / hyp_offset."""
+    `params_kw` are the keyword arguments of Engine.make_params except N / hyp_offset.
+    policy "range": contiguous index ranges -- the kernels write this rank's scores and record straight into its
+    slots of the persistent exchange buffer (hyp_offset keys RNG and tie-breaks), so a call is one memset, the
+    forward launches, the all-reduce and one 1 KB read-back.  policy "expert": shard by expert ownership (index lists)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     ha_full = hyp_assign_full
     n_total = int(ha_full.shape[0])
     E, _, H, W = scene_coords.shape
-    if policy == "range":
-        lo, hi = shard_range(n_total, rank, world)
-        gidx = torch.arange(lo, hi, dtype=torch.int32)
-    elif policy == "expert":
-        gidx = torch.from_numpy(shard_by_expert(ha_full.cpu().numpy(), rank, world))
-    else:
-        raise ValueError(policy)
-    n_local = int(gidx.numel())
     dev = engine.device
+    if policy == "range":
+        # the returned score vector is a view of the persistent buffer: valid until the next call on this device
+        buf = contribute_range(engine, scene_coords, ha_full, params_kw, rank, world, _exchange_buffer(dev, n_total, world))
+        if world > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)  # the one collective of this path
+        return pick_global(buf, n_total, world)
+    if policy != "expert":
+        raise ValueError(policy)
+    gidx = torch.from_numpy(shard_by_expert(ha_full.cpu().numpy(), rank, world))
+    n_local = int(gidx.numel())
     if n_local > 0:
         ha_local = ha_full.to(dev)[gidx.to(dev, torch.long)].contiguous()
         p = engine.make_params(E, H, W, n_local, **params_kw)

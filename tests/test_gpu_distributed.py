@@ -40,3 +40,34 @@ def test_forward_sharded_world1_matches_plain(engine, policy):
         np.testing.assert_array_equal(scores_g.cpu().numpy(), engine.read(api.BUF_SCORES))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_range_contributions_of_several_ranks_on_one_device(engine, world):
+    """The per-rank half of the exchange for every rank of a `world`-rank job, run one after the other on this
+    box's single GPU; summing the buffers is what the all-reduce does.  Winner, pose and the score of every
+    hypothesis the unsharded call scored exactly must equal the unsharded call."""
+    f = S.make_frame(61, E=2, true_expert=1)
+    ha = S.gating_assignment(f, 250, mode="gating")  # 250: ragged shards for world = 3 and 8
+    sc = torch.from_numpy(f["coords"]).cuda()
+    hat = torch.from_numpy(ha).cuda()
+    kw = dict(seed=1305, call=9)
+    n_total = 250
+    total = torch.zeros(n_total + world * D.RES_DOUBLES, dtype=torch.float64, device="cuda")
+    for rank in range(world):
+        buf = torch.empty_like(total)
+        D.contribute_range(engine, sc, hat, kw, rank, world, buf)
+        total += buf
+    scores_g, best = D.pick_global(total, n_total, world)
+    p = engine.make_params(2, 60, 80, n_total, **kw)
+    res = engine.forward_device(sc, hat, p)
+    assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]) and int(best[api.RES_EXPERT]) == int(res[api.RES_EXPERT])
+    np.testing.assert_array_equal(best[api.RES_POSE:api.RES_POSE + 16], res[api.RES_POSE:api.RES_POSE + 16])
+    assert best[api.RES_SCORE] == res[api.RES_SCORE]
+    flags = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
+    full = engine.read(api.BUF_SCORES)
+    got = scores_g.cpu().numpy()
+    # within the margin of the global maximum = within the margin of its shard's maximum: exact on both sides
+    np.testing.assert_array_equal(got[flags], full[flags])
+    # elsewhere a shard may have re-scored exactly what the full call left at its fp32 score
+    np.testing.assert_allclose(got[~flags], full[~flags], rtol=0, atol=2e-3)

@@ -173,7 +173,7 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     a.stats += f * 4;
     a.errs += f * P;
     a.inlier_map += f * 2 * P;
-    a.corr_list = static_cast<char*>(a.corr_list) + f * P * 16;
+    a.corr_list = static_cast<char*>(a.corr_list) + f * (size_t)corr_entries(a.H * a.W) * 16;
     a.inlier_counts += f * (ESAC_MAX_REF_STEPS_K + 1);
     a.result += f * 32;
     a.tstamps = nullptr;  // the span measurement follows frame 0 only

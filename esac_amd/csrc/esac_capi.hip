@@ -142,7 +142,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.inlier_map, (size_t)nP * 2);  // two buffers, see esac_refine.hip
     {
         char* cl = nullptr;
-        rc |= alloc(&cl, (size_t)nP * 16);
+        rc |= alloc(&cl, ((size_t)nP + (size_t)2048 * nB) * 16);  // sum over frames of corr_entries(P) < P + 2048 each
         c->ws.corr_list = cl;
     }
     rc |= alloc(&c->ws.inlier_counts, (size_t)(ESAC_MAX_REF_STEPS + 1) * nB);
@@ -343,7 +343,7 @@ static int ensure_bws(esac_hip_ctx* c, int N, int P) {
     rc |= alloc(&c->bws.map_info, (size_t)ncap * 4);
     if (nlists) {
         char* cl = nullptr;
-        rc |= alloc(&cl, (size_t)ncap * nP * 16);
+        rc |= alloc(&cl, (size_t)ncap * ((size_t)nP + 2048) * 16);  // corr_entries(P) < P + 2048 per slot
         c->bws.corr_lists = cl;
     }
     rc |= alloc(&c->bws.grad1, (size_t)ncap * nP * 3);

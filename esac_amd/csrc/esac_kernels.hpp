@@ -12,6 +12,16 @@ constexpr int ESAC_RES_SCORE_K = 0, ESAC_RES_HYP_K = 1, ESAC_RES_EXPERT_K = 2, E
 constexpr int ESAC_MAX_REF_STEPS_K = 100;
 constexpr int ESAC_BWD_SLOTS_K = 1000;     // = ESAC_BWD_MAX_SLOTS (include/esac_hip.h)
 constexpr int ESAC_REFINE_LDS_CAP = 8192;  // correspondences the refinement kernel stages in LDS (128 KiB of the CU's 160 KiB)
+constexpr int ESAC_REFINE_THREADS = 256;   // 4 wavefronts = one per SIMD of the one CU a refinement occupies
+constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the error pass
+
+// Correspondence list of one refinement: every wavefront owns a region = its share of the cells of each error-pass
+// trip, rounded up to whole trips.  corr_entries(P) is the size of the whole list (>= P, < P + 2048).
+__host__ __device__ inline int corr_region(int P) {
+    constexpr int per_trip = ESAC_REFINE_THREADS * ESAC_ERR_UNROLL;
+    return (P + per_trip - 1) / per_trip * (64 * ESAC_ERR_UNROLL);
+}
+__host__ __device__ inline long long corr_entries(int P) { return (long long)corr_region(P) * (ESAC_REFINE_THREADS / 64); }
 
 // Training path (esac_hip_backward).  "slot" = position in the ordered list of hypotheses whose selection
 // probability reaches PROB_THRESH (esac_derivative.h:33) -- at most 1000 of them exist for any N.
@@ -25,7 +35,7 @@ struct BwdArgs {
     double* dloss;        // [cap,6] d loss / d refined pose
     uint8_t* maps;        // [cap,2,P] alternating inlier maps of the slot's refinement
     int* map_info;        // [cap,4] accepted buffer (-1: none), inliers of the last accepted step, steps, LM iterations
-    void* corr_lists;     // [cap,P] 16-byte correspondences (only for grids above LDS_CAP)
+    void* corr_lists;     // [cap,corr_entries(P)] 16-byte correspondences (only for grids above LDS_CAP)
     double* grad1;        // [cap,3,P] path I: refined pose -> coordinates (unweighted, esac.cpp:375-463)
     double* grad2;        // [cap,3,P] path II: score -> coordinates (esac_derivative.h:205-330)
     double* out;          // [4] expected loss, number of slots, entropy, 0
@@ -61,7 +71,7 @@ struct KArgs {
     double* stats;        // [4] max, sum exp, entropy
     float* errs;          // [P]
     uint8_t* inlier_map;  // [2,P] two alternating buffers; result[31] names the accepted one
-    void* corr_list;      // [P] 16-byte correspondences: refinement fallback when the inliers exceed LDS
+    void* corr_list;      // [corr_entries(P)] 16-byte correspondences: refinement fallback when the grid exceeds LDS
     int* inlier_counts;   // [ESAC_MAX_REF_STEPS_K+1]
     double* result;       // [32]
     long long* cycles;    // [32] shader-cycle counters of the refinement kernel's sections (profiling aid)

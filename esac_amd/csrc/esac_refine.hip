@@ -30,19 +30,13 @@
 
 namespace esac {
 
-#ifndef ESAC_REFINE_B
-#define ESAC_REFINE_B 256
-#endif
-constexpr int REFINE_B = ESAC_REFINE_B;  // default 4 wavefronts = one per SIMD of the one CU this kernel occupies
-constexpr int LDS_CAP = ESAC_REFINE_LDS_CAP;  // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
-#ifndef ESAC_ERR_UNROLL
-#define ESAC_ERR_UNROLL 8
-#endif
+constexpr int REFINE_B = ESAC_REFINE_THREADS;  // 4 wavefronts = one per SIMD of the one CU this kernel occupies
+constexpr int LDS_CAP = ESAC_REFINE_LDS_CAP;   // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
+constexpr int ERR_UNROLL = ESAC_ERR_UNROLL;    // points per lane in flight in the exact error pass
 #ifndef ESAC_LM_NP
 #define ESAC_LM_NP 2
 #endif
-constexpr int ERR_UNROLL = ESAC_ERR_UNROLL;  // points per lane in flight in the exact error pass
-constexpr int LM_NP = ESAC_LM_NP;            // correspondences per lane in flight in an LM pass
+constexpr int LM_NP = ESAC_LM_NP;              // correspondences per lane in flight in an LM pass
 
 // Section cycle counters (clock64 = shader clock), enabled with -DESAC_PROFILE_CYCLES; index:
 // 0 total, 1 argmax, 2 error image + compaction, 3 unused, 4 rodrigues+chain, 5 point loop, 6 block_sum,
@@ -84,11 +78,11 @@ __device__ __forceinline__ double pow10_int(int k) {
 //   a.errs[i]  = min(reprojection error, maxReproj)                (getReproErrs, esac_util.h:292-360);
 //                reference-exact near tau, fp32-accurate (~1e-3 px) elsewhere -- see the screening below
 //   map_out[i] = err < tau                                         (localInlierMap, esac_util.h:401-414)
-//   list[...]  = the inliers, compacted in index order (deterministic), at most `cap`
+//   list[...]  = the inliers, compacted per wavefront: wavefront w owns list[w * corr_region(P) ...], n_wave entries
 // Returns the inlier count (same value in every thread).
 template <int B, bool VEC, typename ListPtr>
 __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __restrict__ mx, int P, const double pose[6],
-                                               const Cam& cam, ListPtr list, int cap, uint8_t* __restrict__ map_out,
+                                               const Cam& cam, ListPtr list, int& n_wave, uint8_t* __restrict__ map_out,
                                                int* s_wcnt, long long* g_cyc) {
     CYC_DECL;
     // VEC: every lane owns G groups of 4 CONSECUTIVE cells per trip (W % 4 == 0: a group never straddles a
@@ -115,7 +109,9 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
     // a lane's groups advance by B*L cells per step: (row, col) kept incrementally, one division in total
     const int stepR = (B * L) / a.W, stepC = B * L - stepR * a.W;
     int row = ((int)threadIdx.x * L) / a.W, col = (int)threadIdx.x * L - row * a.W;
-    int base = 0;
+    const int region = corr_region(P);  // list entries per wavefront
+    const auto wlist = list + (size_t)wave * region;
+    int wcount = 0;
     for (int start = 0; start < P; start += B * U) {
         const bool full = start + B * U <= P;  // wave-uniform: no bounds checks in full trips
         float X[U], Y[U], Z[U], pxf[U], pyf[U], errv[U];
@@ -184,7 +180,6 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
         }
         CYC_END(12);
         CYC_BEGIN();
-        int within[U];
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const bool in_range = full || cell[g] < P;
@@ -205,44 +200,33 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
                 }
             }
         }
+        // wave-local compaction: every wavefront appends to ITS OWN region of the list (ballot prefix, no
+        // cross-wavefront exchange, no barrier); the order (wavefront, trip, sub-step, lane) is fixed -> deterministic
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const unsigned long long m = __ballot(flag[u]);
-            within[u] = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) s_wcnt[u * NW + wave] = __popcll(m);
+            if (flag[u]) {
+                const int slot = wcount + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < region)
+                    wlist[slot] = Corr{X[u], Y[u], Z[u], ((uint32_t)pyi[u] << 16) | ((uint32_t)pxi[u] & 0xffffu)};
+            }
+            wcount += __popcll(m);
         }
         CYC_END(13);
-        CYC_BEGIN();
-        barrier_lds();
-        CYC_END(3);
-        CYC_BEGIN();
-        // deterministic compaction; the order (sub-step, wavefront, lane) is fixed, not the cell order
-        int off = base;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            int woff = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                const int c = s_wcnt[u * NW + w];
-                woff += (w < wave) ? c : 0;
-                total += c;
-            }
-            if (flag[u]) {
-                const int slot = off + woff + within[u];
-                if (slot < cap)
-                    list[slot] = Corr{X[u], Y[u], Z[u], ((uint32_t)pyi[u] << 16) | ((uint32_t)pxi[u] & 0xffffu)};
-            }
-            off += total;
-        }
-        base = off;
-        barrier_lds();
-        CYC_END(14);
     }
+    CYC_BEGIN();
+    if (lane == 0) s_wcnt[wave] = wcount;
+    barrier_lds();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) base += s_wcnt[w];
+    n_wave = wcount < region ? wcount : region;
+    CYC_END(14);
     return base;
 }
 
 // One pass over the compacted correspondences at `param`: residual norm^2 (returned) and the
-// (rvec,tvec)-space normal equations U21 / g6 at that point.
+// (rvec,tvec)-space normal equations U21 / g6 at that point.  `list` / `n`: this wavefront's region and its fill.
 template <int B, typename ListPtr>
 __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double param[6], const Cam& cam, double U21[21],
                                           double g6[6], double* s_part, double* s_tot, long long* g_cyc) {
@@ -250,48 +234,49 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
     CYC_BEGIN();
     double R[9];
     LmChain ch;
-    {
-        double dRdr[27];
-        rodrigues_vec2mat<true>(param, R, dRdr);
-        lm_chain(R, dRdr, param + 3, ch);
-    }
+    lm_pose_chain(param, R, ch);
     CYC_END(4);
     CYC_BEGIN();
-    double acc[LM_NACC];
+    double mom[LM_NMOM];
 #pragma unroll
-    for (int k = 0; k < LM_NACC; k++) acc[k] = 0;
-    // LM_NP correspondences per lane per trip, evaluated stage by stage (lm_accumulate_points)
-    int j = threadIdx.x;
-    for (; j + (LM_NP - 1) * B < n; j += LM_NP * B) {
-        double X[LM_NP], Y[LM_NP], Z[LM_NP], mxp[LM_NP], myp[LM_NP], wgt[LM_NP];
+    for (int k = 0; k < LM_NMOM; k++) mom[k] = 0;
+    // LM_NP correspondences per lane per trip; every wavefront walks the region of the list it filled itself.
+    // Software-pipelined: the terms of trip k+1 (a dependent chain per point) are computed in the same basic block
+    // as the 24 accumulator chains of trip k, so the in-order pipeline always has independent work to issue.
+    const int lane = threadIdx.x & 63;
+    const int trips = (n + LM_NP * 64 - 1) / (LM_NP * 64);
+    auto fetch = [&](int trip, LmTerms<LM_NP>& out) {
+        double X[LM_NP], Y[LM_NP], Z[LM_NP], mxp[LM_NP], myp[LM_NP];
+        bool on[LM_NP];
 #pragma unroll
         for (int p = 0; p < LM_NP; p++) {
-            const Corr c = list[j + p * B];
+            const int jj = (trip * LM_NP + p) * 64 + lane;
+            on[p] = jj < n;
+            const Corr c = list[min(jj, n - 1)];  // clamped, unconditional: no control flow inside the pipelined body
             X[p] = (double)c.x; Y[p] = (double)c.y; Z[p] = (double)c.z;
             mxp[p] = (double)(int)(short)(c.px_py & 0xffffu);
             myp[p] = (double)((int)c.px_py >> 16);
-            wgt[p] = 1.0;
         }
-        lm_accumulate_points<LM_NP, false>(R, param + 3, cam, X, Y, Z, mxp, myp, wgt, acc);
-    }
-    if (j < n) {  // ragged tail: same code with the missing correspondences weighted 0
-        double X[LM_NP], Y[LM_NP], Z[LM_NP], mxp[LM_NP], myp[LM_NP], wgt[LM_NP];
-#pragma unroll
-        for (int p = 0; p < LM_NP; p++) {
-            const int jj = j + p * B;
-            const Corr c = list[jj < n ? jj : j];
-            X[p] = (double)c.x; Y[p] = (double)c.y; Z[p] = (double)c.z;
-            mxp[p] = (double)(int)(short)(c.px_py & 0xffffu);
-            myp[p] = (double)((int)c.px_py >> 16);
-            wgt[p] = jj < n ? 1.0 : 0.0;
+        lm_point_terms<LM_NP>(R, param + 3, cam, X, Y, Z, mxp, myp, on, out);
+    };
+    if (trips > 0) {
+        LmTerms<LM_NP> cur;
+        fetch(0, cur);
+        for (int trip = 1; trip < trips; trip++) {
+            LmTerms<LM_NP> nxt;
+            fetch(trip, nxt);
+            lm_accumulate_moments<LM_NP>(cur, mom);
+            cur = nxt;
         }
-        lm_accumulate_points<LM_NP, true>(R, param + 3, cam, X, Y, Z, mxp, myp, wgt, acc);
+        lm_accumulate_moments<LM_NP>(cur, mom);
     }
     CYC_END(5);
     CYC_BEGIN();
-    block_sum28<LM_NACC, B>(acc, s_part, s_tot);
+    block_sum28<LM_NMOM, B>(mom, s_part, s_tot);
     CYC_END(6);
     CYC_BEGIN();
+    double acc[LM_NACC];
+    lm_moments_to_acc(mom, cam.fx, acc);
     lm_transform(acc, ch, U21, g6);
     CYC_END(7);
     CYC_ADD(9, 1);
@@ -373,7 +358,8 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     __shared__ double s_best[B / 64];
     __shared__ int s_besti[B / 64];
     __shared__ int s_bestg[B / 64];
-    __shared__ int s_wcnt[ERR_UNROLL * (B / 64)];  // per (sub-step, wavefront) inlier counts
+    __shared__ int s_wcnt[B / 64];  // inliers each wavefront put into its region of the list
+    static_assert(B == REFINE_B, "corr_region() assumes the refinement workgroup size");
     frame_view(a);
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
@@ -448,10 +434,11 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
 
     // ---- refineHyp (esac_util.h:378-454): one error-pass site, one re-fit site
     Corr* const list = !GLOBAL_LIST ? s_list
-                       : SLOTS      ? reinterpret_cast<Corr*>(a.bwd.corr_lists) + (size_t)blockIdx.x * P
+                       : SLOTS      ? reinterpret_cast<Corr*>(a.bwd.corr_lists) + (size_t)blockIdx.x * corr_entries(P)
                                     : reinterpret_cast<Corr*>(a.corr_list);
     uint8_t* const maps = SLOTS ? a.bwd.maps + (size_t)blockIdx.x * 2 * P : a.inlier_map;
-    const int cap = GLOBAL_LIST ? P : LDS_CAP;
+    const Corr* const my_list = list + (size_t)wave * corr_region(P);  // the region this wavefront fills and reads
+    int n_wave = 0;
     int accepted = 0, last_inliers = 0, lm_total = 0, map_buf = -1;
     int cur = 0;  // map buffer the next error pass writes
     unsigned best_inliers = 4;
@@ -460,14 +447,14 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         // this step's inlier set and its compacted correspondence list
         CYC_BEGIN();
         __syncthreads();  // every lane is done reading the list before it is rebuilt
-        const int n_inl = error_pass_impl<B, VEC>(a, mx, P, pose, cam, list, cap, maps + (size_t)cur * P, s_wcnt, g_cyc);
+        const int n_inl = error_pass_impl<B, VEC>(a, mx, P, pose, cam, list, n_wave, maps + (size_t)cur * P, s_wcnt, g_cyc);
         __syncthreads();
         CYC_END(2);
         if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
         if (!SLOTS && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
         if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
         best_inliers = (unsigned)n_inl;
-        lm_total += lm_refit<B>((const Corr*)list, n_inl, pose, cam, s_part, s_tot, g_cyc);
+        lm_total += lm_refit<B>(my_list, n_wave, pose, cam, s_part, s_tot, g_cyc);
         accepted++;
         last_inliers = n_inl;
         map_buf = cur;  // inlierMap = this step's set (esac_util.h:440)

@@ -70,13 +70,28 @@ ESAC_HD void lm_accumulate_point(const double R[9], const double t[3], const Cam
     acc[26] += ex * ex + ey * ey;
 }
 
-// NP correspondences at once, stage by stage, so that their independent fp64 chains are adjacent
-// in the (in-order) instruction stream; per element the same arithmetic as lm_accumulate_point<true>.
-// MASKED: wgt[p] in {0,1} switches correspondence p off (ragged tail of the list).
-template <int NP, bool MASKED>
-ESAC_HD void lm_accumulate_points(const double R[9], const double t[3], const Cam& cam, const double (&X)[NP],
-                                  const double (&Y)[NP], const double (&Z)[NP], const double (&mx)[NP],
-                                  const double (&my)[NP], const double (&wgt)[NP], double* acc) {
+// ---- the per-correspondence work of an LM pass, as kernels use it ------------------------------------------------
+// With fx == fy == f (the only camera this path ever builds, esac.cpp:93-97) the twist Jacobian rows are
+//     u: f (-xy, 1+x^2, -y | iz, 0, -iz x)      v: f (-(1+y^2), xy, x | 0, iz, -iz y)
+// (x, y = normalised image coordinates, iz = 1/Zc), and the 20 normal-matrix sums of lm_accumulate_point collapse to
+// sums of MONOMIALS in (x, y, iz) -- several of them to plain sums (sum a2*a0 + b2*b0 = -f^2 sum x, one entry is
+// identically zero): 24 moments, 31 fused ops per correspondence instead of 42, and the ten Jacobian entries are
+// never formed.  lm_moments_to_acc() maps the reduced moments back to the accumulator layout above.
+// (Zc*iz is taken as exactly 1; the reference's `z ? 1/z : 1` guard differs only at Zc == 0.0 exactly.)
+constexpr int LM_NMOM = 24;
+
+// Stage 1 -- projection: a DEPENDENT chain per correspondence (transform, Newton reciprocal, residual).
+// on[p] == false switches correspondence p off (ragged tail of the list) through a 0/1 WEIGHT the optimiser cannot see
+// through: a plain select lets it sink the whole chain under a branch, which splits the software-pipelined loop body.
+template <int NP>
+struct LmTerms {
+    double x[NP], y[NP], iz[NP], ex[NP], ey[NP], w[NP];
+};
+
+template <int NP>
+ESAC_HD void lm_point_terms(const double R[9], const double t[3], const Cam& cam, const double (&X)[NP],
+                            const double (&Y)[NP], const double (&Z)[NP], const double (&mx)[NP],
+                            const double (&my)[NP], const bool (&on)[NP], LmTerms<NP>& o) {
 #pragma clang fp contract(fast)
     double Xc[NP], Yc[NP], Zc[NP], iz[NP];
 #pragma unroll
@@ -103,75 +118,94 @@ ESAC_HD void lm_accumulate_points(const double R[9], const double t[3], const Ca
 #pragma unroll
     for (int p = 0; p < NP; p++) iz[p] = Zc[p] ? 1.0 / Zc[p] : 1;
 #endif
-    double x[NP], y[NP], ex[NP], ey[NP], zz[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        x[p] = Xc[p] * iz[p];
-        y[p] = Yc[p] * iz[p];
-        zz[p] = Zc[p] * iz[p];
-    }
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        ex[p] = (x[p] * cam.fx + cam.cx) - mx[p];
-        ey[p] = (y[p] * cam.fy + cam.cy) - my[p];
-    }
-    double a0[NP], a1[NP], a2[NP], a3[NP], a5[NP], b0[NP], b1[NP], b2[NP], b4[NP], b5[NP];
-#pragma unroll
-    for (int p = 0; p < NP; p++) {
-        a3[p] = cam.fx * iz[p];
-        b4[p] = cam.fy * iz[p];
-        a0[p] = -cam.fx * x[p] * y[p];
-        a1[p] = cam.fx * (zz[p] + x[p] * x[p]);
-        a2[p] = -cam.fx * y[p];
-        b0[p] = -cam.fy * (zz[p] + y[p] * y[p]);
-        b1[p] = cam.fy * x[p] * y[p];
-        b2[p] = cam.fy * x[p];
+        o.w[p] = on[p] ? 1.0 : 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(o.w[p]));
+#endif
+        o.iz[p] = iz[p] * o.w[p];  // iz = 0 makes x, y and every moment below vanish for a switched-off point
     }
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        a5[p] = -a3[p] * x[p];
-        b5[p] = -b4[p] * y[p];
+        o.x[p] = Xc[p] * o.iz[p];
+        o.y[p] = Yc[p] * o.iz[p];
     }
-    if (MASKED) {  // every accumulated term is a product of two of these, so scaling them by 0 removes the point
-#pragma unroll
-        for (int p = 0; p < NP; p++) {
-            a0[p] *= wgt[p]; a1[p] *= wgt[p]; a2[p] *= wgt[p]; a3[p] *= wgt[p]; a5[p] *= wgt[p];
-            b0[p] *= wgt[p]; b1[p] *= wgt[p]; b2[p] *= wgt[p]; b4[p] *= wgt[p]; b5[p] *= wgt[p];
-            ex[p] *= wgt[p]; ey[p] *= wgt[p];
-        }
-    }
-    // 27 independent accumulator chains; the NP contributions of one accumulator are dependent, so
-    // iterate accumulators in the inner position
 #pragma unroll
     for (int p = 0; p < NP; p++) {
-        acc[0] += a0[p] * a0[p] + b0[p] * b0[p];
-        acc[1] += a0[p] * a1[p] + b0[p] * b1[p];
-        acc[2] += a0[p] * a2[p] + b0[p] * b2[p];
-        acc[3] += a0[p] * a3[p];
-        acc[4] += b0[p] * b4[p];
-        acc[5] += a0[p] * a5[p] + b0[p] * b5[p];
-        acc[6] += a1[p] * a1[p] + b1[p] * b1[p];
-        acc[7] += a1[p] * a2[p] + b1[p] * b2[p];
-        acc[8] += a1[p] * a3[p];
-        acc[9] += b1[p] * b4[p];
-        acc[10] += a1[p] * a5[p] + b1[p] * b5[p];
-        acc[11] += a2[p] * a2[p] + b2[p] * b2[p];
-        acc[12] += a2[p] * a3[p];
-        acc[13] += b2[p] * b4[p];
-        acc[14] += a2[p] * a5[p] + b2[p] * b5[p];
-        acc[15] += a3[p] * a3[p];
-        acc[16] += a3[p] * a5[p];
-        acc[17] += b4[p] * b4[p];
-        acc[18] += b4[p] * b5[p];
-        acc[19] += a5[p] * a5[p] + b5[p] * b5[p];
-        acc[20] += a0[p] * ex[p] + b0[p] * ey[p];
-        acc[21] += a1[p] * ex[p] + b1[p] * ey[p];
-        acc[22] += a2[p] * ex[p] + b2[p] * ey[p];
-        acc[23] += a3[p] * ex[p];
-        acc[24] += b4[p] * ey[p];
-        acc[25] += a5[p] * ex[p] + b5[p] * ey[p];
-        acc[26] += ex[p] * ex[p] + ey[p] * ey[p];
+        o.ex[p] = ((o.x[p] * cam.fx + cam.cx) - mx[p]) * o.w[p];
+        o.ey[p] = ((o.y[p] * cam.fx + cam.cy) - my[p]) * o.w[p];
     }
+}
+
+// Stage 2 -- 24 independent accumulator chains (FMA / add INTO the accumulator; the NP contributions of one
+// accumulator are dependent, so accumulators sit in the inner position).
+template <int NP>
+ESAC_HD void lm_accumulate_moments(const LmTerms<NP>& q, double* m) {
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+        const double x = q.x[p], y = q.y[p], iz = q.iz[p], ex = q.ex[p], ey = q.ey[p], w = q.w[p];
+        const double xx = x * x, yy = y * y, xy = x * y;
+        const double r2 = xx + yy, ox = 1.0 + xx, oy = 1.0 + yy, qq = 1.0 + r2, q1 = 1.0 + qq;
+        const double p1 = x * iz, p2 = y * iz, iz2 = iz * iz;
+        const double oxw = ox * w, oyw = oy * w;
+        m[0] += x;
+        m[1] += y;
+        m[2] += r2;
+        m[3] += iz2;
+        m[4] = __builtin_fma(iz2, x, m[4]);
+        m[5] = __builtin_fma(iz2, y, m[5]);
+        m[6] = __builtin_fma(iz2, r2, m[6]);
+        m[7] += p1;
+        m[8] += p2;
+        m[9] = __builtin_fma(xy, iz, m[9]);
+        m[10] = __builtin_fma(oy, iz, m[10]);
+        m[11] = __builtin_fma(ox, iz, m[11]);
+        m[12] = __builtin_fma(p2, qq, m[12]);
+        m[13] = __builtin_fma(p1, qq, m[13]);
+        m[14] = __builtin_fma(xy, q1, m[14]);
+        m[15] = __builtin_fma(xy, xy, __builtin_fma(oyw, oy, m[15]));
+        m[16] = __builtin_fma(xy, xy, __builtin_fma(oxw, ox, m[16]));
+        m[17] = __builtin_fma(xy, ex, __builtin_fma(oy, ey, m[17]));
+        m[18] = __builtin_fma(ox, ex, __builtin_fma(xy, ey, m[18]));
+        m[19] = __builtin_fma(x, ey, __builtin_fma(-y, ex, m[19]));
+        m[20] = __builtin_fma(iz, ex, m[20]);
+        m[21] = __builtin_fma(iz, ey, m[21]);
+        m[22] = __builtin_fma(p1, ex, __builtin_fma(p2, ey, m[22]));
+        m[23] = __builtin_fma(ex, ex, __builtin_fma(ey, ey, m[23]));
+    }
+}
+
+// reduced moments -> the accumulator layout of lm_accumulate_point (f = focal length)
+ESAC_HD void lm_moments_to_acc(const double m[LM_NMOM], double f, double acc[LM_NACC]) {
+    const double f2 = f * f;
+    acc[0] = f2 * m[15];
+    acc[1] = -f2 * m[14];
+    acc[2] = -f2 * m[0];
+    acc[3] = -f2 * m[9];
+    acc[4] = -f2 * m[10];
+    acc[5] = f2 * m[12];
+    acc[6] = f2 * m[16];
+    acc[7] = -f2 * m[1];
+    acc[8] = f2 * m[11];
+    acc[9] = f2 * m[9];
+    acc[10] = -f2 * m[13];
+    acc[11] = f2 * m[2];
+    acc[12] = -f2 * m[8];
+    acc[13] = f2 * m[7];
+    acc[14] = 0.0;
+    acc[15] = f2 * m[3];
+    acc[16] = -f2 * m[4];
+    acc[17] = f2 * m[3];
+    acc[18] = -f2 * m[5];
+    acc[19] = f2 * m[6];
+    acc[20] = -f * m[17];
+    acc[21] = f * m[18];
+    acc[22] = f * m[19];
+    acc[23] = f * m[20];
+    acc[24] = f * m[21];
+    acc[25] = -f * m[22];
+    acc[26] = m[23];
 }
 
 // twist-space sums -> (rvec,tvec)-space normal equations.  U21: upper triangle row-major, g6.
@@ -191,6 +225,58 @@ ESAC_HD void lm_chain(const double R[9], const double dRdr[27], const double t[3
         Mw[1][j] = D[0] * R[6] + D[1] * R[7] + D[2] * R[8];  // S[0][2]
         Mw[2][j] = D[3] * R[0] + D[4] * R[1] + D[5] * R[2];  // S[1][0]
     }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {  // K[:,j] = t x Mw[:,j]
+        K[0][j] = t[1] * Mw[2][j] - t[2] * Mw[1][j];
+        K[1][j] = t[2] * Mw[0][j] - t[0] * Mw[2][j];
+        K[2][j] = t[0] * Mw[1][j] - t[1] * Mw[0][j];
+    }
+}
+
+// R(rvec) and the chain-rule matrices in closed form, without dR/drvec:  Mw_j = vee(dR/dr_j R^T) is column j of the
+// LEFT Jacobian of SO(3),   J_l(r) = (s/th) I + (1 - s/th) n n^T + ((1-c)/th) [n]x,   n = r/th
+// (same matrices as lm_chain(rodrigues_vec2mat<true>) to rounding, ~40 flops instead of ~400 on the per-pass
+// dependent chain every lane walks before it can touch its first correspondence).
+ESAC_HD void lm_pose_chain(const double param[6], double R[9], LmChain& ch) {
+#pragma clang fp contract(fast)
+    double (&Mw)[3][3] = ch.Mw;
+    double (&K)[3][3] = ch.K;
+    double rx = param[0], ry = param[1], rz = param[2];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < DBL_EPSILON) {
+        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) Mw[i][j] = (i == j) ? 1.0 : 0.0;
+    } else {
+        double c, s;
+#if defined(__HIP_DEVICE_COMPILE__)
+        sincos(theta, &s, &c);  // one argument reduction for both (this chain is serial in every lane)
+#else
+        c = cos(theta);
+        s = sin(theta);
+#endif
+        const double c1 = 1. - c;
+        const double itheta = 1. / theta;
+        rx *= itheta; ry *= itheta; rz *= itheta;
+        const double xx = rx * rx, xy = rx * ry, xz = rx * rz, yy = ry * ry, yz = ry * rz, zz = rz * rz;
+        R[0] = c + c1 * xx;      R[1] = c1 * xy - s * rz; R[2] = c1 * xz + s * ry;
+        R[3] = c1 * xy + s * rz; R[4] = c + c1 * yy;      R[5] = c1 * yz - s * rx;
+        R[6] = c1 * xz - s * ry; R[7] = c1 * yz + s * rx; R[8] = c + c1 * zz;
+        // s/th, (1-c)/th, 1 - s/th; below 1e-2 rad the differences cancel (error ~1e-16/th), their series are exact
+        // to rounding there (next term th^8/9! < 1e-21)
+        const bool tiny = theta < 1e-2;
+        const double t2 = theta * theta;
+        const double sb_ser = t2 * (1. / 6. - t2 * (1. / 120. - t2 * (1. / 5040.)));
+        const double sa = tiny ? 1. - sb_ser : s * itheta;
+        const double ca = tiny ? theta * (0.5 - t2 * (1. / 24. - t2 * (1. / 720. - t2 * (1. / 40320.)))) : c1 * itheta;
+        const double sb = tiny ? sb_ser : 1. - sa;
+        Mw[0][0] = sa + sb * xx;      Mw[0][1] = sb * xy - ca * rz; Mw[0][2] = sb * xz + ca * ry;
+        Mw[1][0] = sb * xy + ca * rz; Mw[1][1] = sa + sb * yy;      Mw[1][2] = sb * yz - ca * rx;
+        Mw[2][0] = sb * xz - ca * ry; Mw[2][1] = sb * yz + ca * rx; Mw[2][2] = sa + sb * zz;
+    }
+    const double* t = param + 3;
 #pragma unroll
     for (int j = 0; j < 3; j++) {  // K[:,j] = t x Mw[:,j]
         K[0][j] = t[1] * Mw[2][j] - t[2] * Mw[1][j];

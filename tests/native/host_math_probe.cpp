@@ -39,6 +39,52 @@ void probe_lm_normal(const float* obj, const float* img, int n, const double* po
     lm_to_rvec_space(acc, R, dRdr, pose + 3, U21, g6);
     *e2 = acc[26];
 }
+// the same normal equations through the kernels' own route: closed-form chain + monomial moments (fx == fy)
+void probe_lm_normal_moments(const float* obj, const float* img, int n, const double* pose, double f, double cx, double cy,
+                             double* U21, double* g6, double* e2) {
+    Cam cam{f, f, cx, cy};
+    double R[9], mom[LM_NMOM], acc[LM_NACC];
+    LmChain ch;
+    lm_pose_chain(pose, R, ch);
+    for (int k = 0; k < LM_NMOM; k++) mom[k] = 0;
+    for (int i = 0; i < n; i += 2) {  // pairs, the second one switched off past the end: exercises the 0/1 weight
+        double X[2], Y[2], Z[2], mx[2], my[2];
+        bool on[2];
+        for (int p = 0; p < 2; p++) {
+            const int j = i + p < n ? i + p : i;
+            on[p] = i + p < n;
+            X[p] = obj[3*j]; Y[p] = obj[3*j+1]; Z[p] = obj[3*j+2]; mx[p] = img[2*j]; my[p] = img[2*j+1];
+        }
+        LmTerms<2> t;
+        lm_point_terms<2>(R, pose + 3, cam, X, Y, Z, mx, my, on, t);
+        lm_accumulate_moments<2>(t, mom);
+    }
+    lm_moments_to_acc(mom, f, acc);
+    lm_transform(acc, ch, U21, g6);
+    *e2 = acc[26];
+}
+// closed-form chain (lm_pose_chain) vs the chain built from dR/drvec (lm_chain): max |difference| over R, Mw, K
+double probe_chain_diff(const double* pose) {
+    double R1[9], dRdr[27], R2[9];
+    LmChain a, b;
+    rodrigues_vec2mat<true>(pose, R1, dRdr);
+    lm_chain(R1, dRdr, pose + 3, a);
+    lm_pose_chain(pose, R2, b);
+    double d = 0;
+    for (int k = 0; k < 9; k++) d = fmax(d, fabs(R1[k] - R2[k]));
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            d = fmax(d, fabs(a.Mw[i][j] - b.Mw[i][j]));
+            d = fmax(d, fabs(a.K[i][j] - b.K[i][j]) / (1.0 + fabs(a.K[i][j])));
+        }
+    return d;
+}
+void probe_pose_chain(const double* pose, double* R, double* Mw, double* K) {
+    LmChain ch;
+    lm_pose_chain(pose, R, ch);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) { Mw[3 * i + j] = ch.Mw[i][j]; K[3 * i + j] = ch.K[i][j]; }
+}
 // ---- training-path routines (bwd_math.hpp)
 double probe_pose_loss(const double* pose, const double* gt16, double wR, double wT, double cut) { return pose_loss(pose, gt16, wR, wT, cut); }
 void probe_pose_dloss(const double* est, const double* gt6, double wR, double wT, double cut, double* jac) { pose_dloss(est, gt6, wR, wT, cut, jac); }

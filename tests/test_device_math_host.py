@@ -26,6 +26,7 @@ def probe():
     lib.probe_exact_err.restype = C.c_float
     lib.probe_lm_solve6.argtypes = [vp, vp, d, vp]
     lib.probe_lm_normal.argtypes = [vp, vp, C.c_int, vp, d, d, d, d, vp, vp, vp]
+    lib.probe_lm_normal_moments.argtypes = [vp, vp, C.c_int, vp, d, d, d, vp, vp, vp]
     f = C.c_float
     lib.probe_pose_loss.argtypes = [vp, vp, d, d, d]
     lib.probe_pose_loss.restype = d
@@ -34,6 +35,9 @@ def probe():
     lib.probe_norm_jac_row.argtypes = [vp, vp, f, f, f, f, f, f, f, f, f, vp]
     lib.probe_inv_spd6.argtypes = [vp, vp]
     lib.probe_pinv_sym6.argtypes = [vp, vp]
+    lib.probe_chain_diff.argtypes = [vp]
+    lib.probe_chain_diff.restype = d
+    lib.probe_pose_chain.argtypes = [vp, vp, vp, vp]
     return lib
 
 
@@ -157,6 +161,16 @@ def test_lm_normal_equations_match_numeric_jacobian(oracle, probe):
         assert np.abs(Um - JtJ).max() / np.abs(JtJ).max() < 1e-8
         assert np.abs(g - J.T @ r0).max() / np.abs(J.T @ r0).max() < 1e-8
         assert abs(e2[0] - r0 @ r0) < 1e-9 * (r0 @ r0)
+        # the route the kernels take (closed-form chain, monomial moments, software-pipelined pairs with a 0/1 weight
+        # on the ragged tail) gives the same normal equations as the entry-by-entry accumulation, for odd n too
+        for nn in (n, n - 1, 1):
+            U1, g1, e1 = np.zeros(21), np.zeros(6), np.zeros(1)
+            U2, g2, e2b = np.zeros(21), np.zeros(6), np.zeros(1)
+            probe.probe_lm_normal(_p(obj), _p(img), nn, _p(pose), FX, FY, CX, CY, _p(U1), _p(g1), _p(e1))
+            probe.probe_lm_normal_moments(_p(obj), _p(img), nn, _p(pose), FX, CX, CY, _p(U2), _p(g2), _p(e2b))
+            np.testing.assert_allclose(U2, U1, rtol=0, atol=1e-11 * np.abs(U1).max())
+            np.testing.assert_allclose(g2, g1, rtol=0, atol=1e-11 * np.abs(g1).max())
+            assert abs(e2b[0] - e1[0]) <= 1e-12 * e1[0]
         # damped solve == numpy
         for lam in (1e-3, 1.0):
             dx = np.zeros(6)
@@ -281,3 +295,33 @@ def test_inv_spd6_equals_reference_pseudo_inverse_on_full_rank(oracle, probe):
     A = J.T @ J
     probe.probe_pinv_sym6(_p(np.ascontiguousarray(A[iu])), _p(out))
     np.testing.assert_allclose(out @ A, np.eye(6), atol=1e-10)
+
+
+def test_closed_form_lm_chain_equals_the_rodrigues_jacobian_chain(probe):
+    """lm_pose_chain (left Jacobian of SO(3) in closed form) == lm_chain(dR/drvec): same R, Mw, K -- to rounding for
+    ordinary rotations (up to beyond pi); for tiny rotations, where 1 - cos(theta) cancels in the Rodrigues-Jacobian
+    route, the closed form is checked against the power series of the left Jacobian instead."""
+    rng = np.random.default_rng(21)
+    for scale, bar in ((2e-2, 1e-11), (0.5, 1e-13), (3.0, 1e-13), (3.2, 1e-13)):
+        worst = 0.0
+        for it in range(400):
+            pose = np.concatenate([rng.normal(size=3) * scale, rng.normal(size=3) * 3.0])
+            worst = max(worst, probe.probe_chain_diff(_p(pose)))
+        assert worst < bar, (scale, worst)
+    assert probe.probe_chain_diff(_p(np.array([0, 0, 0, 1.0, -2.0, 0.5]))) == 0.0
+
+    def skew(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0.0]])
+    for scale in (1e-12, 1e-9, 1e-6, 1e-4, 3e-3, 6e-3, 1e-2):
+        for it in range(50):
+            pose = np.concatenate([rng.normal(size=3) * scale, rng.normal(size=3) * 3.0])
+            R, Mw, K = np.zeros(9), np.zeros(9), np.zeros(9)
+            probe.probe_pose_chain(_p(pose), _p(R), _p(Mw), _p(K))
+            S1 = skew(pose[:3])
+            S2 = S1 @ S1
+            th2 = float(pose[:3] @ pose[:3])
+            # series of the left Jacobian: I + (1-cos)/th^2 [r]x + (th-sin)/th^3 [r]x^2
+            Jl = (np.eye(3) + (0.5 - th2 / 24 + th2 ** 2 / 720 - th2 ** 3 / 40320) * S1
+                  + (1 / 6 - th2 / 120 + th2 ** 2 / 5040 - th2 ** 3 / 362880) * S2)
+            np.testing.assert_allclose(Mw.reshape(3, 3), Jl, rtol=0, atol=2e-14)
+            np.testing.assert_allclose(K.reshape(3, 3), skew(pose[3:]) @ Jl, rtol=0, atol=5e-13)

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "esac_hip_abi_version", "esac_hip_last_error", "esac_hip_device_count", "esac_hip_create", "esac_hip_destroy",
     "esac_hip_forward", "esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine",
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
-    "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward",
+    "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug",
 ]
 
 
@@ -86,6 +86,7 @@ def load_library():
         lib.esac_hip_write_hyps.argtypes = [vp, vp, i32]
         lib.esac_hip_phase_ms.argtypes = [vp, vp]
         lib.esac_hip_set_timing.argtypes = [vp, i32]
+        lib.esac_hip_set_debug.argtypes = [vp, i32]
         lib.esac_hip_score_span_ms.argtypes = [vp, vp, vp]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
@@ -255,6 +256,9 @@ class Engine:
         out = np.zeros(shape, dt)
         _check(self.lib.esac_hip_read(self.ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes), self.lib)
         return out
+
+    def set_debug(self, keep_error_image=False):
+        _check(self.lib.esac_hip_set_debug(self.ctx, 1 if keep_error_image else 0), self.lib)
 
     def set_timing(self, on):
         _check(self.lib.esac_hip_set_timing(self.ctx, 1 if on else 0), self.lib)

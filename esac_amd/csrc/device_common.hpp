@@ -171,7 +171,7 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     a.contenders += f * N;
     a.n_contenders += f * 4;
     a.stats += f * 4;
-    a.errs += f * P;
+    if (a.errs) a.errs += f * P;
     a.inlier_map += f * 2 * P;
     a.corr_list = static_cast<char*>(a.corr_list) + f * (size_t)corr_entries(a.H * a.W) * 16;
     a.inlier_counts += f * (ESAC_MAX_REF_STEPS_K + 1);

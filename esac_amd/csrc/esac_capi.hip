@@ -44,6 +44,7 @@ struct esac_hip_ctx {
     KArgs ws{};  // only the workspace pointers are kept here
     int lastN = 0, lastH = 0, lastW = 0;
     bool timing = false;
+    bool keep_errs = false;  // esac_hip_set_debug: store the winner's error image
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     double* h_pin = nullptr;  // pinned, device-visible host buffer: result record [32] + epoch word
@@ -194,6 +195,7 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     a.hyp_offset = p->hyp_offset;
     a.hyp_index = p->d_hyp_index;
     if (!c->timing) a.tstamps = nullptr;  // device-side span stamps only in timing mode
+    if (!c->keep_errs) a.errs = nullptr;
     a.margin = p->rescore_margin > 0 ? p->rescore_margin : fabsf(p->inlier_alpha) * ESAC_DEFAULT_MARGIN;
     c->lastN = p->N; c->lastH = p->H; c->lastW = p->W;
     *out = a;
@@ -489,7 +491,9 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
             return 0;
         }
         case ESAC_BUF_INLIER_COUNTS: src = c->ws.inlier_counts; want = (ESAC_MAX_REF_STEPS + 1) * sizeof(int32_t); break;
-        case ESAC_BUF_WINNER_ERRS: src = c->ws.errs; want = P * sizeof(float); break;
+        case ESAC_BUF_WINNER_ERRS:
+            if (!c->keep_errs) return fail(-6, "esac_hip_read: the error image is only kept after esac_hip_set_debug(ctx, ESAC_DEBUG_ERROR_IMAGE)");
+            src = c->ws.errs; want = P * sizeof(float); break;
         case ESAC_BUF_EXACT_FLAGS: src = c->ws.exact_flag; want = N; break;
         case ESAC_BUF_CYCLES: src = c->ws.cycles; want = 32 * sizeof(long long); break;
         case ESAC_BUF_BWD_PROBS: src = c->bws.probs; want = N * sizeof(double); break;
@@ -532,6 +536,12 @@ extern "C" int esac_hip_write_hyps(esac_hip_ctx* c, const double* h_hyps, int N)
     if ((rc = check_launch("k_hyps_to_rt32"))) return rc;
     HIP_OK(hipDeviceSynchronize());
     c->lastN = N;
+    return 0;
+}
+
+extern "C" int esac_hip_set_debug(esac_hip_ctx* c, int flags) {
+    if (!c) return fail(-1, "null context");
+    c->keep_errs = (flags & ESAC_DEBUG_ERROR_IMAGE) != 0;
     return 0;
 }
 

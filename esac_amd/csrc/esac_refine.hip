@@ -76,7 +76,8 @@ __device__ __forceinline__ double pow10_int(int k) {
 
 // Fused pass over the whole grid at `pose`:
 //   a.errs[i]  = min(reprojection error, maxReproj)                (getReproErrs, esac_util.h:292-360);
-//                reference-exact near tau, fp32-accurate (~1e-3 px) elsewhere -- see the screening below
+//                reference-exact near tau, fp32-accurate (~1e-3 px) elsewhere -- see the screening below;
+//                only stored when the caller asked for it (esac_hip_set_debug), nothing downstream reads it
 //   map_out[i] = err < tau                                         (localInlierMap, esac_util.h:401-414)
 //   list[...]  = the inliers, compacted per wavefront: wavefront w owns list[w * corr_region(P) ...], n_wave entries
 // Returns the inlier count (same value in every thread).
@@ -191,11 +192,12 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
             }
             if (in_range) {
                 if (VEC) {
-                    *reinterpret_cast<float4*>(a.errs + cell[g]) = make_float4(errv[4 * g], errv[4 * g + 1], errv[4 * g + 2], errv[4 * g + 3]);
+                    if (a.errs)  // debug option: the error image itself is nobody's input
+                        *reinterpret_cast<float4*>(a.errs + cell[g]) = make_float4(errv[4 * g], errv[4 * g + 1], errv[4 * g + 2], errv[4 * g + 3]);
                     *reinterpret_cast<uint32_t*>(map_out + cell[g]) = (flag[4 * g] ? 1u : 0u) | (flag[4 * g + 1] ? 0x100u : 0u) |
                                                                         (flag[4 * g + 2] ? 0x10000u : 0u) | (flag[4 * g + 3] ? 0x1000000u : 0u);
                 } else {
-                    a.errs[cell[g]] = errv[g];
+                    if (a.errs) a.errs[cell[g]] = errv[g];
                     map_out[cell[g]] = flag[g] ? 1 : 0;
                 }
             }

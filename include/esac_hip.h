@@ -203,6 +203,10 @@ int esac_hip_phase_ms(esac_hip_ctx* ctx, float out[6]);
 int esac_hip_score_span_ms(esac_hip_ctx* ctx, float* mean_ms, int* launches);
 /* enable/disable the per-phase events (off by default: zero overhead) */
 int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
+/* debug options (off by default). ESAC_DEBUG_ERROR_IMAGE: the refinement also stores the reprojection-error image of
+ * the pose it is refining (ESAC_BUF_WINNER_ERRS); nothing downstream needs it, so the stores are skipped otherwise. */
+#define ESAC_DEBUG_ERROR_IMAGE 1
+int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
 
 #ifdef __cplusplus
 }

@@ -191,3 +191,29 @@ def test_batched_forward_equals_sequential_calls(engine):
     r1 = engine.forward_device(coords[0], ha[1], q)
     np.testing.assert_array_equal(poses[1].numpy().reshape(-1), r1[api.RES_POSE:api.RES_POSE + 16].astype(np.float32))
     assert experts[1] == int(r1[api.RES_EXPERT]) and esac.get_rng_state() == (1305, 43)
+
+
+def test_debug_error_image_option(engine, oracle):
+    """ESAC_BUF_WINNER_ERRS is only kept on request (esac_hip_set_debug); when kept it is the reprojection-error image
+    of the refined pose (the last error pass of refineHyp, esac_util.h:445-452)."""
+    f = S.make_frame(70)
+    ha = S.gating_assignment(f, 64)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    p = engine.make_params(1, 60, 80, 64, seed=3, call=1)
+    engine.set_debug(keep_error_image=False)
+    engine.forward_device(sc, hat, p)
+    with pytest.raises(RuntimeError, match="esac_hip_set_debug"):
+        engine.read(api.BUF_WINNER_ERRS)
+    engine.set_debug(keep_error_image=True)
+    try:
+        res = engine.forward_device(sc, hat, p)
+        errs = engine.read(api.BUF_WINNER_ERRS)
+    finally:
+        engine.set_debug(keep_error_image=False)
+    pose = res[api.RES_RVEC:api.RES_RVEC + 6]
+    pts = f["coords"][0].reshape(3, -1).T.copy()
+    uv = oracle.project(pose[:3], pose[3:], f["focal"], f["focal"], f["ppx"], f["ppy"], pts).reshape(60, 80, 2)
+    ys, xs = np.mgrid[0:60, 0:80]
+    want = np.minimum(np.hypot(xs * 8 + 4 - uv[..., 0], ys * 8 + 4 - uv[..., 1]), 100.0)
+    np.testing.assert_allclose(errs, want, rtol=0, atol=2e-2)  # fp32-accurate away from tau
+    np.testing.assert_array_equal(errs < 10.0, want < 10.0 - 0)  # the inlier side is decided exactly

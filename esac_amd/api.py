@@ -116,6 +116,15 @@ class Engine:
         _check(self.lib.esac_hip_create(C.byref(self.ctx), self.device.index), self.lib)
         self._shape = None
 
+    def _call(self, fn, *args):
+        """One C-ABI call with this engine's device current (the library calls hipSetDevice itself; the context
+        manager is only needed -- and only paid for -- when torch's current device is another one)."""
+        if torch.cuda.current_device() == self.device.index:
+            _check(fn(self.ctx, *args), self.lib)
+        else:
+            with torch.cuda.device(self.device):
+                _check(fn(self.ctx, *args), self.lib)
+
     def __del__(self):
         try:
             if getattr(self, "ctx", None):
@@ -161,12 +170,10 @@ class Engine:
         """scene_coords [E,3,H,W] f32 / hyp_assign [N] i64 on this device. Returns host result (np.float64[32]) or None."""
         sc, ha = self._dev_inputs(scene_coords, hyp_assign)
         host = np.zeros(RES_DOUBLES, np.float64) if want_host else None
-        with torch.cuda.device(self.device):
-            _check(self.lib.esac_hip_forward(
-                self.ctx, sc.data_ptr(), ha.data_ptr(), C.byref(params), self._stream(),
-                scores_out.data_ptr() if scores_out is not None else None,
-                result_out.data_ptr() if result_out is not None else None,
-                host.ctypes.data_as(C.c_void_p) if want_host else None), self.lib)
+        self._call(self.lib.esac_hip_forward, sc.data_ptr(), ha.data_ptr(), C.byref(params), self._stream(),
+                   scores_out.data_ptr() if scores_out is not None else None,
+                   result_out.data_ptr() if result_out is not None else None,
+                   host.ctypes.data if want_host else None)
         self._keep = (sc, ha)  # keep inputs alive until the (possibly asynchronous) kernels have run
         return host
 
@@ -179,12 +186,10 @@ class Engine:
         B = int(ha.shape[0])
         stride = int(sc.stride(0)) if sc.dim() == 5 else 0
         host = np.zeros((B, RES_DOUBLES), np.float64) if want_host else None
-        with torch.cuda.device(self.device):
-            _check(self.lib.esac_hip_forward_batch(
-                self.ctx, B, sc.data_ptr(), stride, ha.data_ptr(), C.byref(params), self._stream(),
-                scores_out.data_ptr() if scores_out is not None else None,
-                result_out.data_ptr() if result_out is not None else None,
-                host.ctypes.data_as(C.c_void_p) if want_host else None), self.lib)
+        self._call(self.lib.esac_hip_forward_batch, B, sc.data_ptr(), stride, ha.data_ptr(), C.byref(params), self._stream(),
+                   scores_out.data_ptr() if scores_out is not None else None,
+                   result_out.data_ptr() if result_out is not None else None,
+                   host.ctypes.data if want_host else None)
         self._keep = (sc, ha)
         return host
 
@@ -260,8 +265,9 @@ class Engine:
     def set_debug(self, keep_error_image=False):
         _check(self.lib.esac_hip_set_debug(self.ctx, 1 if keep_error_image else 0), self.lib)
 
-    def set_timing(self, on):
-        _check(self.lib.esac_hip_set_timing(self.ctx, 1 if on else 0), self.lib)
+    def set_timing(self, on, period=1):
+        """Per-phase events on every `period`-th forward call (the next call is the first sampled one)."""
+        _check(self.lib.esac_hip_set_timing(self.ctx, (max(1, int(period)) if on else 0)), self.lib)
 
     def phase_ms(self):
         out = np.zeros(6, np.float32)

@@ -44,6 +44,8 @@ struct esac_hip_ctx {
     KArgs ws{};  // only the workspace pointers are kept here
     int lastN = 0, lastH = 0, lastW = 0;
     bool timing = false;
+    int timing_period = 1;       // record the phase events / device-side stamps on every timing_period-th forward call
+    long long timing_calls = 0;  // forward calls since timing was enabled
     bool keep_errs = false;  // esac_hip_set_debug: store the winner's error image
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
@@ -194,7 +196,7 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
                                             : ESAC_MAX_REF_STEPS;
     a.hyp_offset = p->hyp_offset;
     a.hyp_index = p->d_hyp_index;
-    if (!c->timing) a.tstamps = nullptr;  // device-side span stamps only in timing mode
+    // (device-side span stamps only on sampled calls in timing mode: forward_impl clears tstamps otherwise)
     if (!c->keep_errs) a.errs = nullptr;
     a.margin = p->rescore_margin > 0 ? p->rescore_margin : fabsf(p->inlier_alpha) * ESAC_DEFAULT_MARGIN;
     c->lastN = p->N; c->lastH = p->H; c->lastW = p->W;
@@ -258,7 +260,9 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     a.result_pin = h_result_out ? c->d_pin : nullptr;
     c->epoch += 1.0;
     a.epoch = c->epoch;
-    const bool tm = c->timing;
+    // events and stamps cost GPU time themselves (an empty event pair reads ~5 us): sample every timing_period-th call
+    const bool tm = c->timing && (c->timing_calls++ % c->timing_period) == 0;
+    if (!tm) a.tstamps = nullptr;
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
     launch_sample(a, s);
     if ((rc = check_launch("k_sample"))) return rc;
@@ -548,6 +552,8 @@ extern "C" int esac_hip_set_debug(esac_hip_ctx* c, int flags) {
 extern "C" int esac_hip_set_timing(esac_hip_ctx* c, int enabled) {
     if (!c) return fail(-1, "null context");
     c->timing = enabled != 0;
+    c->timing_period = enabled > 1 ? enabled : 1;
+    c->timing_calls = 0;
     c->ev_valid = false;
     if (c->ws.span_acc) {
         HIP_OK(hipSetDevice(c->device));

@@ -201,7 +201,8 @@ int esac_hip_phase_ms(esac_hip_ctx* ctx, float out[6]);
  * rocprofv3's kernel trace reports (hipEvents around one ~3 us launch also contain the launch gap).
  * Synchronises the device. */
 int esac_hip_score_span_ms(esac_hip_ctx* ctx, float* mean_ms, int* launches);
-/* enable/disable the per-phase events (off by default: zero overhead) */
+/* enable/disable the per-phase events (off by default: zero overhead).  enabled = k > 1 samples every k-th forward
+ * call only, starting with the next one (the events themselves cost GPU time: an empty pair reads ~5 us). */
 int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
 /* debug options (off by default). ESAC_DEBUG_ERROR_IMAGE: the refinement also stores the reprojection-error image of
  * the pose it is refining (ESAC_BUF_WINNER_ERRS); nothing downstream needs it, so the stores are skipped otherwise. */

@@ -228,10 +228,8 @@ extern "C" int esac_hip_select(esac_hip_ctx* c, const float* d_sc, const int64_t
     KArgs a;
     int rc = make_args(c, d_sc, d_assign, p, &a);
     if (rc) return rc;
-    launch_select(a, (hipStream_t)stream);
-    if ((rc = check_launch("k_select"))) return rc;
-    launch_rescore(a, 0, (hipStream_t)stream);
-    return check_launch("k_rescore");
+    launch_select_rescore(a, (hipStream_t)stream);
+    return check_launch("k_select_rescore");
 }
 extern "C" int esac_hip_refine(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
     KArgs a;
@@ -244,7 +242,7 @@ extern "C" int esac_hip_score_exact(esac_hip_ctx* c, const float* d_sc, const in
     KArgs a;
     int rc = make_args(c, d_sc, d_assign, p, &a);
     if (rc) return rc;
-    launch_rescore(a, 1, (hipStream_t)stream);
+    launch_rescore_all(a, (hipStream_t)stream);
     return check_launch("k_rescore(all)");
 }
 
@@ -270,10 +268,8 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     launch_score_fast(a, s);
     if ((rc = check_launch("k_score_fast"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[2], s));
-    launch_select(a, s);
-    if ((rc = check_launch("k_select"))) return rc;
-    launch_rescore(a, 0, s);
-    if ((rc = check_launch("k_rescore"))) return rc;
+    launch_select_rescore(a, s);
+    if ((rc = check_launch("k_select_rescore"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
     launch_refine(a, s);
     if ((rc = check_launch("k_refine"))) return rc;
@@ -447,7 +443,7 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
     hipStream_t s = (hipStream_t)stream;
     launch_sample(a, s);                                        // esac.cpp:276
     if ((rc = check_launch("k_sample"))) return rc;
-    launch_rescore(a, 1, s);                                    // esac.cpp:295-316, reference arithmetic for every hypothesis
+    launch_rescore_all(a, s);                                   // esac.cpp:295-316, reference arithmetic for every hypothesis
     if ((rc = check_launch("k_rescore(all)"))) return rc;
     launch_bwd_select(a, s);                                    // esac.cpp:319-331
     if ((rc = check_launch("k_bwd_select"))) return rc;

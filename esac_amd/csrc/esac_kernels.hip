@@ -3,8 +3,9 @@
 // Reference path: code/esac/esac.cpp:64-190 (esac_forward).  Phases -> kernels:
 //   K1 k_sample        sampleHypotheses + safeSolvePnP(P3P)        esac_util.h:129-225
 //   K2 k_score_fast    getReproErrs + getHypScores, fused, fp32    esac.cpp:131-147, esac_util.h:235-363
-//   K3 k_select        softMax / entropy / argmax band             esac_util.h:461-530
-//   K3b k_rescore      reference-arithmetic (fp64) re-score of the contenders
+//   K3 k_select_rescore  softMax / entropy / argmax band + reference-arithmetic (fp64) re-score of the
+//                        contenders in the same launch                esac_util.h:461-530
+//   K3b k_rescore      reference-arithmetic score of every hypothesis (training path)
 //   K4 k_refine        draw(argmax) + refineHyp + pose2trans       esac_util.h:378-454,505-548
 //
 // Mapping to CDNA4: K1 = one hypothesis per 64-lane wavefront, lane l evaluates
@@ -35,9 +36,13 @@ namespace esac {
 // SAMPLE_B = tries evaluated per round.  A single call wants latency (256 tries = 4 wavefronts per hypothesis:
 // nearly every hypothesis is accepted in round one, the other CUs are idle anyway); thousands of hypotheses
 // in flight (many experts, batched frames) want throughput (64 tries = one wavefront, no wasted solves).
-template <int SAMPLE_B>
+// QUAD: four lanes per try, lane q evaluates the candidate of quartic root q (lengths + alignment + 4th-point error,
+// the long part of the solver) and the four agree on the winner through shuffles -- the dependent chain of a try is
+// one candidate long instead of up to four.  Used for the single-frame launch, where latency is everything.
+template <int SAMPLE_B, bool QUAD>
 __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     __shared__ int s_first[2][SAMPLE_B / 64];
+    constexpr int TRIES = QUAD ? SAMPLE_B / 4 : SAMPLE_B;  // tries per round
     frame_view(a);
     const int h = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -50,8 +55,10 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     const double tau = (double)a.tau;
 
     int parity = 0;
-    for (int base = 0; base < a.max_tries; base += SAMPLE_B, parity ^= 1) {
-        const int t = base + (int)threadIdx.x;
+    for (int base = 0; base < a.max_tries; base += TRIES, parity ^= 1) {
+        const int t = base + (QUAD ? (int)threadIdx.x >> 2 : (int)threadIdx.x);
+        const int root = threadIdx.x & 3;  // QUAD only
+        bool holder = !QUAD;               // the lane that carries the try's final state (pose or zero pose)
         const bool active = t < a.max_tries;
         int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
         double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
@@ -73,7 +80,33 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
                 mv[j] = (double)cell_py(a, cy[j]);
             }
             double Rp[9], Tp[3];
-            const bool solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp);
+            bool solved;
+            if (QUAD) {
+                P3PSetup S;
+                const bool ok = p3p_setup(Pt, mu, mv, cam, S);
+                const double x = root == 0 ? S.x[0] : root == 1 ? S.x[1] : root == 2 ? S.x[2] : S.x[3];
+                double reproj = 0;
+                const bool valid = ok && root < S.n && p3p_candidate(S, x, Pt, mu[3], mv[3], cam, Rp, Tp, reproj);
+                // every lane replays the sequential scan over the four candidates (same `>` rule, same NaN behaviour)
+                const int quad0 = lane & ~3;
+                bool have = false;
+                double min_reproj = 0;
+                int win = -1;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool vi = __shfl((int)valid, quad0 + i) != 0;
+                    const double ri = __shfl(reproj, quad0 + i);
+                    if (vi && (!have || min_reproj > ri)) {
+                        have = true;
+                        min_reproj = ri;
+                        win = i;
+                    }
+                }
+                solved = have && win == root;
+                holder = solved || (!have && root == 0);
+            } else {
+                solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp);
+            }
             if (solved) {
                 // the reference stores (rvec, tvec) and re-expands it when projecting (esac_util.h:202)
                 rodrigues_mat2vec(Rp, rvec);
@@ -101,12 +134,15 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
         }
         // lowest accepted try of the round = the try the reference's sequential loop stops at
         const unsigned long long m = __ballot(accepted);
-        if (lane == 0) s_first[parity][wave] = m ? base + wave * 64 + (__ffsll((long long)m) - 1) : 0x7fffffff;
+        if (lane == 0) {
+            const int first_lane = __ffsll((long long)m) - 1;
+            s_first[parity][wave] = m ? base + (QUAD ? wave * 16 + (first_lane >> 2) : wave * 64 + first_lane) : 0x7fffffff;
+        }
         __syncthreads();
         int first = s_first[parity][0];
 #pragma unroll
         for (int w = 1; w < SAMPLE_B / 64; w++) first = min(first, s_first[parity][w]);
-        const bool last_round = base + SAMPLE_B >= a.max_tries;
+        const bool last_round = base + TRIES >= a.max_tries;
         int writer = -1, tries_val = -1;
         if (first != 0x7fffffff) {
             writer = first;
@@ -115,7 +151,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             writer = a.max_tries - 1;  // budget exhausted: state of the last try remains
         }
         if (writer >= 0) {
-            if (t == writer) {
+            if (t == writer && holder) {
                 double* hp = a.hyps + (size_t)h * 6;
                 hp[0] = rvec[0]; hp[1] = rvec[1]; hp[2] = rvec[2];
                 hp[3] = T[0]; hp[4] = T[1]; hp[5] = T[2];
@@ -232,46 +268,82 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
     }
 }
 
-// ================================================================= K3: select (band of contenders)
+// ================================================================= K3: select + exact re-score of the contenders
+// softMax / entropy statistics (esac_util.h:461-497) from the fp32-path scores, the band of contenders
+// `score >= max - margin`, and the reference-arithmetic re-score of every contender -- ONE launch:
+// every workgroup finds the fp32 maximum itself (N floats, trivial), then walks its strided share of the
+// hypotheses; a contender is re-scored by the whole workgroup, anything else keeps its fp32 score.  Workgroup 0
+// also reduces the statistics.  (One launch gap and one tiny kernel less on the single-frame critical path.)
 template <int B>
-__global__ __launch_bounds__(B) void k_select(KArgs a) {
+__global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
     __shared__ double s_part[3 * (B / 64)];
     __shared__ double s_tot[3];
     __shared__ float s_max[B / 64];
-    __shared__ int s_count;
     frame_view(a);
+    const int P = a.H * a.W;
+    const Cam cam = make_cam(a);
     // max (NaN-ignoring)
     float m = -INFINITY;
     for (int i = threadIdx.x; i < a.N; i += B) m = fmaxf(m, a.fast_scores[i]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
-    if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
     m = s_max[0];
 #pragma unroll
     for (int k = 1; k < B / 64; k++) m = fmaxf(m, s_max[k]);
     const float band = m - a.margin;
-    // softmax statistics (esac_util.h:461-497) from the fp32-path scores, in double
+
+    for (int h = blockIdx.x; h < a.N; h += gridDim.x) {
+        const float fs = a.fast_scores[h];  // workgroup-uniform
+        if (!(fs >= band)) {
+            if (threadIdx.x == 0) {
+                a.scores[h] = (double)fs;
+                if (a.scores_user) a.scores_user[h] = (double)fs;
+                a.exact_flag[h] = 0;
+            }
+            continue;
+        }
+        const int e = (int)a.assign[h];
+        const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
+        const double* hp = a.hyps + (size_t)h * 6;
+        const double rv[3] = {hp[0], hp[1], hp[2]};
+        const double t[3] = {hp[3], hp[4], hp[5]};
+        double R[9];
+        rodrigues_vec2mat<false>(rv, R, nullptr);
+        double acc[1] = {0};
+        for (int i = threadIdx.x; i < P; i += B) {
+            const int row = i / a.W, col = i - row * a.W;
+            float err = project_exact_err(R, t, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
+            err = err < a.max_reproj ? err : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+            acc[0] += soft_inlier_exact(err, a.tau, a.beta);
+        }
+        block_sum<1, B>(acc, s_part, s_tot);
+        if (threadIdx.x == 0) {
+            const float scale = a.alpha / a.W / a.H;
+            double s = acc[0];
+            s *= scale;  // double *= float
+            a.scores[h] = s;
+            if (a.scores_user) a.scores_user[h] = s;
+            a.exact_flag[h] = 1;
+        }
+        __syncthreads();
+    }
+    if (blockIdx.x != 0) return;
+
+    // softmax statistics (esac_util.h:461-497) from the fp32-path scores, in double; number of contenders
     double acc[3] = {0, 0, 0};
     for (int i = threadIdx.x; i < a.N; i += B) {
         const float s = a.fast_scores[i];
-        a.scores[i] = (double)s;
-        if (a.scores_user) a.scores_user[i] = (double)s;
-        a.exact_flag[i] = 0;
         const double d = (double)s - (double)m;
         const double ex = exp(d);
         acc[0] += ex;
         acc[1] += ex * d;
-        if (s >= band) {
-            const int slot = atomicAdd(&s_count, 1);
-            a.contenders[slot] = i;
-        }
+        acc[2] += (s >= band) ? 1.0 : 0.0;
     }
     block_sum<3, B>(acc, s_part, s_tot);
     if (threadIdx.x == 0) {
-        const int n = s_count;
-        a.n_contenders[0] = n;
+        a.n_contenders[0] = (int)acc[2];
         a.stats[0] = (double)m;  // max
         a.stats[1] = acc[0];     // sum exp(s - max)
         // entropy = -sum p log2 p,  p = exp(d)/S  ->  log2(S) - (sum exp(d) d) / (S ln 2)
@@ -307,17 +379,18 @@ __global__ __launch_bounds__(B) void k_select(KArgs a) {
     }
 }
 
-// ================================================================= K3b: exact re-score
+// ================================================================= K3b: exact score of EVERY hypothesis
+// (training path esac.cpp:295-316, esac_hip_score_exact)
 template <int B>
-__global__ __launch_bounds__(B) void k_rescore(KArgs a, int all) {
+__global__ __launch_bounds__(B) void k_rescore(KArgs a) {
     __shared__ double s_part[B / 64];
     __shared__ double s_tot[1];
     frame_view(a);
-    const int n = all ? a.N : a.n_contenders[0];
+    const int n = a.N;
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
-        const int h = all ? c : a.contenders[c];
+        const int h = c;
         const int e = (int)a.assign[h];
         const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
         const double* hp = a.hyps + (size_t)h * 6;
@@ -348,12 +421,12 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a, int all) {
 // ---------------------------------------------------------------- launchers
 void launch_sample(const KArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.frames;
-    if (total <= 1024)
-        hipLaunchKernelGGL(k_sample<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
+    if (total <= 1024)  // latency: 64 tries per round, the candidates of a try on four lanes
+        hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, a);
     else if (total <= 4096)
-        hipLaunchKernelGGL(k_sample<128>, dim3(a.N, a.frames), dim3(128), 0, s, a);
+        hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, a);
     else
-        hipLaunchKernelGGL(k_sample<64>, dim3(a.N, a.frames), dim3(64), 0, s, a);
+        hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, a);
 }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hyps_to_rt32, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
@@ -364,14 +437,16 @@ void launch_score_fast(const KArgs& a, hipStream_t s) {
     if ((long long)a.N * a.frames <= 2048) hipLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, a);
     else               hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
 }
-void launch_select(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_select<1024>, dim3(1, a.frames), dim3(1024), 0, s, a); }
-void launch_rescore(const KArgs& a, int all, hipStream_t s) {
-    const int grid = all ? (a.N < 4096 ? a.N : 4096) : (a.N < 256 ? a.N : 256);
-    // few contenders, latency matters: 16 wavefronts per hypothesis; bulk exact scoring: 4 are enough
-    if (all)
-        hipLaunchKernelGGL(k_rescore<256>, dim3(grid, a.frames), dim3(256), 0, s, a, all);
-    else
-        hipLaunchKernelGGL(k_rescore<1024>, dim3(grid, a.frames), dim3(1024), 0, s, a, all);
+void launch_select_rescore(const KArgs& a, hipStream_t s) {
+    // few contenders, latency matters: 16 wavefronts per workgroup; a single frame spreads its hypotheses over up to
+    // 256 workgroups (a contender gets a CU to itself), batched frames over 16 each (the frames fill the chip)
+    const int cap = a.frames > 1 ? 16 : 256;
+    const int grid = a.N < cap ? a.N : cap;
+    hipLaunchKernelGGL(k_select_rescore<1024>, dim3(grid, a.frames), dim3(1024), 0, s, a);
+}
+void launch_rescore_all(const KArgs& a, hipStream_t s) {
+    const int grid = a.N < 4096 ? a.N : 4096;  // bulk exact scoring: 4 wavefronts per hypothesis are enough
+    hipLaunchKernelGGL(k_rescore<256>, dim3(grid, a.frames), dim3(256), 0, s, a);
 }
 
 }  // namespace esac

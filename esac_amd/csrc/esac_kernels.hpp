@@ -66,8 +66,8 @@ struct KArgs {
     float* fast_scores;   // [N]
     double* scores;       // [N]
     uint8_t* exact_flag;  // [N]
-    int* contenders;      // [N]
-    int* n_contenders;    // [1]
+    int* contenders;      // [N] (unused since the select and re-score launches were fused; kept for layout stability)
+    int* n_contenders;    // [1] hypotheses inside the band of the fp32 maximum
     double* stats;        // [4] max, sum exp, entropy
     float* errs;          // [P]
     uint8_t* inlier_map;  // [2,P] two alternating buffers; result[31] names the accepted one
@@ -91,8 +91,8 @@ struct KArgs {
 void launch_sample(const KArgs& a, hipStream_t s);
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s);
 void launch_score_fast(const KArgs& a, hipStream_t s);
-void launch_select(const KArgs& a, hipStream_t s);
-void launch_rescore(const KArgs& a, int all, hipStream_t s);
+void launch_select_rescore(const KArgs& a, hipStream_t s);
+void launch_rescore_all(const KArgs& a, hipStream_t s);
 void launch_refine(const KArgs& a, hipStream_t s);
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);

@@ -380,8 +380,8 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const int nc = SLOTS ? 0 : a.n_contenders[0];
     double bs = -INFINITY;
     int bi = 0x7fffffff, bg = 0x7fffffff;
-    for (int c = threadIdx.x; c < nc; c += B) {
-        const int h = a.contenders[c];
+    for (int h = threadIdx.x; h < (SLOTS ? 0 : a.N); h += B) {
+        if (!a.exact_flag[h]) continue;  // contenders = the hypotheses that were re-scored exactly
         const int g = global_hyp(a, h);
         const double s = a.scores[h];
         if (s > bs || (s == bs && g < bg)) {

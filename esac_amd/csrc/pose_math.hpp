@@ -376,20 +376,31 @@ ESAC_HD void align_triangles(V3 P0, V3 P1, V3 P2, V3 Q0, V3 Q1, V3 Q2, double R[
 
 // 4-point P3P (Gao, Hou, Tang, Cheng, PAMI 2003; main branch): up to four poses
 // from points 0..2, the one with the smallest reprojection error of point 3 wins.
-// obj: 4 scene points, img: 4 pixel positions.  Returns false when there is no solution.
-ESAC_HD bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4], const Cam& cam,
-                                        double Rbest[9], double Tbest[3]) {
-    const double inv_fx = 1. / cam.fx, inv_fy = 1. / cam.fy, cx_fx = cam.cx / cam.fx, cy_fy = cam.cy / cam.fy;
+// Split in two so that the (up to four) candidates can be evaluated by different lanes: p3p_setup = everything up to
+// the real roots of the quartic, p3p_candidate(i) = lengths + alignment + 4th-point error of root i.  p3p_4pt runs
+// them in sequence; both routes execute the same operations per candidate, so they agree bit for bit.
+struct P3PSetup {
     double mu[3], mv[3], mk[3];
+    double dist2, a, b, p, q, r;
+    double a2, b2, p2, q2, r2, pqr, ab, a_2, a_4, r3, pr2, r3q, inv_b0;
+    double x[4];
+    int n;
+};
+
+ESAC_HD bool p3p_setup(const V3 P[4], const double mu_px[4], const double mv_px[4], const Cam& cam, P3PSetup& S) {
+    const double inv_fx = 1. / cam.fx, inv_fy = 1. / cam.fy, cx_fx = cam.cx / cam.fx, cy_fy = cam.cy / cam.fy;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        mu[i] = inv_fx * mu_px[i] - cx_fx;
-        mv[i] = inv_fy * mv_px[i] - cy_fy;
-        const double norm = sqrt(mu[i] * mu[i] + mv[i] * mv[i] + 1);
-        mk[i] = 1. / norm;
-        mu[i] *= mk[i];
-        mv[i] *= mk[i];
+        S.mu[i] = inv_fx * mu_px[i] - cx_fx;
+        S.mv[i] = inv_fy * mv_px[i] - cy_fy;
+        const double norm = sqrt(S.mu[i] * S.mu[i] + S.mv[i] * S.mv[i] + 1);
+        S.mk[i] = 1. / norm;
+        S.mu[i] *= S.mk[i];
+        S.mv[i] *= S.mk[i];
     }
+    const double* mu = S.mu;
+    const double* mv = S.mv;
+    const double* mk = S.mk;
     const V3 d12 = P[1] - P[2], d02 = P[0] - P[2], d01 = P[0] - P[1];
     const double dist0 = sqrt(d12.x * d12.x + d12.y * d12.y + d12.z * d12.z);
     const double dist1 = sqrt(d02.x * d02.x + d02.y * d02.y + d02.z * d02.z);
@@ -404,6 +415,7 @@ ESAC_HD bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4]
     const double b = inv_d22 * (dist1 * dist1);
     const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
     const double pr = p * r, pqr = q * pr;
+    S.n = 0;
     if (p2 + q2 + r2 - pqr - 1 == 0) return false;
     const double ab = a * b, a_2 = 2 * a;
     const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
@@ -420,48 +432,70 @@ ESAC_HD bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4]
     double x0 = 0, x1 = 0, x2r = 0, x3 = 0;
     const int n = quartic_real_roots(A, B, C, D, E, x0, x1, x2r, x3);
     if (n == 0) return false;
+    S.n = n;
+    S.x[0] = x0; S.x[1] = x1; S.x[2] = x2r; S.x[3] = x3;
+    S.dist2 = dist2; S.a = a; S.b = b; S.p = p; S.q = q; S.r = r;
+    S.a2 = a2; S.b2 = b2; S.p2 = p2; S.q2 = q2; S.r2 = r2; S.pqr = pqr; S.ab = ab; S.a_2 = a_2; S.a_4 = a_4;
+    S.r3 = r2 * r; S.pr2 = p * r2; S.r3q = S.r3 * q;
+    S.inv_b0 = 1. / b0;
+    return true;
+}
 
-    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
-    const double inv_b0 = 1. / b0;
+// candidate of root x: false when it is not a valid solution
+ESAC_HD bool p3p_candidate(const P3PSetup& S, double x, const V3 P[4], const double mu3_px, const double mv3_px,
+                           const Cam& cam, double R[9], double T[3], double& reproj) {
+    const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
+    const double a2 = S.a2, b2 = S.b2, p2 = S.p2, q2 = S.q2, r2 = S.r2, pqr = S.pqr, ab = S.ab, a_2 = S.a_2, a_4 = S.a_4;
+    const double r3 = S.r3, pr2 = S.pr2, r3q = S.r3q;
+    (void)pqr;
+    if (x <= 0) return false;
+    const double xx = x * x;
+    // same association order as the CPU solver: b1 suffers heavy cancellation, and the two
+    // sides only agree on ill-conditioned samples if they round the same way
+    const double b1 =
+        ((1 - a - b) * xx + (q * a - q) * x + 1 - a + b) *
+        (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+          (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) +
+           pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * xx +
+         (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) +
+          r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+          pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+         2 * r3q * (a_2 - b - a2 + ab - 1) +
+         pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+         p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+    if (b1 <= 0) return false;
+    const double y = S.inv_b0 * b1;
+    const double v = xx + y * y - x * y * r;
+    if (v <= 0) return false;
+    const double Z = S.dist2 / sqrt(v);
+    const double X = x * Z;
+    const double Y = y * Z;
+    const V3 Q0 = {X * S.mu[0], X * S.mv[0], X * S.mk[0]};
+    const V3 Q1 = {Y * S.mu[1], Y * S.mv[1], Y * S.mk[1]};
+    const V3 Q2 = {Z * S.mu[2], Z * S.mv[2], Z * S.mk[2]};
+    align_triangles(P[0], P[1], P[2], Q0, Q1, Q2, R, T);
+    const double X3p = R[0] * P[3].x + R[1] * P[3].y + R[2] * P[3].z + T[0];
+    const double Y3p = R[3] * P[3].x + R[4] * P[3].y + R[5] * P[3].z + T[1];
+    const double Z3p = R[6] * P[3].x + R[7] * P[3].y + R[8] * P[3].z + T[2];
+    const double mu3p = cam.cx + cam.fx * X3p / Z3p;
+    const double mv3p = cam.cy + cam.fy * Y3p / Z3p;
+    reproj = (mu3p - mu3_px) * (mu3p - mu3_px) + (mv3p - mv3_px) * (mv3p - mv3_px);
+    return true;
+}
+
+// obj: 4 scene points, img: 4 pixel positions.  Returns false when there is no solution.
+ESAC_HD bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4], const Cam& cam,
+                                        double Rbest[9], double Tbest[3]) {
+    P3PSetup S;
+    if (!p3p_setup(P, mu_px, mv_px, cam, S)) return false;
     bool have = false;
     double min_reproj = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        if (i >= n) continue;
-        const double x = (i == 0) ? x0 : (i == 1) ? x1 : (i == 2) ? x2r : x3;
-        if (x <= 0) continue;
-        const double xx = x * x;
-        // same association order as the CPU solver: b1 suffers heavy cancellation, and the two
-        // sides only agree on ill-conditioned samples if they round the same way
-        const double b1 =
-            ((1 - a - b) * xx + (q * a - q) * x + 1 - a + b) *
-            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
-              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) +
-               pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * xx +
-             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) +
-              r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
-              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
-             2 * r3q * (a_2 - b - a2 + ab - 1) +
-             pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
-             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
-        if (b1 <= 0) continue;
-        const double y = inv_b0 * b1;
-        const double v = xx + y * y - x * y * r;
-        if (v <= 0) continue;
-        const double Z = dist2 / sqrt(v);
-        const double X = x * Z;
-        const double Y = y * Z;
-        const V3 Q0 = {X * mu[0], X * mv[0], X * mk[0]};
-        const V3 Q1 = {Y * mu[1], Y * mv[1], Y * mk[1]};
-        const V3 Q2 = {Z * mu[2], Z * mv[2], Z * mk[2]};
-        double R[9], T[3];
-        align_triangles(P[0], P[1], P[2], Q0, Q1, Q2, R, T);
-        const double X3p = R[0] * P[3].x + R[1] * P[3].y + R[2] * P[3].z + T[0];
-        const double Y3p = R[3] * P[3].x + R[4] * P[3].y + R[5] * P[3].z + T[1];
-        const double Z3p = R[6] * P[3].x + R[7] * P[3].y + R[8] * P[3].z + T[2];
-        const double mu3p = cam.cx + cam.fx * X3p / Z3p;
-        const double mv3p = cam.cy + cam.fy * Y3p / Z3p;
-        const double reproj = (mu3p - mu_px[3]) * (mu3p - mu_px[3]) + (mv3p - mv_px[3]) * (mv3p - mv_px[3]);
+        if (i >= S.n) continue;
+        const double x = (i == 0) ? S.x[0] : (i == 1) ? S.x[1] : (i == 2) ? S.x[2] : S.x[3];
+        double R[9], T[3], reproj;
+        if (!p3p_candidate(S, x, P, mu_px[3], mv_px[3], cam, R, T, reproj)) continue;
         if (!have || min_reproj > reproj) {
             have = true;
             min_reproj = reproj;

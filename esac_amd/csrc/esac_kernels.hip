@@ -36,13 +36,14 @@ namespace esac {
 // SAMPLE_B = tries evaluated per round.  A single call wants latency (256 tries = 4 wavefronts per hypothesis:
 // nearly every hypothesis is accepted in round one, the other CUs are idle anyway); thousands of hypotheses
 // in flight (many experts, batched frames) want throughput (64 tries = one wavefront, no wasted solves).
-// QUAD: four lanes per try, lane q evaluates the candidate of quartic root q (lengths + alignment + 4th-point error,
-// the long part of the solver) and the four agree on the winner through shuffles -- the dependent chain of a try is
-// one candidate long instead of up to four.  Used for the single-frame launch, where latency is everything.
+// QUAD: in the first rounds (SAMPLE_B tries) four lanes share a try, lane q evaluates the candidate of quartic root q (lengths +
+// alignment + 4th-point error, the long part of the solver) and the four agree on the winner through shuffles -- the
+// dependent chain of a try is one candidate long instead of up to four.  A hypothesis on a good map is accepted within
+// its first few dozen tries, so the single-frame launch, where latency is everything, ends after one or two short
+// rounds; a hypothesis that needs hundreds of tries (wrong expert) continues with one try per lane, the throughput shape.
 template <int SAMPLE_B, bool QUAD>
 __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     __shared__ int s_first[2][SAMPLE_B / 64];
-    constexpr int TRIES = QUAD ? SAMPLE_B / 4 : SAMPLE_B;  // tries per round
     frame_view(a);
     const int h = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -55,10 +56,12 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     const double tau = (double)a.tau;
 
     int parity = 0;
-    for (int base = 0; base < a.max_tries; base += TRIES, parity ^= 1) {
-        const int t = base + (QUAD ? (int)threadIdx.x >> 2 : (int)threadIdx.x);
-        const int root = threadIdx.x & 3;  // QUAD only
-        bool holder = !QUAD;               // the lane that carries the try's final state (pose or zero pose)
+    for (int base = 0, TRIES = 0; base < a.max_tries; base += TRIES, parity ^= 1) {
+        const bool quad = QUAD && base < SAMPLE_B;  // workgroup-uniform: the first SAMPLE_B tries go four lanes a try
+        TRIES = quad ? SAMPLE_B / 4 : SAMPLE_B;
+        const int t = base + (quad ? (int)threadIdx.x >> 2 : (int)threadIdx.x);
+        const int root = threadIdx.x & 3;  // quad round only
+        bool holder = !quad;               // the lane that carries the try's final state (pose or zero pose)
         const bool active = t < a.max_tries;
         int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
         double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             }
             double Rp[9], Tp[3];
             bool solved;
-            if (QUAD) {
+            if (QUAD && quad) {
                 P3PSetup S;
                 const bool ok = p3p_setup(Pt, mu, mv, cam, S);
                 const double x = root == 0 ? S.x[0] : root == 1 ? S.x[1] : root == 2 ? S.x[2] : S.x[3];
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
         const unsigned long long m = __ballot(accepted);
         if (lane == 0) {
             const int first_lane = __ffsll((long long)m) - 1;
-            s_first[parity][wave] = m ? base + (QUAD ? wave * 16 + (first_lane >> 2) : wave * 64 + first_lane) : 0x7fffffff;
+            s_first[parity][wave] = m ? base + (quad ? wave * 16 + (first_lane >> 2) : wave * 64 + first_lane) : 0x7fffffff;
         }
         __syncthreads();
         int first = s_first[parity][0];

@@ -107,6 +107,11 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
     const float tmag2 = 2.0f * (fabsf(tf[0]) + fabsf(tf[1]) + fabsf(tf[2]));
     const float kf = 1.2e-6f * a.focal;
     const float kpix = 1.2e-6f * 4.0f * ((float)(a.W + a.H) * (float)a.sub + fabsf(a.ppx) + fabsf(a.ppy) + a.tau);
+    // second screen (fp64): the reference's float rounding of the projected pixel, see below
+    const double band2 = 2.4e-7 * ((double)(a.W > a.H ? a.W : a.H) * a.sub + abs(a.shift_x) + abs(a.shift_y) + (double)a.tau) + 2e-6;
+    const double tlo = (double)a.tau - band2, thi = (double)a.tau + band2;
+    const double tau_lo2 = tlo > 0 ? tlo * tlo : -1.0, tau_hi2 = thi * thi;
+    const float tau_below = nextafterf(a.tau, -INFINITY);
     // a lane's groups advance by B*L cells per step: (row, col) kept incrementally, one division in total
     const int stepR = (B * L) / a.W, stepC = B * L - stepR * a.W;
     int row = ((int)threadIdx.x * L) / a.W, col = (int)threadIdx.x * L - row * a.W;
@@ -155,7 +160,7 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
         // fp32 screening: a cell whose fp32 error is farther from tau than the bound above cannot change
         // side under the reference arithmetic.  Only cells inside that band -- a few per ten thousand --
         // pay for the exact fp64 evaluation, so `err < tau` is decided exactly everywhere.
-        bool need_exact = false;
+        bool need[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const float xc = fmaf(Rf[0], X[u], fmaf(Rf[1], Y[u], fmaf(Rf[2], Z[u], tf[0])));
@@ -167,17 +172,36 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
             errv[u] = __builtin_amdgcn_sqrtf(fmaf(du, du, dv * dv));
             const float aiz = fabsf(iz), axy = fabsf(xc) + fabsf(yc);
             const float guard = fmaf(kf * aiz * (axy + fabsf(zc) + tmag2), fmaf(axy, aiz, 1.0f), kpix);
-            // not finite, or within the band -> the reference-exact evaluation decides
-            need_exact |= !(fabsf(errv[u] - a.tau) > guard);
+            // not finite, or within the band -> the second screen / the reference-exact evaluation decides
+            need[u] = !(fabsf(errv[u] - a.tau) > guard);
         }
         CYC_END(11);
         CYC_BEGIN();
-        if (__any(need_exact)) {  // wave-uniform branch: the exact pass costs ~10x the screening
-            CYC_ADD(15, 1);
-            float exact[U];
-            project_exact_err_batch<U>(R, pose + 3, cam, X, Y, Z, pxf, pyf, exact);
+        // Second screen, per sub-step and only where some lane asked for it (wave-uniform branches): the error in
+        // fp64 with a Newton reciprocal and no square root (~25 dependent ops instead of the ~70 of the reference
+        // sequence).  The reference rounds the projection to float before taking the difference, so its error differs
+        // from the fp64 value by at most ~sqrt(2)/2 ulp of the pixel coordinate (+1e-6); `band2` leaves 3.5x of
+        // head-room on that.  What is still undecided inside that band gets the bit-exact evaluation.
 #pragma unroll
-            for (int u = 0; u < U; u++) errv[u] = exact[u];
+        for (int u = 0; u < U; u++) {
+            if (!__any(need[u])) continue;
+            CYC_ADD(15, 1);
+            const double Xd = X[u], Yd = Y[u], Zd = Z[u];
+            const double xc = R[0] * Xd + R[1] * Yd + R[2] * Zd + pose[3];
+            const double yc = R[3] * Xd + R[4] * Yd + R[5] * Zd + pose[4];
+            const double zc = R[6] * Xd + R[7] * Yd + R[8] * Zd + pose[5];
+            const double iz = zc ? fast_rcp(zc) : 1.0;
+            const double du = (double)pxf[u] - (xc * iz * cam.fx + cam.cx);
+            const double dv = (double)pyf[u] - (yc * iz * cam.fy + cam.cy);
+            const double e2 = du * du + dv * dv;
+            const bool in2 = e2 < tau_lo2, out2 = e2 > tau_hi2;  // NaN: neither
+            const bool undecided = need[u] && !(in2 || out2);
+            if (need[u] && in2) errv[u] = fminf(errv[u], tau_below);   // keep the fp32 value on the decided side
+            if (need[u] && out2) errv[u] = fmaxf(errv[u], a.tau);
+            if (__any(undecided)) {
+                const float exact = project_exact_err(R, pose + 3, cam, X[u], Y[u], Z[u], pxf[u], pyf[u]);
+                if (undecided) errv[u] = exact;
+            }
         }
         CYC_END(12);
         CYC_BEGIN();

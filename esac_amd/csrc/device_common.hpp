@@ -168,7 +168,6 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     a.fast_scores += f * N;
     a.scores += f * N;
     a.exact_flag += f * N;
-    a.contenders += f * N;
     a.n_contenders += f * 4;
     a.stats += f * 4;
     if (a.errs) a.errs += f * P;

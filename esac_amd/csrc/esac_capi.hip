@@ -67,7 +67,7 @@ extern "C" int esac_hip_device_count(void) {
 
 static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.fast_scores,
-                    c->ws.scores,     c->ws.exact_flag,   c->ws.contenders, c->ws.n_contenders, c->ws.stats,
+                    c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -138,7 +138,6 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.fast_scores, (size_t)nN);
     rc |= alloc(&c->ws.scores, (size_t)nN);
     rc |= alloc(&c->ws.exact_flag, (size_t)nN);
-    rc |= alloc(&c->ws.contenders, (size_t)nN);
     rc |= alloc(&c->ws.n_contenders, (size_t)4 * nB);
     rc |= alloc(&c->ws.stats, (size_t)4 * nB);
     rc |= alloc(&c->ws.errs, (size_t)nP);

@@ -66,7 +66,6 @@ struct KArgs {
     float* fast_scores;   // [N]
     double* scores;       // [N]
     uint8_t* exact_flag;  // [N]
-    int* contenders;      // [N] (unused since the select and re-score launches were fused; kept for layout stability)
     int* n_contenders;    // [1] hypotheses inside the band of the fp32 maximum
     double* stats;        // [4] max, sum exp, entropy
     float* errs;          // [P]

@@ -3,15 +3,16 @@
 // Reference: esac.cpp:153-187, refineHyp esac_util.h:378-454, draw esac_util.h:505-530,
 // pose2trans esac_util.h:537-548.  The reference runs this serially on one CPU thread
 // (esac.cpp:167 is outside every omp region); here it is the latency-critical tail of
-// the whole call.  On gfx950 a DEPENDENT fp64 op costs ~32 cycles (issue: 4) and the
+// the whole call.  On gfx950 a DEPENDENT fp64 op costs ~40 cycles (issue: 4) and the
 // pipeline is in-order, so everything below is organised to keep independent fp64
 // work adjacent in the instruction stream and the dependent chains short:
-//   * one fused pass computes the exact error image of the current pose, the inlier
-//     count AND the compacted inlier list of the next re-fit (16 B per correspondence in
-//     LDS: x,y,z + packed pixel), four points per lane in flight, loads issued up front;
-//   * per-point LM work is the twist-space Jacobian of lm_math.hpp (~80 fp64 ops), two
-//     correspondences per lane interleaved, Newton reciprocal instead of IEEE division;
-//   * the 27 fp64 sums of a pass are reduced with v_permlane32/16_swap pair-sums
+//   * one fused pass decides `err < tau` for every cell (fp32 screen, fp64 screen, bit-exact evaluation only inside
+//     the last band), counts the inliers and appends them to a WAVE-LOCAL list (16 B per correspondence in LDS:
+//     x,y,z + packed pixel) -- no cross-wavefront prefix, one barrier per pass;
+//   * per-point LM work: with fx = fy the normal matrix is a set of 24 monomial moments in (x, y, 1/z)
+//     (lm_math.hpp, ~68 fp64 ops per correspondence), Newton reciprocal instead of IEEE division, the projection
+//     chain of the next correspondences software-pipelined against the accumulation of the current ones;
+//   * the 24 fp64 sums of a pass are reduced with v_permlane32/16_swap pair-sums
 //     (halving the live values per stage) + DPP row stages (device_common.hpp);
 //   * every lane carries the 6-parameter LM state redundantly: all lanes take the same
 //     branches from the same reduced sums, so nothing is broadcast;

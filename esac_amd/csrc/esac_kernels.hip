@@ -33,6 +33,109 @@
 namespace esac {
 
 // ================================================================= K1: sample + P3P
+// Stored pose and acceptance of a solved sample: the reference keeps (rvec, tvec), re-expands it when projecting
+// (esac_util.h:202) and accepts iff the 4 sampled points reproject within tau (esac_util.h:210-221, norm in double).
+__device__ __forceinline__ bool accept_sample(const double Rp[9], const double Tp[3], const float (&Pf)[4][3], const double (&mu)[4],
+                                              const double (&mv)[4], const Cam& cam, double tau, double rvec[3], double T[3],
+                                              double R[9]) {
+    rodrigues_mat2vec(Rp, rvec);
+    rodrigues_vec2mat<false>(rvec, R, nullptr);
+    T[0] = Tp[0]; T[1] = Tp[1]; T[2] = Tp[2];
+    bool accepted = true;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const double Xd = Pf[j][0], Yd = Pf[j][1], Zd = Pf[j][2];
+        double x = R[0] * Xd + R[1] * Yd + R[2] * Zd + T[0];
+        double y = R[3] * Xd + R[4] * Yd + R[5] * Zd + T[1];
+        double z = R[6] * Xd + R[7] * Yd + R[8] * Zd + T[2];
+        z = z ? 1. / z : 1;
+        x *= z;
+        y *= z;
+        const float u = (float)(x * cam.fx + cam.cx), v = (float)(y * cam.fy + cam.cy);
+        const float dx = (float)mu[j] - u, dy = (float)mv[j] - v;
+        const double nrm = sqrt((double)dx * dx + (double)dy * dy);
+        if (nrm < tau) continue;
+        accepted = false;
+    }
+    return accepted;
+}
+
+// the 4 cells of try t of hypothesis gh, their scene points and pixel positions
+__device__ __forceinline__ void gather_sample(const KArgs& a, const float* __restrict__ map, int P, const Philox& rng, uint32_t gh,
+                                              uint32_t t, int (&cx)[4], int (&cy)[4], V3 (&Pt)[4], float (&Pf)[4][3],
+                                              double (&mu)[4], double (&mv)[4]) {
+    draw_cells(rng, gh, t, a.W, a.H, cx, cy);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int idx = cy[j] * a.W + cx[j];
+        Pf[j][0] = map[idx];
+        Pf[j][1] = map[P + idx];
+        Pf[j][2] = map[2 * P + idx];
+        Pt[j] = V3{(double)Pf[j][0], (double)Pf[j][1], (double)Pf[j][2]};
+        mu[j] = (double)cell_px(a, cx[j]);
+        mv[j] = (double)cell_py(a, cy[j]);
+    }
+}
+
+__device__ __forceinline__ void store_hypothesis(const KArgs& a, int h, const double rvec[3], const double T[3], const double R[9],
+                                                 const int (&cx)[4], const int (&cy)[4], int tries_val) {
+    double* hp = a.hyps + (size_t)h * 6;
+    hp[0] = rvec[0]; hp[1] = rvec[1]; hp[2] = rvec[2];
+    hp[3] = T[0]; hp[4] = T[1]; hp[5] = T[2];
+    float* rt = a.rt32 + (size_t)h * 12;
+#pragma unroll
+    for (int k = 0; k < 9; k++) rt[k] = (float)R[k];
+    rt[9] = (float)T[0]; rt[10] = (float)T[1]; rt[11] = (float)T[2];
+    int* sx = a.sample_xy + (size_t)h * 8;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        sx[2 * j] = cx[j];
+        sx[2 * j + 1] = cy[j];
+    }
+    a.tries[h] = tries_val;
+}
+
+constexpr int SAMPLE_PENDING = -2;  // tries[h] between the two phases of the throughput-shaped sampling
+constexpr int FIRST_PHASE_TRIES = 16;
+
+// Throughput shape, phase 1: a hypothesis on a usable map is accepted within its first few tries, so a whole
+// wavefront per hypothesis solves ~60 P3P problems nobody needs.  Here a wavefront serves FOUR hypotheses, 16 tries
+// each (one round); what is not accepted is marked pending and continues in k_sample from try 16 on.
+__global__ __launch_bounds__(64) void k_sample_first(KArgs a) {
+    frame_view(a);
+    const int lane = threadIdx.x, grp = lane >> 4, t = lane & 15;
+    const int h = blockIdx.x * 4 + grp;
+    const bool active = h < a.N && t < a.max_tries;
+    const int hc = h < a.N ? h : a.N - 1;
+    const int e = (int)a.assign[hc];
+    const int P = a.H * a.W;
+    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
+    const Philox rng(a.seed, a.call);
+    const Cam cam = make_cam(a);
+    int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
+    double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    bool accepted = false;
+    if (active) {
+        V3 Pt[4];
+        float Pf[4][3];
+        double mu[4], mv[4], Rp[9], Tp[3];
+        gather_sample(a, map, P, rng, (uint32_t)global_hyp(a, hc), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+        if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp)) accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
+    }
+    const unsigned long long m = __ballot(accepted);
+    const unsigned mine = (unsigned)(m >> (16 * grp)) & 0xffffu;
+    if (h >= a.N) return;
+    if (mine) {
+        const int first = __ffs((int)mine) - 1;
+        if (t == first) store_hypothesis(a, h, rvec, T, R, cx, cy, first);
+    } else if (a.max_tries <= FIRST_PHASE_TRIES) {
+        if (t == a.max_tries - 1) store_hypothesis(a, h, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
+    } else if (t == 0) {
+        a.tries[h] = SAMPLE_PENDING;
+    }
+}
+
 // SAMPLE_B = tries evaluated per round.  A single call wants latency (256 tries = 4 wavefronts per hypothesis:
 // nearly every hypothesis is accepted in round one, the other CUs are idle anyway); thousands of hypotheses
 // in flight (many experts, batched frames) want throughput (64 tries = one wavefront, no wasted solves).
@@ -54,9 +157,10 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     const Cam cam = make_cam(a);
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const double tau = (double)a.tau;
+    if (a.first_try > 0 && a.tries[h] != SAMPLE_PENDING) return;  // phase 2 of the throughput shape: done in phase 1
 
     int parity = 0;
-    for (int base = 0, TRIES = 0; base < a.max_tries; base += TRIES, parity ^= 1) {
+    for (int base = a.first_try, TRIES = 0; base < a.max_tries; base += TRIES, parity ^= 1) {
         const bool quad = QUAD && base < SAMPLE_B;  // workgroup-uniform: the first SAMPLE_B tries go four lanes a try
         TRIES = quad ? SAMPLE_B / 4 : SAMPLE_B;
         const int t = base + (quad ? (int)threadIdx.x >> 2 : (int)threadIdx.x);
@@ -68,20 +172,10 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
         double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         bool accepted = false;
         if (active) {
-            draw_cells(rng, gh, (uint32_t)t, a.W, a.H, cx, cy);
             V3 Pt[4];
             float Pf[4][3];
             double mu[4], mv[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int idx = cy[j] * a.W + cx[j];
-                Pf[j][0] = map[idx];
-                Pf[j][1] = map[P + idx];
-                Pf[j][2] = map[2 * P + idx];
-                Pt[j] = V3{(double)Pf[j][0], (double)Pf[j][1], (double)Pf[j][2]};
-                mu[j] = (double)cell_px(a, cx[j]);
-                mv[j] = (double)cell_py(a, cy[j]);
-            }
+            gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
             double Rp[9], Tp[3];
             bool solved;
             if (QUAD && quad) {
@@ -110,29 +204,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             } else {
                 solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp);
             }
-            if (solved) {
-                // the reference stores (rvec, tvec) and re-expands it when projecting (esac_util.h:202)
-                rodrigues_mat2vec(Rp, rvec);
-                rodrigues_vec2mat<false>(rvec, R, nullptr);
-                T[0] = Tp[0]; T[1] = Tp[1]; T[2] = Tp[2];
-                accepted = true;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    // 4 sampled points must reproject within tau (esac_util.h:210-221), norm in double
-                    const double Xd = Pf[j][0], Yd = Pf[j][1], Zd = Pf[j][2];
-                    double x = R[0] * Xd + R[1] * Yd + R[2] * Zd + T[0];
-                    double y = R[3] * Xd + R[4] * Yd + R[5] * Zd + T[1];
-                    double z = R[6] * Xd + R[7] * Yd + R[8] * Zd + T[2];
-                    z = z ? 1. / z : 1;
-                    x *= z;
-                    y *= z;
-                    const float u = (float)(x * cam.fx + cam.cx), v = (float)(y * cam.fy + cam.cy);
-                    const float dx = (float)mu[j] - u, dy = (float)mv[j] - v;
-                    const double nrm = sqrt((double)dx * dx + (double)dy * dy);
-                    if (nrm < tau) continue;
-                    accepted = false;
-                }
-            }
+            if (solved) accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, tau, rvec, T, R);
             // a failed solve leaves the zero pose (safeSolvePnP, esac_util.h:107-111)
         }
         // lowest accepted try of the round = the try the reference's sequential loop stops at
@@ -154,22 +226,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             writer = a.max_tries - 1;  // budget exhausted: state of the last try remains
         }
         if (writer >= 0) {
-            if (t == writer && holder) {
-                double* hp = a.hyps + (size_t)h * 6;
-                hp[0] = rvec[0]; hp[1] = rvec[1]; hp[2] = rvec[2];
-                hp[3] = T[0]; hp[4] = T[1]; hp[5] = T[2];
-                float* rt = a.rt32 + (size_t)h * 12;
-#pragma unroll
-                for (int k = 0; k < 9; k++) rt[k] = (float)R[k];
-                rt[9] = (float)T[0]; rt[10] = (float)T[1]; rt[11] = (float)T[2];
-                int* sx = a.sample_xy + (size_t)h * 8;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    sx[2 * j] = cx[j];
-                    sx[2 * j + 1] = cy[j];
-                }
-                a.tries[h] = tries_val;
-            }
+            if (t == writer && holder) store_hypothesis(a, h, rvec, T, R, cx, cy, tries_val);
             return;
         }
     }
@@ -428,8 +485,12 @@ void launch_sample(const KArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, a);
     else if (total <= 4096)
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, a);
-    else
-        hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, a);
+    else {  // throughput: 16 tries of four hypotheses per wavefront first, the unaccepted rest one wavefront each
+        hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, a);
+        KArgs b = a;
+        b.first_try = FIRST_PHASE_TRIES;
+        if (a.max_tries > FIRST_PHASE_TRIES) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
+    }
 }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hyps_to_rt32, dim3((a.N + 255) / 256), dim3(256), 0, s, a);

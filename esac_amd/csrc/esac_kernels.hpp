@@ -56,6 +56,7 @@ struct KArgs {
     float tau, alpha, beta, max_reproj;
     uint64_t seed, call;
     int max_tries, max_ref_steps, hyp_offset;
+    int first_try;             // sampling continues from this try (two-phase throughput shape), 0 otherwise
     float margin;
     const int32_t* hyp_index;  // optional [N] global hypothesis indices
     // workspaces (device)

@@ -217,3 +217,51 @@ def test_debug_error_image_option(engine, oracle):
     want = np.minimum(np.hypot(xs * 8 + 4 - uv[..., 0], ys * 8 + 4 - uv[..., 1]), 100.0)
     np.testing.assert_allclose(errs, want, rtol=0, atol=2e-2)  # fp32-accurate away from tau
     np.testing.assert_array_equal(errs < 10.0, want < 10.0 - 0)  # the inlier side is decided exactly
+
+
+@pytest.mark.parametrize("max_tries", [0, 40, 16, 7])
+def test_two_phase_sampling_matches_oracle(engine, oracle, max_tries):
+    """More than 4096 hypotheses in flight take the throughput-shaped sampling: 16 tries of four hypotheses per
+    wavefront first, the unaccepted rest one wavefront each from try 16 on.  Sampled cells, accepted try and poses
+    must still be what the sequential loop of the reference produces -- incl. wrong-expert hypotheses that need
+    hundreds of tries (phase 2) and exhausted budgets inside phase 1 (7, 16) and phase 2 (40)."""
+    f = S.make_frame(120, E=4, true_expert=2)
+    N = 4608
+    ha = S.gating_assignment(f, N, mode="gating")
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    p = engine.make_params(4, 60, 80, N, seed=11, call=3, max_tries=max_tries)
+    engine.sample(sc, hat, p)
+    ref = oracle.forward(f["coords"], ha, seed=11, call=3, max_tries=max_tries)
+    tries = engine.read(api.BUF_TRIES)
+    np.testing.assert_array_equal(tries, ref["tries"])
+    np.testing.assert_array_equal(engine.read(api.BUF_SAMPLE_XY), ref["sample_xy"])
+    diff = np.abs(engine.read(api.BUF_HYPS) - ref["hyps"]).max(axis=1)
+    # every ACCEPTED hypothesis agrees; a hypothesis whose budget ran out keeps the pose of its last, rejected try, and
+    # on such a sample two P3P candidates can be equally bad for the 4th point: the two solvers may then keep different
+    # ones (seen on 1 of 4608 at max_tries = 7) -- tolerated for at most one in a thousand of the exhausted ones
+    assert (diff[tries >= 0] <= 1e-6).all()
+    assert (diff[tries < 0] > 1e-6).sum() <= max(1, int((tries < 0).sum()) // 1000)
+    if max_tries == 0:
+        assert (tries >= 16).any() and (tries < 16).any()  # both phases delivered hypotheses
+    else:
+        assert (tries == -1).any()  # some budgets ran out
+
+
+def test_large_batch_equals_sequential_calls(engine):
+    """The same through forward_batch: 48 frames x 128 hypotheses (two-phase sampling, 4-wavefront score kernel) ==
+    48 single calls (quad sampling, 8-wavefront score kernel) in everything that is decided exactly: winner, its exact
+    score, expert, refined pose, refinement trace.  (Selection probability and entropy are statistics of the fp32
+    score stream, whose summation order follows the launch shape: equal to ~1e-6, not bit for bit.)"""
+    B, N = 48, 128
+    frames = [S.make_frame(130 + b, E=2, true_expert=b % 2) for b in range(B)]
+    assigns = np.stack([S.gating_assignment(f, N, mode="gating") for f in frames])
+    coords = torch.from_numpy(np.stack([f["coords"] for f in frames])).cuda()
+    ha = torch.from_numpy(assigns).cuda()
+    p = engine.make_params(2, 60, 80, N, call=500)
+    res_b = engine.forward_batch(coords, ha, p)
+    for b in range(0, B, 5):
+        q = engine.make_params(2, 60, 80, N, call=500 + b)
+        res_1 = engine.forward_device(coords[b], ha[b], q)
+        np.testing.assert_array_equal(res_b[b][:api.RES_PROB], res_1[:api.RES_PROB])
+        assert res_b[b][api.RES_LM_ITERS] == res_1[api.RES_LM_ITERS]
+        np.testing.assert_allclose(res_b[b][api.RES_PROB:api.RES_ENTROPY + 1], res_1[api.RES_PROB:api.RES_ENTROPY + 1], rtol=1e-5)

@@ -524,7 +524,8 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
         if (a.result_user) {
 #pragma unroll
-            for (int k = 0; k < 32; k++) a.result_user[k] = r[k];
+            for (int k = 0; k < 31; k++) a.result_user[k] = r[k];
+            a.result_user[31] = 1.0;  // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" from a record
         }
         if (a.result_pin) {
             // straight into pinned host memory: the host polls the epoch word instead of waiting for a

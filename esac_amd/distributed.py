@@ -77,6 +77,26 @@ def _exchange_buffer(dev, n_total, world):
     return buf
 
 
+_params_cache = {}
+
+
+def _shard_params(engine, E, H, W, n, lo, params_kw):
+    """Parameter block of a shard; per frame only the RNG key moves, so the block is built once and re-keyed."""
+    fixed = tuple(sorted((k, v) for k, v in params_kw.items() if k not in ("seed", "call")))
+    key = (id(engine), E, H, W, n, lo, fixed)
+    p = _params_cache.get(key)
+    if p is None:
+        if len(_params_cache) > 64:
+            _params_cache.clear()
+        p = engine.make_params(E, H, W, n, hyp_offset=lo, **params_kw)
+        _params_cache[key] = p
+    else:
+        p.seed = int(params_kw.get("seed", 1305)) & (2**64 - 1)
+        p.call = int(params_kw.get("call", 0)) & (2**64 - 1)
+        engine._shape = (int(n), int(H), int(W))
+    return p
+
+
 def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, world, buf):
     """Rank `rank`'s part of the exchange for contiguous-range sharding: zero `buf`, run the forward path on
     hypotheses [lo, hi) with the kernels writing scores and record into this rank's slots of `buf`."""
@@ -89,11 +109,12 @@ def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, wor
         ha_dev = hyp_assign_full if hyp_assign_full.is_cuda else hyp_assign_full.to(dev)
         if ha_dev.stride(0) != 1:
             ha_dev = ha_dev.contiguous()  # stride-0 expand() of --expertselection
-        p = engine.make_params(E, H, W, hi - lo, hyp_offset=lo, **params_kw)
+        p = _shard_params(engine, E, H, W, hi - lo, lo, params_kw)
         rec0 = n_total + rank * RES_DOUBLES
+        # the refinement kernel writes the record itself, incl. the "this rank contributed" marker in its last slot
+        # (ESAC_RES_VALID, the convention pack_local follows for the index-list path)
         engine.forward_device(scene_coords, ha_dev[lo:hi], p, scores_out=buf[lo:hi], result_out=buf[rec0:rec0 + RES_DOUBLES],
                               want_host=False)
-        buf[rec0 + RES_DOUBLES - 1:rec0 + RES_DOUBLES].fill_(1.0)  # "this rank contributed" marker (see pack_local)
     return buf
 
 

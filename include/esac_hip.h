@@ -79,6 +79,8 @@ enum {
     ESAC_RES_ENTROPY = 28,   /* entropy of the hypothesis distribution (esac.cpp:158)            */
     ESAC_RES_CONTENDERS = 29,/* how many hypotheses were re-scored exactly                       */
     ESAC_RES_LM_ITERS = 30,  /* total LM iterations spent in refinement                          */
+    ESAC_RES_VALID = 31,     /* d_result_out only: 1.0 once a record has been written (multi-GPU exchange buffers
+                                are zero-padded; the host copy carries the inlier-map buffer index here instead) */
     ESAC_RES_DOUBLES = 32
 };
 

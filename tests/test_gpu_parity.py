@@ -105,3 +105,31 @@ def test_drop_in_module(oracle):
     g_r, g_t = S.pose_errors(out_pose.numpy(), f["gt_pose"])
     assert g_r < np.radians(5) and g_t < 0.05  # the 5cm/5deg criterion of test_esac.py:259
     assert esac.get_rng_state() == (1305, 6)
+
+
+def test_parity_sweep_over_frame_kinds(engine, oracle):
+    """96 frames of four kinds (plain, multi-expert gating, heavy noise + 50 % outliers, odd grid with a shifted crop):
+    winner, accepted refinement steps, per-step inlier counts, inlier map and LM iteration count identical to the
+    oracle on every one; pose within the north-star bars (in practice ~1e-8)."""
+    worst_r = worst_t = 0.0
+    for k in range(96):
+        kind = k % 4
+        if kind == 0:
+            f, N, mode = S.make_frame(1000 + k), 256, "single"
+        elif kind == 1:
+            f, N, mode = S.make_frame(1000 + k, E=3, true_expert=k % 3), 192, "gating"
+        elif kind == 2:
+            f, N, mode = S.make_frame(1000 + k, noise=0.05, outlier_frac=0.5), 128, "single"
+        else:
+            f, N, mode = S.make_frame(1000 + k, H=45, W=61, sub=10, shift=(k % 7 - 3, 2)), 96, "single"
+        ha = S.gating_assignment(f, N, mode=mode)
+        res, ref = _run_both(engine, oracle, f, ha, seed=77, call=k)
+        assert int(res[api.RES_HYP]) == ref["winner"] and int(res[api.RES_EXPERT]) == ref["expert"], k
+        assert int(res[api.RES_REF_STEPS]) == ref["ref_steps"], k
+        np.testing.assert_array_equal(engine.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
+        np.testing.assert_array_equal(engine.read(api.BUF_INLIER_MAP), ref["inlier_map"])
+        assert int(res[api.RES_LM_ITERS]) == ref["lm_iters"], k
+        r, t = S.pose_errors(res[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
+        assert r <= ROT_TOL and t <= TRANS_TOL, (k, r, t)
+        worst_r, worst_t = max(worst_r, r), max(worst_t, t)
+    assert worst_r < 1e-6 and worst_t < 1e-5, (worst_r, worst_t)

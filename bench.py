@@ -193,7 +193,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 (P3P, LM refinement, exact re-score) + f32 (streaming soft-inlier score)",
+            "dtype": "f64 (P3P, LM refinement, exact decisions) + f32 (streaming soft-inlier score, ranking only)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 1 expert, %d hypotheses/GPU, %dx%d grid (640x480 frame, "
                                    "sub-sampling %d), tau=10 alpha=100 beta=0.5 maxReproj=100; box-room frames, "

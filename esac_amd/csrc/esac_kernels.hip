@@ -101,7 +101,8 @@ constexpr int FIRST_PHASE_TRIES = 16;
 // Throughput shape, phase 1: a hypothesis on a usable map is accepted within its first few tries, so a whole
 // wavefront per hypothesis solves ~60 P3P problems nobody needs.  Here a wavefront serves FOUR hypotheses, 16 tries
 // each (one round); what is not accepted is marked pending and continues in k_sample from try 16 on.
-__global__ __launch_bounds__(64) void k_sample_first(KArgs a) {
+// two wavefronts per SIMD (256 registers each, ~80 B of spill): the solver is one long dependent fp64 chain per lane
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_first(KArgs a) {
     frame_view(a);
     const int lane = threadIdx.x, grp = lane >> 4, t = lane & 15;
     const int h = blockIdx.x * 4 + grp;

@@ -490,9 +490,10 @@ ESAC_HD bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4]
     if (!p3p_setup(P, mu_px, mv_px, cam, S)) return false;
     bool have = false;
     double min_reproj = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i >= S.n) continue;
+    // not unrolled: four inlined copies of the alignment bought nothing (each candidate is one dependent chain)
+    // and cost registers and instruction cache
+#pragma nounroll
+    for (int i = 0; i < S.n; i++) {
         const double x = (i == 0) ? S.x[0] : (i == 1) ? S.x[1] : (i == 2) ? S.x[2] : S.x[3];
         double R[9], T[3], reproj;
         if (!p3p_candidate(S, x, P, mu_px[3], mv_px[3], cam, R, T, reproj)) continue;

@@ -575,7 +575,7 @@ ESAC_HD void lm_solve6(const double U21[21], const double g[6], double lambda, d
 #pragma unroll
         for (int m = 0; m < j; m++) d -= W[j][m] * L[j][m];
         if (!(d > 0)) ok = false;
-        const double inv = 1. / d;
+        const double inv = fast_rcp(d);  // six reciprocals sit on the serial chain of every LM iteration
         Dinv[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {

@@ -306,3 +306,56 @@ def test_argument_errors(oracle):
         oracle.forward(np.zeros((1, 3, 2, 2), np.float32), np.zeros(4, np.int64))
     with pytest.raises(RuntimeError):
         oracle.forward(np.zeros((1, 3, 8, 8), np.float32), np.full(4, 3, np.int64))
+
+
+# ---------------------------------------------------------------- training path of the oracle
+def test_backward_score_path_matches_finite_differences(oracle):
+    """Oracle esac_backward with max_ref_steps = 0 (no re-fit: path I vanishes, refined pose = initial pose): moving a
+    coordinate of a cell nobody sampled changes the expected loss only through the scores, an exact derivative in the
+    reference's formulas (softmax x sigmoid x d error / d point) -- central differences of the returned loss agree."""
+    from esac_amd import synthetic as S
+    f = S.make_frame(300, H=24, W=32, sub=20)
+    ha = S.gating_assignment(f, 24)
+    gt = f["gt_pose"].astype(np.float32)
+    gt[:3, 3] += np.float32(0.05)
+    kw = dict(focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], inlier_alpha=3.0, seed=5, call=2, max_ref_steps=0)
+    g = np.zeros_like(f["coords"])
+    out = oracle.backward(f["coords"], g, ha, gt, **kw)
+    assert (out["probs"] >= 1e-3).sum() >= 5
+    sampled = set(map(tuple, out["sample_xy"].reshape(-1, 2)))
+    checked = 0
+    for idx in np.argsort(-np.abs(g[0]).reshape(-1)):
+        c, rem = divmod(int(idx), 24 * 32)
+        y, x = divmod(rem, 32)
+        if (x, y) in sampled:
+            continue
+        h = 1e-3
+        vals = []
+        for s in (+1, -1):
+            pert = f["coords"].copy()
+            pert[0, c, y, x] += s * h
+            vals.append(oracle.backward(pert, np.zeros_like(g), ha, gt, **kw)["loss"])
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - g[0, c, y, x]) <= 0.02 * abs(g[0, c, y, x]) + 1e-6, (fd, g[0, c, y, x])
+        checked += 1
+        if checked == 4:
+            break
+    assert checked == 4
+
+
+def test_backward_accumulates_and_is_deterministic(oracle):
+    from esac_amd import synthetic as S
+    f = S.make_frame(301, H=24, W=32, sub=20)
+    ha = S.gating_assignment(f, 16)
+    gt = f["gt_pose"].astype(np.float32)
+    kw = dict(focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=5, call=3)
+    g1 = np.zeros_like(f["coords"])
+    a = oracle.backward(f["coords"], g1, ha, gt, **kw)
+    g2 = g1.copy()
+    b = oracle.backward(f["coords"], g2, ha, gt, **kw)
+    assert a["loss"] == b["loss"] and np.abs(g1).max() > 0
+    np.testing.assert_allclose(g2, 2 * g1, rtol=1e-5, atol=1e-9)  # float `+=` into the caller's tensor (esac.cpp:491-508)
+    g3 = np.zeros_like(g1)
+    c = oracle.backward(f["coords"], g3, ha, gt, num_threads=1, **kw)
+    assert c["loss"] == a["loss"]
+    np.testing.assert_array_equal(g3, g1)  # thread-count independent

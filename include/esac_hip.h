@@ -93,7 +93,8 @@ enum {
     ESAC_BUF_RESULT = 4,     /* double[ESAC_RES_DOUBLES]                                          */
     ESAC_BUF_INLIER_MAP = 5, /* uint8[H*W] last accepted inlier set (esac_util.h:440 inlierMap)  */
     ESAC_BUF_INLIER_COUNTS = 6, /* int32[ESAC_MAX_REF_STEPS+1] inlier count seen at each step    */
-    ESAC_BUF_WINNER_ERRS = 7,   /* float[H*W] reprojection errors of the current pose            */
+    ESAC_BUF_WINNER_ERRS = 7,   /* float[H*W] reprojection errors of the refined pose; only kept after
+                                   esac_hip_set_debug(ctx, ESAC_DEBUG_ERROR_IMAGE)               */
     ESAC_BUF_EXACT_FLAGS = 8,   /* uint8[N] 1 where ESAC_BUF_SCORES holds an exact re-score      */
     ESAC_BUF_CYCLES = 9,        /* int64[32] shader-cycle counters of the refinement kernel (profiling) */
     /* stage outputs of the most recent esac_hip_backward */

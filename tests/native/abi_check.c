@@ -1,0 +1,128 @@
+/* abi_check.c -- TEST-ONLY: include/esac_hip.h is a plain C header and libesac_hip.so a plain C ABI.
+ * Built with gcc -std=c99 (no C++, no HIP headers) by tests/test_abi_and_api.py; dlopens the library, resolves every
+ * entry point the header declares through its C prototype, checks the parameter block's size and runs the calls that
+ * need no GPU.  With a device (argv[2] == "gpu") it also runs one whole forward call on raw hipMalloc'ed buffers
+ * obtained through the HIP runtime's C entry points -- no torch anywhere. */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/esac_hip.h"
+
+#define RESOLVE(name)                                              \
+    do {                                                           \
+        *(void**)(&p_##name) = dlsym(lib, #name);                  \
+        if (!p_##name) {                                           \
+            fprintf(stderr, "missing symbol %s\n", #name);         \
+            return 2;                                              \
+        }                                                          \
+    } while (0)
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 64;
+    void* lib = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);  /* global: the HIP runtime it depends on becomes visible too */
+    if (!lib) {
+        fprintf(stderr, "dlopen failed: %s\n", dlerror());
+        return 1;
+    }
+    int (*p_esac_hip_abi_version)(void);
+    const char* (*p_esac_hip_last_error)(void);
+    int (*p_esac_hip_device_count)(void);
+    int (*p_esac_hip_create)(esac_hip_ctx**, int);
+    int (*p_esac_hip_destroy)(esac_hip_ctx*);
+    int (*p_esac_hip_forward)(esac_hip_ctx*, const float*, const int64_t*, const esac_hip_params*, void*, double*, double*, double*);
+    int (*p_esac_hip_forward_batch)(esac_hip_ctx*, int, const float*, int64_t, const int64_t*, const esac_hip_params*, void*, double*,
+                                    double*, double*);
+    int (*p_esac_hip_backward)(esac_hip_ctx*, const float*, float*, const int64_t*, const float*, float, float, float,
+                               const esac_hip_params*, void*, double*);
+    int (*p_esac_hip_read)(esac_hip_ctx*, int, void*, size_t);
+    RESOLVE(esac_hip_abi_version);
+    RESOLVE(esac_hip_last_error);
+    RESOLVE(esac_hip_device_count);
+    RESOLVE(esac_hip_create);
+    RESOLVE(esac_hip_destroy);
+    RESOLVE(esac_hip_forward);
+    RESOLVE(esac_hip_forward_batch);
+    RESOLVE(esac_hip_backward);
+    RESOLVE(esac_hip_read);
+    if (p_esac_hip_abi_version() != ESAC_HIP_ABI_VERSION) return 3;
+    if (sizeof(esac_hip_params) != 96) {
+        fprintf(stderr, "sizeof(esac_hip_params) = %zu\n", sizeof(esac_hip_params));
+        return 4;
+    }
+    printf("abi %d, params %zu bytes, devices %d\n", p_esac_hip_abi_version(), sizeof(esac_hip_params), p_esac_hip_device_count());
+    esac_hip_ctx* ctx = NULL;
+    int rc = p_esac_hip_create(&ctx, 0);
+    if (argc < 3 || strcmp(argv[2], "gpu") != 0) {
+        /* no device here: creation must fail loudly, never fall back */
+        if (rc == 0) return 5;
+        printf("create without a device: status %d, \"%s\"\n", rc, p_esac_hip_last_error());
+        return strstr(p_esac_hip_last_error(), "no CPU fallback") ? 0 : 6;
+    }
+    if (rc != 0) {
+        fprintf(stderr, "create failed: %s\n", p_esac_hip_last_error());
+        return 7;
+    }
+    /* device buffers through the HIP runtime's own C ABI */
+    int (*hipMalloc_)(void**, size_t);
+    int (*hipMemcpy_)(void*, const void*, size_t, int);
+    int (*hipFree_)(void*);
+    *(void**)(&hipMalloc_) = dlsym(RTLD_DEFAULT, "hipMalloc");
+    *(void**)(&hipMemcpy_) = dlsym(RTLD_DEFAULT, "hipMemcpy");
+    *(void**)(&hipFree_) = dlsym(RTLD_DEFAULT, "hipFree");
+    if (!hipMalloc_ || !hipMemcpy_ || !hipFree_) return 9;
+    /* a flat wall 3 m in front of an identity camera: scene point of cell (x,y) = ray through its pixel centre at z = 3 */
+    enum { H = 60, W = 80, N = 32, P = H * W };
+    float* sc = (float*)malloc(sizeof(float) * 3 * P);
+    int64_t assign[N];
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            const float px = (float)(x * 8 + 4), py = (float)(y * 8 + 4);
+            sc[0 * P + y * W + x] = (px - 320.0f) / 525.0f * 3.0f;
+            sc[1 * P + y * W + x] = (py - 240.0f) / 525.0f * 3.0f;
+            sc[2 * P + y * W + x] = 3.0f;
+        }
+    for (int i = 0; i < N; i++) assign[i] = 0;
+    void *d_sc = NULL, *d_assign = NULL;
+    if (hipMalloc_(&d_sc, sizeof(float) * 3 * P) || hipMalloc_(&d_assign, sizeof(assign))) return 10;
+    if (hipMemcpy_(d_sc, sc, sizeof(float) * 3 * P, 1) || hipMemcpy_(d_assign, assign, sizeof(assign), 1)) return 11;
+    esac_hip_params p;
+    memset(&p, 0, sizeof(p));
+    p.E = 1; p.H = H; p.W = W; p.N = N;
+    p.focal = 525.0f; p.ppx = 320.0f; p.ppy = 240.0f;
+    p.inlier_thresh = 10.0f; p.inlier_alpha = 100.0f; p.inlier_beta = 0.5f; p.max_reproj = 100.0f;
+    p.sub_sampling = 8; p.seed = 1305; p.call = 0; p.max_ref_steps = -1;
+    double res[ESAC_RES_DOUBLES];
+    rc = p_esac_hip_forward(ctx, (const float*)d_sc, (const int64_t*)d_assign, &p, NULL, NULL, NULL, res);
+    if (rc != 0) {
+        fprintf(stderr, "forward failed: %s\n", p_esac_hip_last_error());
+        return 12;
+    }
+    /* the map was generated with the identity pose: the estimate must be the identity transform */
+    double worst = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            const double d = res[ESAC_RES_POSE + 4 * i + j] - (i == j ? 1.0 : 0.0);
+            worst = d < 0 ? (-d > worst ? -d : worst) : (d > worst ? d : worst);
+        }
+    printf("forward ok: expert %d, inliers %d, |pose - I|max %.2e\n", (int)res[ESAC_RES_EXPERT], (int)res[ESAC_RES_INLIERS], worst);
+    /* training path: ground truth = identity -> loss ~ 0 */
+    float gt[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    void* d_grad = NULL;
+    if (hipMalloc_(&d_grad, sizeof(float) * 3 * P)) return 13;
+    memset(sc, 0, sizeof(float) * 3 * P);
+    if (hipMemcpy_(d_grad, sc, sizeof(float) * 3 * P, 1)) return 14;
+    double out[4];
+    rc = p_esac_hip_backward(ctx, (const float*)d_sc, (float*)d_grad, (const int64_t*)d_assign, gt, 1.0f, 100.0f, 100.0f, &p, NULL, out);
+    if (rc != 0) {
+        fprintf(stderr, "backward failed: %s\n", p_esac_hip_last_error());
+        return 15;
+    }
+    printf("backward ok: expected loss %.3e over %d refined hypotheses\n", out[0], (int)out[1]);
+    hipFree_(d_grad); hipFree_(d_sc); hipFree_(d_assign);
+    free(sc);
+    p_esac_hip_destroy(ctx);
+    return (worst < 1e-5 && (int)res[ESAC_RES_INLIERS] == P && out[0] >= 0 && out[0] < 1e-2) ? 0 : 16;
+}

@@ -16,3 +16,13 @@ def build(force=False):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC",
                                "-shared", SRC, "-o", LIB])
     return LIB
+
+
+def build_abi_check():
+    """gcc -std=c99 build of abi_check.c: the header must be plain C, the library a plain C ABI."""
+    src = os.path.join(HERE, "abi_check.c")
+    exe = os.path.join(HERE, "abi_check")
+    hdr = os.path.join(HERE, "..", "..", "include", "esac_hip.h")
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in (src, hdr)):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-O1", src, "-o", exe, "-ldl"])
+    return exe

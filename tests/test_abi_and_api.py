@@ -161,3 +161,26 @@ def test_product_does_not_import_the_oracle():
                 assert "esac_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
     for f in ("esac.py",):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_header_is_plain_c_and_library_resolves_from_c():
+    """include/esac_hip.h compiles as C99 with -Wall -Wextra -Werror; a C program dlopens libesac_hip.so, resolves the
+    entry points through the header's prototypes and gets the loud no-device failure (no CPU fallback)."""
+    import subprocess
+    from tests.native import build as nb
+    exe = nb.build_abi_check()
+    out = subprocess.run([exe, build.LIB_PATH], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "params 96 bytes" in out.stdout and "no CPU fallback" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_program_runs_forward_and_backward_without_torch():
+    """The same C program on the GPU box: hipMalloc'ed buffers through the HIP runtime's C entry points, one forward
+    and one backward call -- the boundary really is torch-free."""
+    import subprocess
+    from tests.native import build as nb
+    exe = nb.build_abi_check()
+    out = subprocess.run([exe, build.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "forward ok" in out.stdout and "backward ok" in out.stdout

@@ -284,7 +284,7 @@ class Engine:
 # ---------------------------------------------------------------- module-level state
 # The reference keeps a static RNG whose state advances from call to call
 # (thread_rand.cpp:4-5); here that state is (seed, call counter).
-_state = {"seed": 1305, "call": 0, "engines": {}, "last": None, "max_tries": 0, "max_ref_steps": -1}
+_state = {"seed": 1305, "call": 0, "engines": {}, "last": None, "max_tries": 0, "max_ref_steps": -1, "fwd_cache": {}}
 
 
 def set_seed(seed, call=0):
@@ -310,7 +310,8 @@ def engine(device=None):
 
 
 def last_result():
-    """Details of the most recent forward(): scores tensor (device, float64 [N]) and the result record."""
+    """Details of the most recent forward(): scores tensor (device, float64 [N]; a buffer the next call with the same
+    signature overwrites -- clone it to keep it) and the result record."""
     return _state["last"]
 
 
@@ -349,11 +350,22 @@ def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLengt
         lo, hi = int(ha_host_check.min()), int(ha_host_check.max())
         if lo < 0 or hi >= E:
             raise RuntimeError("esac.forward: hypAssignment values must lie in [0,%d), found [%d,%d]" % (E, lo, hi))
-    p = eng.make_params(E, H, W, N, shiftX, shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha,
-                        inlierBeta, maxReproj, subSampling, seed=_state["seed"], call=_state["call"],
-                        max_tries=_state["max_tries"], max_ref_steps=_state["max_ref_steps"])
+    # per call only the RNG key moves: parameter block and score buffer are kept per call signature
+    key = (eng.device.index, E, H, W, N, shiftX, shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha,
+           inlierBeta, maxReproj, subSampling, _state["max_tries"], _state["max_ref_steps"])
+    cached = _state["fwd_cache"].get(key)
+    if cached is None:
+        if len(_state["fwd_cache"]) > 16:
+            _state["fwd_cache"].clear()
+        cached = (eng.make_params(E, H, W, N, shiftX, shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha,
+                                  inlierBeta, maxReproj, subSampling, max_tries=_state["max_tries"],
+                                  max_ref_steps=_state["max_ref_steps"]),
+                  torch.empty(N, dtype=torch.float64, device=eng.device))
+        _state["fwd_cache"][key] = cached
+    p, scores = cached
+    p.seed, p.call = _state["seed"] & (2**64 - 1), _state["call"] & (2**64 - 1)
+    eng._shape = (int(N), int(H), int(W))
     _state["call"] += 1
-    scores = torch.empty(N, dtype=torch.float64, device=eng.device)
     res = eng.forward_device(sceneCoordinates, hypAssignment, p, scores_out=scores)
     pose = torch.from_numpy(res[RES_POSE:RES_POSE + 16].astype(np.float32).reshape(4, 4))
     outPose.copy_(pose)  # in place, caller-owned (esac.cpp:184-187)

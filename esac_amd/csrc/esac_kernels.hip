@@ -8,20 +8,18 @@
 //   K3b k_rescore      reference-arithmetic score of every hypothesis (training path)
 //   K4 k_refine        draw(argmax) + refineHyp + pose2trans       esac_util.h:378-454,505-548
 //
-// Mapping to CDNA4: K1 = one hypothesis per 64-lane wavefront, lane l evaluates
-// sampling try 64*round+l with the whole P3P in fp64 registers, `ballot` picks the
-// lowest accepted try (= the try a sequential loop would stop at).  K2 = one
-// hypothesis per workgroup, the H x W map streamed with 16-byte coalesced loads
-// (x/y/z planes), ~30 fp32 VALU ops per cell, DPP wavefront reductions; no MFMA:
-// there is no dense contraction anywhere on this path.  K4 = one workgroup, LM
-// normal equations reduced with DPP + v_permlane swaps, pose state kept
+// Mapping to CDNA4: K1 = one hypothesis per workgroup, a lane evaluates one sampling try with the whole P3P in fp64
+// registers (single frames: the four candidates of a try on four lanes; thousands of hypotheses: four hypotheses per
+// wavefront for their first 16 tries), `ballot` picks the lowest accepted try (= the try a sequential loop would stop
+// at).  K2 = one hypothesis per workgroup, the H x W map streamed with 16-byte coalesced loads (x/y/z planes), ~30 fp32
+// VALU ops per cell, DPP wavefront reductions; no MFMA: there is no dense contraction anywhere on this path.
+// K4 (esac_refine.hip) = one workgroup, LM normal equations reduced with DPP + v_permlane swaps, pose state kept
 // redundantly in every lane so no broadcast is needed.
 //
-// Precision split: the streaming score (K2) runs in fp32 and only ranks; every
-// hypothesis within `margin` of the fp32 maximum is re-scored by K3b with the
-// reference's exact mixed float/double arithmetic, and the winner is the argmax
-// of those exact scores (first index on ties, esac_util.h:519).  All discrete
-// decisions of refinement (inlier tests, stopping rule) use the exact arithmetic.
+// Precision split: the streaming score (K2) runs in fp32 and only ranks; every hypothesis within `margin` of the fp32
+// maximum is re-scored by K3 with the reference's exact mixed float/double arithmetic, and the winner is the argmax of
+// those exact scores (first index on ties, esac_util.h:519).  All discrete decisions of refinement (inlier tests,
+// stopping rule) use the exact arithmetic.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

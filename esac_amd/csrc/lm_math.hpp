@@ -19,7 +19,9 @@
 namespace esac {
 
 // accumulator layout: 20 upper-triangle entries of the twist normal matrix (entry (3,4) is
-// structurally zero and skipped), 6 gradient entries, 1 squared residual
+// structurally zero and skipped), 6 gradient entries, 1 squared residual.
+// lm_accumulate_point / lm_chain / lm_to_rvec_space are the straightforward entry-by-entry route: the kernels take
+// the moment route further down, the host tests check one against the other and against a numeric Jacobian.
 constexpr int LM_NACC = 27;
 
 template <bool WITH_J>

@@ -111,11 +111,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
+    # test hook (tests/test_gpu_distributed.py): several ranks on ONE device with gloo, to exercise this file's
+    # multi-rank path on a single-GPU box; RCCL itself refuses two ranks on one device
+    one_device = os.environ.get("ESAC_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
     assert args.gpus == world or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     H, W = (int(v) for v in args.grid.split("x"))
@@ -168,7 +176,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     phase /= max(n_phase, 1)

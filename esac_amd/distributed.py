@@ -118,6 +118,17 @@ def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, wor
     return buf
 
 
+def _all_reduce_sum(buf, group):
+    """The one collective.  RCCL ("nccl") reduces the device buffer in place; a gloo group (CPU tests, or several
+    ranks sharing one GPU) gets the 1-2 KB payload staged through the host."""
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+
+
 def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None, policy="range"):
     """Multi-GPU esac_forward: every rank holds `scene_coords` (or at least its experts' maps) and
     the full assignment vector; returns (scores_global [N] f64 device tensor, winning record np[32]).
@@ -136,7 +147,7 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
         # the returned score vector is a view of the persistent buffer: valid until the next call on this device
         buf = contribute_range(engine, scene_coords, ha_full, params_kw, rank, world, _exchange_buffer(dev, n_total, world))
         if world > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)  # the one collective of this path
+            _all_reduce_sum(buf, group)  # the one collective of this path
         return pick_global(buf, n_total, world)
     if policy != "expert":
         raise ValueError(policy)
@@ -155,5 +166,5 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
         record = torch.zeros(RES_DOUBLES, dtype=torch.float64, device=dev)
     buf = pack_local(scores_local, record, n_total, gidx, rank, world)
     if world > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)  # the one collective of this path
+        _all_reduce_sum(buf, group)  # the one collective of this path
     return pick_global(buf, n_total, world)

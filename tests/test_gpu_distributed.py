@@ -71,3 +71,83 @@ def test_range_contributions_of_several_ranks_on_one_device(engine, world):
     np.testing.assert_array_equal(got[flags], full[flags])
     # elsewhere a shard may have re-scored exactly what the full call left at its fp32 score
     np.testing.assert_allclose(got[~flags], full[~flags], rtol=0, atol=2e-3)
+
+
+def _two_rank_worker(rank, world, port, policy, q):
+    """One of `world` processes sharing this box's single GPU: own engine / context, gloo group (RCCL refuses two
+    ranks on one device), the real forward_sharded."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        eng = api.Engine(0)
+        f = S.make_frame(62, E=3, true_expert=1)
+        ha = torch.from_numpy(S.gating_assignment(f, 250, mode="gating")).cuda()
+        sc = torch.from_numpy(f["coords"]).cuda()
+        out = []
+        for call in (20, 21):  # two frames: the persistent exchange buffer is re-zeroed between calls
+            scores_g, best = D.forward_sharded(eng, sc, ha, dict(seed=1305, call=call), policy=policy)
+            out.append((scores_g.cpu().numpy().copy(), best.copy()))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,policy", [(2, "range"), (3, "range"), (2, "expert")])
+def test_forward_sharded_across_processes_on_one_device(engine, world, policy):
+    """The whole multi-rank path as the bench drives it -- forward_sharded in `world` processes, one collective per
+    frame -- with gloo standing in for RCCL: every rank ends with the same winner, and it is the unsharded winner."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, policy, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f = S.make_frame(62, E=3, true_expert=1)
+    ha = torch.from_numpy(S.gating_assignment(f, 250, mode="gating")).cuda()
+    sc = torch.from_numpy(f["coords"]).cuda()
+    for i, call in enumerate((20, 21)):
+        res = engine.forward_device(sc, ha, engine.make_params(3, 60, 80, 250, seed=1305, call=call))
+        for rank in range(world):
+            scores_g, best = results[rank][i]
+            assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]) and int(best[api.RES_EXPERT]) == int(res[api.RES_EXPERT])
+            np.testing.assert_array_equal(best[api.RES_POSE:api.RES_POSE + 16], res[api.RES_POSE:api.RES_POSE + 16])
+            assert best[api.RES_SCORE] == res[api.RES_SCORE]
+            np.testing.assert_array_equal(scores_g, results[0][i][0])  # every rank holds the same global score vector
+
+
+def test_bench_multi_rank_path_on_one_device():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with
+    two ranks sharing the one GPU through the ESAC_BENCH_ONE_DEVICE test hook (gloo instead of RCCL): barrier-bracketed
+    timing, max over ranks, ONE JSON line from rank 0 with the whole-job aggregate."""
+    import json
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ESAC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30",
+                          "--warmup", "4"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["warmup"] == 4 and d["scaling"] == "weak"
+    assert d["config"]["hypotheses_total"] == 512 and d["config"]["hypotheses_per_gpu"] == 256
+    assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "batched" not in d and "cpu_baseline" not in d  # single-GPU extras only

@@ -95,17 +95,23 @@ __device__ __forceinline__ void store_hypothesis(const KArgs& a, int h, const do
 
 constexpr int SAMPLE_PENDING = -2;  // tries[h] between the two phases of the throughput-shaped sampling
 constexpr int FIRST_PHASE_TRIES = 16;
+#ifndef ESAC_FIRST_PHASE_PASSES
+#define ESAC_FIRST_PHASE_PASSES 2
+#endif
+constexpr int FIRST_PHASE_PASSES = ESAC_FIRST_PHASE_PASSES;
 
-// Throughput shape, phase 1: a hypothesis on a usable map is accepted within its first few tries, so a whole
+// Throughput shape, first phases: a hypothesis on a usable map is accepted within its first few tries, so a whole
 // wavefront per hypothesis solves ~60 P3P problems nobody needs.  Here a wavefront serves FOUR hypotheses, 16 tries
-// each (one round); what is not accepted is marked pending and continues in k_sample from try 16 on.
-// two wavefronts per SIMD (256 registers each, ~80 B of spill): the solver is one long dependent fp64 chain per lane
+// each: tries [first_try, first_try + 16).  What is not accepted stays pending for the next pass (launched with
+// first_try + 16) and finally for k_sample, one wavefront per hypothesis.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_first(KArgs a) {
     frame_view(a);
-    const int lane = threadIdx.x, grp = lane >> 4, t = lane & 15;
+    const int lane = threadIdx.x, grp = lane >> 4, t = a.first_try + (lane & 15);
     const int h = blockIdx.x * 4 + grp;
-    const bool active = h < a.N && t < a.max_tries;
     const int hc = h < a.N ? h : a.N - 1;
+    const bool mine_pending = h < a.N && (a.first_try == 0 || a.tries[hc] == SAMPLE_PENDING);
+    if (!__any(mine_pending)) return;  // all four hypotheses of this wavefront are done
+    const bool active = mine_pending && t < a.max_tries;
     const int e = (int)a.assign[hc];
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
@@ -124,13 +130,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     const unsigned long long m = __ballot(accepted);
     const unsigned mine = (unsigned)(m >> (16 * grp)) & 0xffffu;
-    if (h >= a.N) return;
+    if (!mine_pending) return;
     if (mine) {
         const int first = __ffs((int)mine) - 1;
-        if (t == first) store_hypothesis(a, h, rvec, T, R, cx, cy, first);
-    } else if (a.max_tries <= FIRST_PHASE_TRIES) {
+        if ((lane & 15) == first) store_hypothesis(a, h, rvec, T, R, cx, cy, a.first_try + first);
+    } else if (a.max_tries <= a.first_try + FIRST_PHASE_TRIES) {
         if (t == a.max_tries - 1) store_hypothesis(a, h, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
-    } else if (t == 0) {
+    } else if ((lane & 15) == 0) {
         a.tries[h] = SAMPLE_PENDING;
     }
 }
@@ -484,11 +490,13 @@ void launch_sample(const KArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, a);
     else if (total <= 4096)
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, a);
-    else {  // throughput: 16 tries of four hypotheses per wavefront first, the unaccepted rest one wavefront each
-        hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, a);
+    else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest one wavefront each
         KArgs b = a;
-        b.first_try = FIRST_PHASE_TRIES;
-        if (a.max_tries > FIRST_PHASE_TRIES) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
+        for (int pass = 0; pass < FIRST_PHASE_PASSES && b.first_try < a.max_tries; pass++) {
+            hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
+            b.first_try += FIRST_PHASE_TRIES;
+        }
+        if (b.first_try < a.max_tries) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
     }
 }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {

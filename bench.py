@@ -221,10 +221,10 @@ def main():
                          "traffic": (2 * 272.02 + 8.58) * 1024 if default_workload else None,
                          "traffic_source": "profiles/r01_bench_cfg2_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
                          # the same launch as rocprofv3's kernel trace times it (dispatch to completion signal, which for
-                         # a ~3 us kernel adds the command processor's launch and end-of-kernel cache work): 4.57 us in
+                         # a ~3 us kernel adds the command processor's launch and end-of-kernel cache work): 4.51 us in
                          # the committed summary.  `achieved` above uses the device-side span; both are given.
-                         "rocprofv3_kernel_ms": 0.00457 if default_workload else None,
-                         "achieved_at_rocprofv3_duration": alg_bytes / 0.00457e-3 / 1e9 if default_workload else None,
+                         "rocprofv3_kernel_ms": 0.00451 if default_workload else None,
+                         "achieved_at_rocprofv3_duration": alg_bytes / 0.00451e-3 / 1e9 if default_workload else None,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": score_ms,
                          "note": "60x80 grid: 14.7 MB algorithmic per launch, map re-read from L2 by every "

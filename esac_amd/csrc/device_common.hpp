@@ -181,6 +181,10 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     if (a.result_pin) a.result_pin += f * 33;
 }
 
+// expert of hypothesis h.  With a single expert the answer is known without the (dependent, ~0.5 us) load every kernel
+// would otherwise start with; hypAssignment values other than 0 are meaningless there (esac.cpp:189 would return them).
+__device__ __forceinline__ int expert_of(const KArgs& a, int h) { return a.E == 1 ? 0 : (int)a.assign[h]; }
+
 __device__ __forceinline__ Cam make_cam(const KArgs& a) {
     // camMat is a float matrix widened to double by the solver (esac.cpp:93-97)
     return Cam{(double)a.focal, (double)a.focal, (double)a.ppx, (double)a.ppy};

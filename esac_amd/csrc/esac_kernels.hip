@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bool mine_pending = h < a.N && (a.first_try == 0 || a.tries[hc] == SAMPLE_PENDING);
     if (!__any(mine_pending)) return;  // all four hypotheses of this wavefront are done
     const bool active = mine_pending && t < a.max_tries;
-    const int e = (int)a.assign[hc];
+    const int e = expert_of(a, hc);
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
     const Philox rng(a.seed, a.call);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     frame_view(a);
     const int h = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e = (int)a.assign[h];
+    const int e = expert_of(a, h);
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
     const Philox rng(a.seed, a.call);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
     // max(end) - min(start) over its workgroups, on the constant 100 MHz wall clock
     long long t_start = 0;
     if (a.tstamps && threadIdx.x == 0) t_start = wall_clock64();
-    const int e = (int)a.assign[h];
+    const int e = expert_of(a, h);
     const int P = a.H * a.W;
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
     const float* __restrict__ my = mx + P;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
             }
             continue;
         }
-        const int e = (int)a.assign[h];
+        const int e = expert_of(a, h);
         const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
         const double* hp = a.hyps + (size_t)h * 6;
         const double rv[3] = {hp[0], hp[1], hp[2]};
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a) {
     const Cam cam = make_cam(a);
     for (int c = blockIdx.x; c < n; c += gridDim.x) {
         const int h = c;
-        const int e = (int)a.assign[h];
+        const int e = expert_of(a, h);
         const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
         const double* hp = a.hyps + (size_t)h * 6;
         const double rv[3] = {hp[0], hp[1], hp[2]};

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     }
     const int win = SLOTS ? a.bwd.sel[blockIdx.x] : (bi == 0x7fffffff) ? 0 : bi;
     const double win_score = a.scores[win];
-    const int e = (int)a.assign[win];
+    const int e = expert_of(a, win);
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
 
     double pose[6];

@@ -26,6 +26,10 @@ CASES = {
     "ref_bwd_small": dict(kind="backward", frame=dict(k=22, H=24, W=32, sub=20), N=32, loss=dict()),
     "ref_bwd_clamped": dict(kind="backward", frame=dict(k=23, H=24, W=32, sub=20, shift=(3, -2)), N=32,
                             loss=dict(w_rot=2.0, w_trans=50.0, loss_cut=0.5)),
+    "ref_bwd_3experts": dict(kind="backward", frame=dict(k=24, H=24, W=32, sub=20, E=3, true_expert=2), N=48, mode="gating",
+                             loss=dict(), params=dict(inlier_alpha=10.0)),
+    "ref_fwd_params": dict(kind="forward", frame=dict(k=25, H=27, W=35, sub=18, shift=(-4, 5)), N=40,
+                           params=dict(inlier_thresh=6.0, inlier_alpha=50.0, inlier_beta=0.8, max_reproj=60.0)),
 }
 
 
@@ -48,8 +52,12 @@ def main():
         f = S.make_frame(**c["frame"])
         ha = S.gating_assignment(f, c["N"], mode=c.get("mode", "single"))
         kw = dict(shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"])
+        kw.update(c.get("params", {}))
+        params = dict(inlier_thresh=10.0, inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0)
+        params.update(c.get("params", {}))
         out = dict(coords=f["coords"], assign=ha, focal=np.float32(f["focal"]), ppx=np.float32(f["ppx"]), ppy=np.float32(f["ppy"]),
-                   sub=np.int32(f["sub"]), shift=np.array(f["shift"], np.int32), kind=c["kind"])
+                   sub=np.int32(f["sub"]), shift=np.array(f["shift"], np.int32), kind=c["kind"],
+                   **{k: np.float32(v) for k, v in params.items()})
         if c["kind"] == "forward":
             expert, pose = R.esac_forward(f["coords"], ha, seed=SEED, **kw)          # the reference's esac_forward
             staged = R.forward(f["coords"], ha, seed=SEED, **kw)                     # its stages, same stream

@@ -22,13 +22,17 @@ def _replayer(draws):
 
 
 def _kw(g):
-    return dict(shift_x=int(g["shift"][0]), shift_y=int(g["shift"][1]), focal=float(g["focal"]), ppx=float(g["ppx"]),
-                ppy=float(g["ppy"]), sub_sampling=int(g["sub"]))
+    kw = dict(shift_x=int(g["shift"][0]), shift_y=int(g["shift"][1]), focal=float(g["focal"]), ppx=float(g["ppx"]),
+              ppy=float(g["ppy"]), sub_sampling=int(g["sub"]))
+    for k in ("inlier_thresh", "inlier_alpha", "inlier_beta", "max_reproj"):
+        if k in g.files:
+            kw[k] = float(g[k])
+    return kw
 
 
 def test_reference_fixtures_exist():
     kinds = sorted(str(np.load(p)["kind"]) for p in FIXTURES)
-    assert kinds.count("forward") >= 2 and kinds.count("backward") >= 2
+    assert kinds.count("forward") >= 3 and kinds.count("backward") >= 3
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])

@@ -58,6 +58,15 @@ __device__ __forceinline__ bool accept_sample(const double Rp[9], const double T
     return accepted;
 }
 
+// A solved sample whose 4th point already misses tau by a clear margin under the chosen candidate cannot pass the
+// acceptance test: the stored pose differs from the candidate only by the rvec round trip (~1e-12 px) and the
+// reference's float rounding of the projection (< 1e-4 px).  Such a try needs neither the matrix->vector->matrix
+// conversion nor the four reprojections -- unless it is the LAST try of the budget, whose state must remain.
+__device__ __forceinline__ bool cannot_pass(double reproj2, double tau) {
+    const double lim = tau + 0.01;
+    return reproj2 > lim * lim;  // NaN: false -> the full test decides
+}
+
 // the 4 cells of try t of hypothesis gh, their scene points and pixel positions
 __device__ __forceinline__ void gather_sample(const KArgs& a, const float* __restrict__ map, int P, const Philox& rng, uint32_t gh,
                                               uint32_t t, int (&cx)[4], int (&cy)[4], V3 (&Pt)[4], float (&Pf)[4][3],
@@ -126,7 +135,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         float Pf[4][3];
         double mu[4], mv[4], Rp[9], Tp[3];
         gather_sample(a, map, P, rng, (uint32_t)global_hyp(a, hc), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-        if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp)) accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
+        double reproj2 = 0;
+        if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2) && (t == a.max_tries - 1 || !cannot_pass(reproj2, (double)a.tau)))
+            accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
     }
     const unsigned long long m = __ballot(accepted);
     const unsigned mine = (unsigned)(m >> (16 * grp)) & 0xffffu;
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             float Pf[4][3];
             double mu[4], mv[4];
             gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-            double Rp[9], Tp[3];
+            double Rp[9], Tp[3], reproj2 = 0;
             bool solved;
             if (QUAD && quad) {
                 P3PSetup S;
@@ -206,10 +217,12 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
                 }
                 solved = have && win == root;
                 holder = solved || (!have && root == 0);
+                reproj2 = min_reproj;
             } else {
-                solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp);
+                solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2);
             }
-            if (solved) accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, tau, rvec, T, R);
+            if (solved && (t == a.max_tries - 1 || !cannot_pass(reproj2, tau)))
+                accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, tau, rvec, T, R);
             // a failed solve leaves the zero pose (safeSolvePnP, esac_util.h:107-111)
         }
         // lowest accepted try of the round = the try the reference's sequential loop stops at

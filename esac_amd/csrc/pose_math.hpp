@@ -485,7 +485,7 @@ ESAC_HD bool p3p_candidate(const P3PSetup& S, double x, const V3 P[4], const dou
 
 // obj: 4 scene points, img: 4 pixel positions.  Returns false when there is no solution.
 ESAC_HD bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4], const Cam& cam,
-                                        double Rbest[9], double Tbest[3]) {
+                                        double Rbest[9], double Tbest[3], double* best_reproj = nullptr) {
     P3PSetup S;
     if (!p3p_setup(P, mu_px, mv_px, cam, S)) return false;
     bool have = false;
@@ -505,6 +505,7 @@ ESAC_HD bool p3p_4pt(const V3 P[4], const double mu_px[4], const double mv_px[4]
             Tbest[0] = T[0]; Tbest[1] = T[1]; Tbest[2] = T[2];
         }
     }
+    if (best_reproj) *best_reproj = min_reproj;  // squared pixel error of the 4th point under the chosen candidate
     return have;
 }
 

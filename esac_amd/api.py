@@ -35,8 +35,10 @@ ABI_SYMBOLS = [
     "esac_hip_abi_version", "esac_hip_last_error", "esac_hip_device_count", "esac_hip_create", "esac_hip_destroy",
     "esac_hip_forward", "esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine",
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
-    "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug",
+    "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug", "esac_hip_check",
 ]
+ABI_VERSION = 2
+FLAG_EXACT_SCORES = 1
 
 
 class Params(C.Structure):
@@ -51,6 +53,7 @@ class Params(C.Structure):
         ("max_tries", C.c_int32), ("max_ref_steps", C.c_int32), ("hyp_offset", C.c_int32),
         ("rescore_margin", C.c_float),
         ("d_hyp_index", C.c_void_p),
+        ("flags", C.c_int32),
     ]
 
 
@@ -88,11 +91,12 @@ def load_library():
         lib.esac_hip_set_timing.argtypes = [vp, i32]
         lib.esac_hip_set_debug.argtypes = [vp, i32]
         lib.esac_hip_score_span_ms.argtypes = [vp, vp, vp]
+        lib.esac_hip_check.argtypes = [vp]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
                 getattr(lib, name).restype = i32
         lib.esac_hip_last_error.restype = C.c_char_p
-        if lib.esac_hip_abi_version() != 1:
+        if lib.esac_hip_abi_version() != ABI_VERSION:
             raise RuntimeError("esac: libesac_hip.so ABI version mismatch")
         _lib = lib
         return lib
@@ -139,7 +143,7 @@ class Engine:
 
     def make_params(self, E, H, W, N, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
                     inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0,
-                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0):
+                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0, exact_scores=False):
         p = Params()
         p.E, p.H, p.W, p.N = int(E), int(H), int(W), int(N)
         p.shift_x, p.shift_y = int(shift_x), int(shift_y)
@@ -150,6 +154,7 @@ class Engine:
         p.max_tries, p.max_ref_steps, p.hyp_offset = int(max_tries), int(max_ref_steps), int(hyp_offset)
         p.rescore_margin = float(rescore_margin)
         p.d_hyp_index = None
+        p.flags = FLAG_EXACT_SCORES if exact_scores else 0
         self._shape = (int(N), int(H), int(W))
         return p
 
@@ -262,6 +267,10 @@ class Engine:
         _check(self.lib.esac_hip_read(self.ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes), self.lib)
         return out
 
+    def check(self):
+        """Waits for the device; raises if the most recent (asynchronous) call met an out-of-range hypAssignment."""
+        _check(self.lib.esac_hip_check(self.ctx), self.lib)
+
     def set_debug(self, keep_error_image=False):
         _check(self.lib.esac_hip_set_debug(self.ctx, 1 if keep_error_image else 0), self.lib)
 
@@ -284,7 +293,8 @@ class Engine:
 # ---------------------------------------------------------------- module-level state
 # The reference keeps a static RNG whose state advances from call to call
 # (thread_rand.cpp:4-5); here that state is (seed, call counter).
-_state = {"seed": 1305, "call": 0, "engines": {}, "last": None, "max_tries": 0, "max_ref_steps": -1, "fwd_cache": {}}
+_state = {"seed": 1305, "call": 0, "engines": {}, "last": None, "max_tries": 0, "max_ref_steps": -1, "fwd_cache": {},
+          "exact_scores": False}
 
 
 def set_seed(seed, call=0):
@@ -299,6 +309,12 @@ def get_rng_state():
 def set_limits(max_tries=0, max_ref_steps=-1):
     """Override MAX_SAMPLING_TRIES / MAX_REF_STEPS (esac.cpp:44-45); 0 / -1 restore the reference values."""
     _state["max_tries"], _state["max_ref_steps"] = int(max_tries), int(max_ref_steps)
+
+
+def set_exact_scores(on):
+    """True: every hypothesis is scored in the reference's arithmetic (ESAC_FLAG_EXACT_SCORES), so the score vector of
+    last_result() and the record's probability / entropy are the reference's own values; the pose is the same either way."""
+    _state["exact_scores"] = bool(on)
 
 
 def engine(device=None):
@@ -350,19 +366,22 @@ def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLengt
         lo, hi = int(ha_host_check.min()), int(ha_host_check.max())
         if lo < 0 or hi >= E:
             raise RuntimeError("esac.forward: hypAssignment values must lie in [0,%d), found [%d,%d]" % (E, lo, hi))
-    # per call only the RNG key moves: parameter block and score buffer are kept per call signature
-    key = (eng.device.index, E, H, W, N, shiftX, shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha,
-           inlierBeta, maxReproj, subSampling, _state["max_tries"], _state["max_ref_steps"])
+    # parameter block and score buffer are kept per SHAPE; the scalar fields are rewritten per call (a per-frame focal
+    # length -- Aachen, Dubrovnik -- must not evict anything)
+    key = (eng.device.index, E, H, W, N)
     cached = _state["fwd_cache"].get(key)
     if cached is None:
         if len(_state["fwd_cache"]) > 16:
             _state["fwd_cache"].clear()
-        cached = (eng.make_params(E, H, W, N, shiftX, shiftY, focalLength, ppointX, ppointY, inlierThreshold, inlierAlpha,
-                                  inlierBeta, maxReproj, subSampling, max_tries=_state["max_tries"],
-                                  max_ref_steps=_state["max_ref_steps"]),
-                  torch.empty(N, dtype=torch.float64, device=eng.device))
+        cached = (eng.make_params(E, H, W, N), torch.empty(N, dtype=torch.float64, device=eng.device))
         _state["fwd_cache"][key] = cached
     p, scores = cached
+    p.shift_x, p.shift_y = int(shiftX), int(shiftY)
+    p.focal, p.ppx, p.ppy = float(focalLength), float(ppointX), float(ppointY)
+    p.inlier_thresh, p.inlier_alpha, p.inlier_beta = float(inlierThreshold), float(inlierAlpha), float(inlierBeta)
+    p.max_reproj, p.sub_sampling = float(maxReproj), int(subSampling)
+    p.max_tries, p.max_ref_steps = int(_state["max_tries"]), int(_state["max_ref_steps"])
+    p.flags = FLAG_EXACT_SCORES if _state["exact_scores"] else 0
     p.seed, p.call = _state["seed"] & (2**64 - 1), _state["call"] & (2**64 - 1)
     eng._shape = (int(N), int(H), int(W))
     _state["call"] += 1

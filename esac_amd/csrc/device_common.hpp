@@ -178,12 +178,24 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     a.tstamps = nullptr;  // the span measurement follows frame 0 only
     if (a.scores_user) a.scores_user += f * N;
     if (a.result_user) a.result_user += f * 32;
-    if (a.result_pin) a.result_pin += f * 33;
+    if (a.result_pin) a.result_pin += f * ESAC_PIN_DOUBLES;
 }
 
 // expert of hypothesis h.  With a single expert the answer is known without the (dependent, ~0.5 us) load every kernel
 // would otherwise start with; hypAssignment values other than 0 are meaningless there (esac.cpp:189 would return them).
-__device__ __forceinline__ int expert_of(const KArgs& a, int h) { return a.E == 1 ? 0 : (int)a.assign[h]; }
+// A value outside [0,E) (the reference would index out of bounds, esac_util.h:183; only a device-resident assignment can
+// get this far, the host API range-checks CPU tensors) is mapped to expert 0 here -- never an out-of-bounds read -- and
+// reported by the sampling kernel through KArgs::status (flag_bad_assignment), which the host turns into an error.
+__device__ __forceinline__ int expert_of(const KArgs& a, int h) {
+    if (a.E == 1) return 0;
+    const long long e = a.assign[h];
+    return (unsigned long long)e < (unsigned long long)a.E ? (int)e : 0;
+}
+__device__ __forceinline__ void flag_bad_assignment(const KArgs& a, int h) {
+    if (a.E == 1) return;
+    const long long e = a.assign[h];
+    if ((unsigned long long)e >= (unsigned long long)a.E) atomicMax(a.status, (unsigned long long)a.epoch);
+}
 
 __device__ __forceinline__ Cam make_cam(const KArgs& a) {
     // camMat is a float matrix widened to double by the solver (esac.cpp:93-97)
@@ -194,6 +206,21 @@ __device__ __forceinline__ Cam make_cam(const KArgs& a) {
 __device__ __forceinline__ int global_hyp(const KArgs& a, int h) { return a.hyp_index ? a.hyp_index[h] : a.hyp_offset + h; }
 __device__ __forceinline__ float cell_px(const KArgs& a, int x) { return (float)(x * a.sub + a.sub / 2 - a.shift_x); }
 __device__ __forceinline__ float cell_py(const KArgs& a, int y) { return (float)(y * a.sub + a.sub / 2 - a.shift_y); }
+
+// Origin of the fp32 scoring stream for one expert's map: the scene point of the middle cell (0 when it is not finite).
+// The stream evaluates R*(X - c) + (t + R*c) with the second term formed in double when the hypothesis is stored, so its
+// rounding error scales with the extent of the scene around c, not with the distance of the scene from the world origin
+// (world-frame maps of outdoor scenes sit ~1e3 m out: float(t) alone would shift every projection by ~1e-2 px).
+struct Centre {
+    float x, y, z;
+};
+__device__ __forceinline__ Centre map_centre(const KArgs& a, const float* __restrict__ map) {
+    const int P = a.H * a.W, mid = (a.H >> 1) * a.W + (a.W >> 1);
+    Centre c{map[mid], map[P + mid], map[2 * P + mid]};
+    const bool ok = fabsf(c.x) <= 3.0e38f && fabsf(c.y) <= 3.0e38f && fabsf(c.z) <= 3.0e38f;  // false for NaN / inf
+    if (!ok) c = Centre{0.0f, 0.0f, 0.0f};
+    return c;
+}
 
 
 }  // namespace esac

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(B) void k_bwd_select(KArgs a) {
     block_sum<2, B>(acc, s_part, s_tot);
     if (threadIdx.x == 0) {
         a.bwd.n_sel[0] = s_base < a.bwd.cap ? s_base : a.bwd.cap;
+        a.bwd.n_sel[1] = s_base;  // unclamped: > cap tells the host to grow the slot workspace and run the call again
         a.stats[0] = m;
         a.stats[1] = sum;
         a.stats[2] = acc[0];
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(B) void k_bwd_loss(KArgs a) {
     }
     if (threadIdx.x == 0) {
         a.bwd.out[0] = expected;
-        a.bwd.out[1] = (double)n_sel;
+        a.bwd.out[1] = (double)a.bwd.n_sel[1];
         a.bwd.out[2] = a.stats[2];
-        a.bwd.out[3] = 0;
+        a.bwd.out[3] = (a.status[0] == (unsigned long long)a.epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment (k_sample)
     }
 }
 
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(B) void k_bwd_path1(KArgs a) {
         return;
     }
     const uint8_t* __restrict__ map = a.bwd.maps + ((size_t)slot * 2 + buf) * P;
-    const int e = (int)a.assign[h];
+    const int e = expert_of(a, h);
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
     const Cam cam = make_cam(a);
     const double* hp = a.bwd.ref_hyps + (size_t)h * 6;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(B) void k_bwd_path2(KArgs a) {
     const int h = a.bwd.sel[slot];
     const int P = a.H * a.W;
     double* __restrict__ g = a.bwd.grad2 + (size_t)slot * P * 3;
-    const int e = (int)a.assign[h];
+    const int e = expert_of(a, h);
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
     const Cam cam = make_cam(a);
     const int* sxy = a.sample_xy + (size_t)h * 8;
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(256) void k_bwd_accumulate(KArgs a) {
     const int P = a.H * a.W;
     const int e = blockIdx.y;
     const int n_sel = a.bwd.n_sel[0];
+    if (a.bwd.n_sel[1] > a.bwd.cap) return;  // more slots than the workspace holds: nothing is accumulated, the host grows it and retries
     if (threadIdx.x < 64) {
         int count = 0;
         for (int base = 0; base < n_sel; base += 64) {
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void k_bwd_accumulate(KArgs a) {
             bool mine = false;
             if (slot < n_sel) {
                 h = a.bwd.sel[slot];
-                mine = (int)a.assign[h] == e;
+                mine = expert_of(a, h) == e;
             }
             const unsigned long long bal = __ballot(mine);
             if (mine) {

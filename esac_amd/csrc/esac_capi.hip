@@ -38,6 +38,22 @@ static int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(-100 - (int)_e, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+// Makes the context's GPU current for the duration of one entry point and restores the caller's device afterwards
+// (torch and every other runtime user read the same thread-local "current device").
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) == hipSuccess && cur != dev) prev = cur;
+        if (cur != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct esac_hip_ctx {
     int device = 0;
     int capN = 0, capP = 0, capB = 0;  // capN / capP count elements over ALL frames of a batch
@@ -55,6 +71,7 @@ struct esac_hip_ctx {
     BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
     int bN = 0, bP = 0, bcap = 0;
     bool b_lists = false;
+    bool rt32_stale = false;  // esac_hip_write_hyps ran: the fp32 [R|t] rows are rebuilt by the next esac_hip_score
 };
 
 extern "C" int esac_hip_abi_version(void) { return ESAC_HIP_ABI_VERSION; }
@@ -68,7 +85,8 @@ extern "C" int esac_hip_device_count(void) {
 static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.stats,
-                    c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc};
+                    c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
+                    c->ws.status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws = KArgs{};
@@ -83,12 +101,12 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
         return fail(-2, "esac_hip_create: no HIP device available (%s); this library has no CPU fallback",
                     e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
     if (device < 0 || device >= n) return fail(-3, "esac_hip_create: device %d out of range [0,%d)", device, n);
-    HIP_OK(hipSetDevice(device));
+    DeviceGuard guard(device);
     esac_hip_ctx* c = new esac_hip_ctx();
     c->device = device;
     for (auto& ev : c->ev) HIP_OK(hipEventCreate(&ev));
-    HIP_OK(hipHostMalloc((void**)&c->h_pin, (size_t)33 * ESAC_MAX_BATCH * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
-    memset(c->h_pin, 0, (size_t)33 * ESAC_MAX_BATCH * sizeof(double));
+    HIP_OK(hipHostMalloc((void**)&c->h_pin, (size_t)ESAC_PIN_DOUBLES * ESAC_MAX_BATCH * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->h_pin, 0, (size_t)ESAC_PIN_DOUBLES * ESAC_MAX_BATCH * sizeof(double));
     HIP_OK(hipHostGetDevicePointer((void**)&c->d_pin, c->h_pin, 0));
     *out = c;
     return 0;
@@ -106,7 +124,7 @@ static void free_bws(esac_hip_ctx* c) {
 
 extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     if (!c) return 0;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     free_ws(c);
     free_bws(c);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
@@ -129,10 +147,17 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     HIP_OK(hipDeviceSynchronize());
     const int nN = N > c->capN ? (int)N : c->capN, nP = P > c->capP ? (int)P : c->capP;
     const int nB = B > c->capB ? B : c->capB;
+    // hypotheses handed in through esac_hip_write_hyps (and the status word) survive a growing workspace
+    double* old_hyps = c->ws.hyps;
+    const size_t old_n = (size_t)c->capN;
+    unsigned long long old_status = 0;
+    if (c->ws.status) HIP_OK(hipMemcpy(&old_status, c->ws.status, sizeof(old_status), hipMemcpyDeviceToHost));
+    c->ws.hyps = nullptr;
     free_ws(c);
     int rc = 0;
     rc |= alloc(&c->ws.hyps, (size_t)nN * 6);
     rc |= alloc(&c->ws.rt32, (size_t)nN * 12);
+    rc |= alloc(&c->ws.status, (size_t)1);
     rc |= alloc(&c->ws.sample_xy, (size_t)nN * 8);
     rc |= alloc(&c->ws.tries, (size_t)nN);
     rc |= alloc(&c->ws.fast_scores, (size_t)nN);
@@ -152,9 +177,17 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.cycles, (size_t)32);
     rc |= alloc(&c->ws.tstamps, (size_t)nN * 2);
     rc |= alloc(&c->ws.span_acc, (size_t)2);
-    if (rc) return rc;
+    if (rc) {
+        if (old_hyps) (void)hipFree(old_hyps);
+        return rc;
+    }
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
     HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
+    HIP_OK(hipMemcpy(c->ws.status, &old_status, sizeof(old_status), hipMemcpyHostToDevice));
+    if (old_hyps) {
+        if (old_n) HIP_OK(hipMemcpy(c->ws.hyps, old_hyps, old_n * 6 * sizeof(double), hipMemcpyDeviceToDevice));
+        (void)hipFree(old_hyps);
+    }
     HIP_OK(hipMemset(c->ws.result, 0, (size_t)ESAC_RES_DOUBLES * nB * sizeof(double)));
     HIP_OK(hipMemset(c->ws.n_contenders, 0, (size_t)4 * nB * sizeof(int)));
     c->capN = nN;
@@ -172,10 +205,17 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     if (p->E <= 0 || p->N <= 0) return fail(-4, "E=%d, N=%d must be positive", p->E, p->N);
     if (p->H < 3 || p->W < 3 || (int64_t)(p->H - 1) * (p->W - 1) < 4)
         return fail(-4, "grid %dx%d too small: 4 distinct cells must exist in [0,W-2]x[0,H-2] (esac_util.h:164-176)", p->H, p->W);
-    if ((int64_t)p->H * p->W > (int64_t)1 << 28) return fail(-4, "grid %dx%d too large", p->H, p->W);
+    if ((int64_t)p->H * p->W > (int64_t)1 << 28 || p->H > 65535 || p->W > 65535)
+        return fail(-4, "grid %dx%d too large (at most 65535 rows / columns, 2^28 cells)", p->H, p->W);
     if (p->sub_sampling <= 0) return fail(-4, "subSampling=%d must be positive", p->sub_sampling);
+    {   // pixel centres col*sub + sub/2 - shift (esac_util.h:64-66) are formed in int32 on the device
+        const int64_t lim = 0x7fffffffLL, half = p->sub_sampling / 2;
+        const int64_t xs[4] = {half - p->shift_x, (int64_t)(p->W - 1) * p->sub_sampling + half - p->shift_x,
+                               half - p->shift_y, (int64_t)(p->H - 1) * p->sub_sampling + half - p->shift_y};
+        for (int64_t v : xs)
+            if (v > lim || v < -lim) return fail(-4, "pixel positions overflow int32 (subSampling=%d, shift=(%d,%d))", p->sub_sampling, p->shift_x, p->shift_y);
+    }
     if (!(p->focal > 0)) return fail(-4, "focal length must be positive");
-    HIP_OK(hipSetDevice(c->device));
     const int P = p->H * p->W;
     if (B < 1 || B > ESAC_MAX_BATCH) return fail(-4, "batch size %d outside [1,%d]", B, ESAC_MAX_BATCH);
     int rc = ensure_ws(c, p->N, P, B);
@@ -195,9 +235,15 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
                                             : ESAC_MAX_REF_STEPS;
     a.hyp_offset = p->hyp_offset;
     a.hyp_index = p->d_hyp_index;
+    a.flags = p->flags;
+    c->epoch += 1.0;  // every call gets its own epoch: result hand-off word and the tag of the status word
+    a.epoch = c->epoch;
     // (device-side span stamps only on sampled calls in timing mode: forward_impl clears tstamps otherwise)
     if (!c->keep_errs) a.errs = nullptr;
-    a.margin = p->rescore_margin > 0 ? p->rescore_margin : fabsf(p->inlier_alpha) * ESAC_DEFAULT_MARGIN;
+    // band of the fp32 maximum that is re-scored exactly: the stream's rounding (<= 2e-5 * alpha measured) plus two
+    // cells' weight -- an ill-conditioned projection (scene point next to the camera centre) can put a cell on the other
+    // side of tau under fp32, which moves a score by alpha / (H*W); on small grids that exceeds alpha * 1e-3
+    a.margin = p->rescore_margin > 0 ? p->rescore_margin : fabsf(p->inlier_alpha) * (ESAC_DEFAULT_MARGIN + 2.0f / (float)P);
     c->lastN = p->N; c->lastH = p->H; c->lastW = p->W;
     *out = a;
     return 0;
@@ -209,45 +255,52 @@ static int check_launch(const char* what) {
     return 0;
 }
 
-extern "C" int esac_hip_sample(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
+// stage entry points: validate, make the context's GPU current, launch one phase on the caller's stream
+template <typename Launch>
+static int run_stage(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream,
+                     const char* what, Launch launch) {
+    if (!c) return fail(-1, "null context");
+    DeviceGuard guard(c->device);
     KArgs a;
     int rc = make_args(c, d_sc, d_assign, p, &a);
     if (rc) return rc;
-    launch_sample(a, (hipStream_t)stream);
-    return check_launch("k_sample");
+    launch(c, a, (hipStream_t)stream);
+    return check_launch(what);
+}
+extern "C" int esac_hip_sample(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
+    return run_stage(c, d_sc, d_assign, p, stream, "k_sample", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) {
+        cc->rt32_stale = false;
+        launch_sample(a, s);
+    });
 }
 extern "C" int esac_hip_score(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    KArgs a;
-    int rc = make_args(c, d_sc, d_assign, p, &a);
-    if (rc) return rc;
-    launch_score_fast(a, (hipStream_t)stream);
-    return check_launch("k_score_fast");
+    return run_stage(c, d_sc, d_assign, p, stream, "k_score_fast", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) {
+        if (cc->rt32_stale) {  // hypotheses came from esac_hip_write_hyps: their fp32 [R|t] rows need the maps' origins
+            launch_hyps_to_rt32(a, s);
+            cc->rt32_stale = false;
+        }
+        launch_score(a, s);
+    });
 }
 extern "C" int esac_hip_select(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    KArgs a;
-    int rc = make_args(c, d_sc, d_assign, p, &a);
-    if (rc) return rc;
-    launch_select_rescore(a, (hipStream_t)stream);
-    return check_launch("k_select_rescore");
+    return run_stage(c, d_sc, d_assign, p, stream, "k_select_rescore",
+                     [](esac_hip_ctx*, const KArgs& a, hipStream_t s) { launch_select_rescore(a, s); });
 }
 extern "C" int esac_hip_refine(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    KArgs a;
-    int rc = make_args(c, d_sc, d_assign, p, &a);
-    if (rc) return rc;
-    launch_refine(a, (hipStream_t)stream);
-    return check_launch("k_refine");
+    return run_stage(c, d_sc, d_assign, p, stream, "k_refine", [](esac_hip_ctx*, const KArgs& a, hipStream_t s) { launch_refine(a, s); });
 }
 extern "C" int esac_hip_score_exact(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    KArgs a;
-    int rc = make_args(c, d_sc, d_assign, p, &a);
-    if (rc) return rc;
-    launch_rescore_all(a, (hipStream_t)stream);
-    return check_launch("k_rescore(all)");
+    return run_stage(c, d_sc, d_assign, p, stream, "k_rescore(all)", [](esac_hip_ctx*, const KArgs& a, hipStream_t s) {
+        launch_rescore_all(a, s);
+        launch_stats_exact(a, s);  // softmax statistics of the exact scores (the record's probability / entropy)
+    });
 }
 
 static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_stride, const int64_t* d_assign,
                         const esac_hip_params* p, int B, void* stream, double* d_scores_out, double* d_result_out,
                         double* h_result_out) {
+    if (!c) return fail(-1, "null context");
+    DeviceGuard guard(c->device);
     KArgs a;
     int rc = make_args(c, d_sc, d_assign, p, &a, B, sc_frame_stride);
     if (rc) return rc;
@@ -255,20 +308,24 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     a.scores_user = d_scores_out;
     a.result_user = d_result_out;
     a.result_pin = h_result_out ? c->d_pin : nullptr;
-    c->epoch += 1.0;
-    a.epoch = c->epoch;
     // events and stamps cost GPU time themselves (an empty event pair reads ~5 us): sample every timing_period-th call
     const bool tm = c->timing && (c->timing_calls++ % c->timing_period) == 0;
     if (!tm) a.tstamps = nullptr;
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
+    c->rt32_stale = false;
     launch_sample(a, s);
     if ((rc = check_launch("k_sample"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[1], s));
-    launch_score_fast(a, s);
-    if ((rc = check_launch("k_score_fast"))) return rc;
+    const bool exact = (a.flags & ESAC_FLAG_EXACT_SCORES) != 0;
+    // ESAC_FLAG_EXACT_SCORES: every hypothesis scored in the reference's arithmetic (esac_util.h:235-260), softmax
+    // statistics from those scores -- the score vector, probability and entropy are then the reference's own values
+    if (exact) launch_rescore_all(a, s);
+    else       launch_score(a, s);
+    if ((rc = check_launch(exact ? "k_rescore(all)" : "k_score_fast"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[2], s));
-    launch_select_rescore(a, s);
-    if ((rc = check_launch("k_select_rescore"))) return rc;
+    if (exact) launch_stats_exact(a, s);
+    else       launch_select_rescore(a, s);
+    if ((rc = check_launch(exact ? "k_stats_exact" : "k_select_rescore"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
     launch_refine(a, s);
     if ((rc = check_launch("k_refine"))) return rc;
@@ -282,11 +339,11 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     }
     if (h_result_out) {
         // the refinement kernel stores the record and then the epoch word into pinned host memory
-        // (one 33-double slot per frame: record + epoch word)
+        // (one ESAC_PIN_DOUBLES slot per frame: record, epoch word, status word)
         const double want = c->epoch;
         auto all_landed = [&]() {
             for (int b = 0; b < B; b++)
-                if (*(volatile double*)(c->h_pin + (size_t)b * 33 + 32) != want) return false;
+                if (*(volatile double*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES + 32) != want) return false;
             return true;
         };
         bool landed = false;
@@ -305,9 +362,14 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             if (!all_landed()) return fail(-9, "esac_hip_forward: the refinement kernel did not deliver a result record");
         }
         __sync_synchronize();
-        for (int b = 0; b < B; b++)
-            memcpy(h_result_out + (size_t)b * ESAC_RES_DOUBLES, (const void*)(c->h_pin + (size_t)b * 33),
+        bool bad_assign = false;
+        for (int b = 0; b < B; b++) {
+            memcpy(h_result_out + (size_t)b * ESAC_RES_DOUBLES, (const void*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES),
                    ESAC_RES_DOUBLES * sizeof(double));
+            bad_assign |= c->h_pin[(size_t)b * ESAC_PIN_DOUBLES + 33] != 0.0;
+        }
+        if (bad_assign)
+            return fail(-10, "hypAssignment holds a value outside [0,%d) (device-resident tensor; such hypotheses were scored against expert 0)", p->E);
     }
     return 0;
 }
@@ -324,8 +386,8 @@ extern "C" int esac_hip_forward_batch(esac_hip_ctx* c, int B, const float* d_sc,
 }
 
 // ---------------------------------------------------------------- training path
-static int ensure_bws(esac_hip_ctx* c, int N, int P) {
-    const int cap = N < ESAC_BWD_MAX_SLOTS ? N : ESAC_BWD_MAX_SLOTS;
+// `cap` = slots (hypotheses with p >= PROB_THRESH) the slab workspace must hold; it only ever grows
+static int ensure_bws(esac_hip_ctx* c, int N, int P, int cap) {
     const bool lists = P > ESAC_REFINE_LDS_CAP;
     if (N <= c->bN && P <= c->bP && cap <= c->bcap && (!lists || c->b_lists)) return 0;
     HIP_OK(hipDeviceSynchronize());
@@ -339,9 +401,10 @@ static int ensure_bws(esac_hip_ctx* c, int N, int P) {
     rc |= alloc(&c->bws.losses, (size_t)nN);
     rc |= alloc(&c->bws.ref_hyps, (size_t)nN * 6);
     rc |= alloc(&c->bws.sgrad, (size_t)nN);
-    rc |= alloc(&c->bws.dloss, (size_t)ncap * 6);
+    const size_t rows = (size_t)(nN < ESAC_BWD_MAX_SLOTS ? nN : ESAC_BWD_MAX_SLOTS);  // small per-slot tables: worst case
+    rc |= alloc(&c->bws.dloss, rows * 6);
     rc |= alloc(&c->bws.maps, (size_t)ncap * 2 * nP);
-    rc |= alloc(&c->bws.map_info, (size_t)ncap * 4);
+    rc |= alloc(&c->bws.map_info, rows * 4);
     if (nlists) {
         char* cl = nullptr;
         rc |= alloc(&cl, (size_t)ncap * ((size_t)nP + 2048) * 16);  // corr_entries(P) < P + 2048 per slot
@@ -417,6 +480,8 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
                                  const float* h_gt_pose, float w_loss_rot, float w_loss_trans, float loss_cut,
                                  const esac_hip_params* p, void* stream, double* h_out) {
     if (!d_out_gradients || !h_gt_pose) return fail(-1, "esac_hip_backward: null gradient tensor or ground-truth pose");
+    if (!c) return fail(-1, "null context");
+    DeviceGuard guard(c->device);
     KArgs a;
     int rc = make_args(c, d_sc, d_assign, p, &a);
     if (rc) return rc;
@@ -424,48 +489,81 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
     if (p->d_hyp_index || p->hyp_offset)
         return fail(-4, "esac_hip_backward: sharded calls are not supported (the expectation needs every hypothesis)");
     const int P = p->H * p->W;
-    if ((rc = ensure_bws(c, p->N, P))) return rc;
-    a.bwd = c->bws;
-    a.bwd.cap = p->N < ESAC_BWD_MAX_SLOTS ? p->N : ESAC_BWD_MAX_SLOTS;
-    a.bwd.out_grad = d_out_gradients;
-    a.bwd.w_rot = (double)w_loss_rot;
-    a.bwd.w_trans = (double)w_loss_trans;
-    a.bwd.cut = (double)loss_cut;
-    double Ti[16];
-    for (int i = 0; i < 16; i++) a.bwd.gt[i] = (double)h_gt_pose[i];
-    if (!inv4_host(a.bwd.gt, Ti)) return fail(-4, "esac_hip_backward: the ground-truth pose is singular");
+    // Slot workspace (two 3P-double slabs + two inlier maps per slot).  How many hypotheses reach PROB_THRESH is only
+    // known on the device: a blocking call starts from what earlier calls needed (at least 64 slots) and, when the
+    // selection overflows it, grows the workspace and runs selection..accumulation again -- the accumulation kernel
+    // adds nothing on overflow, so the caller's tensor is untouched by the aborted pass.  An asynchronous call
+    // (h_out == NULL) cannot look at the count and reserves the worst case min(N, 1000).
+    const int worst = p->N < ESAC_BWD_MAX_SLOTS ? p->N : ESAC_BWD_MAX_SLOTS;
+    int cap = worst;
+    if (h_out) {
+        cap = c->bcap > 64 ? c->bcap : 64;
+        if (cap > worst) cap = worst;
+    }
+    double Ti[16], gt[16], gt_pose[6];
+    for (int i = 0; i < 16; i++) gt[i] = (double)h_gt_pose[i];
+    if (!inv4_host(gt, Ti)) return fail(-4, "esac_hip_backward: the ground-truth pose is singular");
     double Rg[9] = {Ti[0], Ti[1], Ti[2], Ti[4], Ti[5], Ti[6], Ti[8], Ti[9], Ti[10]};
     nearest_rotation_host(Rg);
-    rodrigues_mat2vec(Rg, a.bwd.gt_pose);
-    a.bwd.gt_pose[3] = Ti[3]; a.bwd.gt_pose[4] = Ti[7]; a.bwd.gt_pose[5] = Ti[11];
+    rodrigues_mat2vec(Rg, gt_pose);
+    gt_pose[3] = Ti[3]; gt_pose[4] = Ti[7]; gt_pose[5] = Ti[11];
     a.tstamps = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    c->rt32_stale = false;
     launch_sample(a, s);                                        // esac.cpp:276
     if ((rc = check_launch("k_sample"))) return rc;
     launch_rescore_all(a, s);                                   // esac.cpp:295-316, reference arithmetic for every hypothesis
     if ((rc = check_launch("k_rescore(all)"))) return rc;
-    launch_bwd_select(a, s);                                    // esac.cpp:319-331
-    if ((rc = check_launch("k_bwd_select"))) return rc;
-    launch_refine_slots(a, s);                                  // esac.cpp:328-347
-    if ((rc = check_launch("k_refine(slots)"))) return rc;
-    launch_bwd_loss(a, s);                                      // esac.cpp:354-362 + dLoss + softmax derivative
-    if ((rc = check_launch("k_bwd_loss"))) return rc;
-    launch_bwd_path1(a, s);                                     // esac.cpp:375-463
-    if ((rc = check_launch("k_bwd_path1"))) return rc;
-    launch_bwd_path2(a, s);                                     // esac.cpp:470-488
-    if ((rc = check_launch("k_bwd_path2"))) return rc;
-    launch_bwd_accumulate(a, s);                                // esac.cpp:491-508
-    if ((rc = check_launch("k_bwd_accumulate"))) return rc;
-    if (h_out) {
+    for (int attempt = 0;; attempt++) {
+        if ((rc = ensure_bws(c, p->N, P, cap))) return rc;
+        a.bwd = c->bws;
+        a.bwd.cap = cap;
+        a.bwd.out_grad = d_out_gradients;
+        a.bwd.w_rot = (double)w_loss_rot;
+        a.bwd.w_trans = (double)w_loss_trans;
+        a.bwd.cut = (double)loss_cut;
+        for (int i = 0; i < 16; i++) a.bwd.gt[i] = gt[i];
+        for (int i = 0; i < 6; i++) a.bwd.gt_pose[i] = gt_pose[i];
+        launch_bwd_select(a, s);                                    // esac.cpp:319-331
+        if ((rc = check_launch("k_bwd_select"))) return rc;
+        launch_refine_slots(a, s);                                  // esac.cpp:328-347
+        if ((rc = check_launch("k_refine(slots)"))) return rc;
+        launch_bwd_loss(a, s);                                      // esac.cpp:354-362 + dLoss + softmax derivative
+        if ((rc = check_launch("k_bwd_loss"))) return rc;
+        launch_bwd_path1(a, s);                                     // esac.cpp:375-463
+        if ((rc = check_launch("k_bwd_path1"))) return rc;
+        launch_bwd_path2(a, s);                                     // esac.cpp:470-488
+        if ((rc = check_launch("k_bwd_path2"))) return rc;
+        launch_bwd_accumulate(a, s);                                // esac.cpp:491-508
+        if ((rc = check_launch("k_bwd_accumulate"))) return rc;
+        if (!h_out) return 0;
         HIP_OK(hipMemcpyAsync(h_out, a.bwd.out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        const int needed = (int)h_out[1];
+        if (needed <= cap || attempt >= 1) break;  // one retry suffices: the second pass is sized by the true count
+        cap = needed + 31 > worst ? worst : (needed + 31) / 32 * 32;
     }
+    if (h_out[3] != 0.0)
+        return fail(-10, "hypAssignment holds a value outside [0,%d) (device-resident tensor; such hypotheses were scored against expert 0)", p->E);
+    return 0;
+}
+
+// Asynchronous calls (no host result) cannot report an out-of-range hypAssignment themselves: this waits for the
+// device and returns -10 when the most recent call on the context flagged one, 0 otherwise.
+extern "C" int esac_hip_check(esac_hip_ctx* c) {
+    if (!c) return fail(-1, "null context");
+    DeviceGuard guard(c->device);
+    if (!c->ws.status) return 0;
+    HIP_OK(hipDeviceSynchronize());
+    unsigned long long st = 0;
+    HIP_OK(hipMemcpy(&st, c->ws.status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st != 0 && (double)st == c->epoch) return fail(-10, "hypAssignment held a value outside [0,E) in the most recent call");
     return 0;
 }
 
 extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t bytes) {
     if (!c || !h_dst) return fail(-1, "esac_hip_read: null argument");
-    HIP_OK(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     const size_t N = (size_t)c->lastN, P = (size_t)c->lastH * c->lastW;
     const void* src = nullptr;
     size_t want = 0;
@@ -506,7 +604,7 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
         case ESAC_BUF_BWD_PATH2: {
             // [slots,3,P] doubles; the caller asks for the first k slots (k = bytes / (3 P 8))
             const size_t slab = 3 * P * sizeof(double);
-            const size_t cap = (size_t)(c->lastN < ESAC_BWD_MAX_SLOTS ? c->lastN : ESAC_BWD_MAX_SLOTS);
+            const size_t cap = (size_t)c->bcap;  // slots the slab workspace holds (>= the slots of the last call)
             src = which == ESAC_BUF_BWD_PATH1 ? c->bws.grad1 : c->bws.grad2;
             if (!src || slab == 0) return fail(-6, "esac_hip_read: buffer %d is empty (no backward call has run yet)", which);
             if (bytes == 0 || bytes % slab || bytes / slab > cap)
@@ -525,15 +623,14 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
 
 extern "C" int esac_hip_write_hyps(esac_hip_ctx* c, const double* h_hyps, int N) {
     if (!c || !h_hyps || N <= 0) return fail(-1, "esac_hip_write_hyps: bad argument");
-    HIP_OK(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     int rc = ensure_ws(c, N, c->capP > 0 ? c->capP : 1);
     if (rc) return rc;
-    HIP_OK(hipMemcpy(c->ws.hyps, h_hyps, (size_t)N * 6 * sizeof(double), hipMemcpyHostToDevice));
-    KArgs a = c->ws;
-    a.N = N;
-    launch_hyps_to_rt32(a, nullptr);
-    if ((rc = check_launch("k_hyps_to_rt32"))) return rc;
     HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(c->ws.hyps, h_hyps, (size_t)N * 6 * sizeof(double), hipMemcpyHostToDevice));
+    // the fp32 [R | t] rows of the streaming score are relative to each expert map's origin (device_common.hpp:
+    // map_centre): they are rebuilt by the next esac_hip_score, which knows the maps
+    c->rt32_stale = true;
     c->lastN = N;
     return 0;
 }
@@ -551,7 +648,7 @@ extern "C" int esac_hip_set_timing(esac_hip_ctx* c, int enabled) {
     c->timing_calls = 0;
     c->ev_valid = false;
     if (c->ws.span_acc) {
-        HIP_OK(hipSetDevice(c->device));
+        DeviceGuard guard(c->device);
         HIP_OK(hipDeviceSynchronize());
         HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
     }
@@ -561,6 +658,7 @@ extern "C" int esac_hip_set_timing(esac_hip_ctx* c, int enabled) {
 extern "C" int esac_hip_phase_ms(esac_hip_ctx* c, float out[6]) {
     if (!c || !out) return fail(-1, "esac_hip_phase_ms: null argument");
     if (!c->timing || !c->ev_valid) return fail(-8, "esac_hip_phase_ms: timing is off or no forward has run");
+    DeviceGuard guard(c->device);
     HIP_OK(hipEventSynchronize(c->ev[4]));
     for (int i = 0; i < 4; i++) HIP_OK(hipEventElapsedTime(&out[i], c->ev[i], c->ev[i + 1]));
     HIP_OK(hipEventElapsedTime(&out[4], c->ev[0], c->ev[4]));
@@ -572,7 +670,7 @@ extern "C" int esac_hip_phase_ms(esac_hip_ctx* c, float out[6]) {
 extern "C" int esac_hip_score_span_ms(esac_hip_ctx* c, float* mean_ms, int* launches) {
     if (!c || !mean_ms) return fail(-1, "esac_hip_score_span_ms: null argument");
     if (!c->ws.span_acc) return fail(-8, "esac_hip_score_span_ms: no forward has run");
-    HIP_OK(hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     HIP_OK(hipDeviceSynchronize());
     // mean device-side span of the score kernel since timing was enabled (100 MHz wall clock -> ms)
     long long acc[2] = {0, 0};

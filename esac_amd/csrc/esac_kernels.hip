@@ -84,15 +84,26 @@ __device__ __forceinline__ void gather_sample(const KArgs& a, const float* __res
     }
 }
 
-__device__ __forceinline__ void store_hypothesis(const KArgs& a, int h, const double rvec[3], const double T[3], const double R[9],
-                                                 const int (&cx)[4], const int (&cy)[4], int tries_val) {
-    double* hp = a.hyps + (size_t)h * 6;
-    hp[0] = rvec[0]; hp[1] = rvec[1]; hp[2] = rvec[2];
-    hp[3] = T[0]; hp[4] = T[1]; hp[5] = T[2];
+// float [R | t + R c] for the fp32 scoring stream, c = origin of the expert's map (device_common.hpp:map_centre);
+// the shifted translation is formed in double
+__device__ __forceinline__ void store_rt32(const KArgs& a, int h, const float* __restrict__ map, const double R[9], const double T[3]) {
+    const Centre c = map_centre(a, map);
+    const double cx = c.x, cy = c.y, cz = c.z;
     float* rt = a.rt32 + (size_t)h * 12;
 #pragma unroll
     for (int k = 0; k < 9; k++) rt[k] = (float)R[k];
-    rt[9] = (float)T[0]; rt[10] = (float)T[1]; rt[11] = (float)T[2];
+    rt[9] = (float)(R[0] * cx + R[1] * cy + R[2] * cz + T[0]);
+    rt[10] = (float)(R[3] * cx + R[4] * cy + R[5] * cz + T[1]);
+    rt[11] = (float)(R[6] * cx + R[7] * cy + R[8] * cz + T[2]);
+}
+
+__device__ __forceinline__ void store_hypothesis(const KArgs& a, int h, const float* __restrict__ map, const double rvec[3],
+                                                 const double T[3], const double R[9], const int (&cx)[4], const int (&cy)[4],
+                                                 int tries_val) {
+    double* hp = a.hyps + (size_t)h * 6;
+    hp[0] = rvec[0]; hp[1] = rvec[1]; hp[2] = rvec[2];
+    hp[3] = T[0]; hp[4] = T[1]; hp[5] = T[2];
+    store_rt32(a, h, map, R, T);
     int* sx = a.sample_xy + (size_t)h * 8;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -121,6 +132,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bool mine_pending = h < a.N && (a.first_try == 0 || a.tries[hc] == SAMPLE_PENDING);
     if (!__any(mine_pending)) return;  // all four hypotheses of this wavefront are done
     const bool active = mine_pending && t < a.max_tries;
+    if (a.first_try == 0 && h < a.N && (lane & 15) == 0) flag_bad_assignment(a, h);
     const int e = expert_of(a, hc);
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
@@ -144,9 +156,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (!mine_pending) return;
     if (mine) {
         const int first = __ffs((int)mine) - 1;
-        if ((lane & 15) == first) store_hypothesis(a, h, rvec, T, R, cx, cy, a.first_try + first);
+        if ((lane & 15) == first) store_hypothesis(a, h, map, rvec, T, R, cx, cy, a.first_try + first);
     } else if (a.max_tries <= a.first_try + FIRST_PHASE_TRIES) {
-        if (t == a.max_tries - 1) store_hypothesis(a, h, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
+        if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
     } else if ((lane & 15) == 0) {
         a.tries[h] = SAMPLE_PENDING;
     }
@@ -174,6 +186,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const double tau = (double)a.tau;
     if (a.first_try > 0 && a.tries[h] != SAMPLE_PENDING) return;  // phase 2 of the throughput shape: done in phase 1
+    if (a.first_try == 0 && threadIdx.x == 0) flag_bad_assignment(a, h);
 
     int parity = 0;
     for (int base = a.first_try, TRIES = 0; base < a.max_tries; base += TRIES, parity ^= 1) {
@@ -244,24 +257,22 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             writer = a.max_tries - 1;  // budget exhausted: state of the last try remains
         }
         if (writer >= 0) {
-            if (t == writer && holder) store_hypothesis(a, h, rvec, T, R, cx, cy, tries_val);
+            if (t == writer && holder) store_hypothesis(a, h, map, rvec, T, R, cx, cy, tries_val);
             return;
         }
     }
 }
 
-// (rvec,tvec) -> float [R|t] for the fp32 scoring stream (used after esac_hip_write_hyps)
+// (rvec,tvec) -> float [R | t + R c] for the fp32 scoring stream (hypotheses handed in through esac_hip_write_hyps)
 __global__ void k_hyps_to_rt32(KArgs a) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= a.N) return;
     double R[9];
     const double* hp = a.hyps + (size_t)h * 6;
     const double r[3] = {hp[0], hp[1], hp[2]};
+    const double t[3] = {hp[3], hp[4], hp[5]};
     rodrigues_vec2mat<false>(r, R, nullptr);
-    float* rt = a.rt32 + (size_t)h * 12;
-#pragma unroll
-    for (int k = 0; k < 9; k++) rt[k] = (float)R[k];
-    rt[9] = (float)hp[3]; rt[10] = (float)hp[4]; rt[11] = (float)hp[5];
+    store_rt32(a, h, a.sc + (size_t)expert_of(a, h) * 3 * a.H * a.W, R, t);
 }
 
 // ================================================================= K2: fused soft-inlier score, fp32
@@ -300,6 +311,7 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
     const float* __restrict__ mz = my + P;
     const float* rt = a.rt32 + (size_t)h * 12;  // wave-uniform -> scalar loads
     const PoseF p{rt[0], rt[1], rt[2], rt[3], rt[4], rt[5], rt[6], rt[7], rt[8], rt[9], rt[10], rt[11]};
+    const Centre o = map_centre(a, mx);  // rt32's translation is relative to this origin (store_rt32)
     const float fx = a.focal, fy = a.focal, cx = a.ppx, cy = a.ppy;
     const float beta_log2e = a.beta * 1.4426950408889634f;
     float acc = 0.0f;
@@ -317,16 +329,16 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
             const int col = (i - row * wq) << 2;
             const float py = cell_py(a, row);
             const float px = cell_px(a, col);
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.x, Y.x, Z.x, px, py, a.max_reproj, beta_log2e, a.tau);
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.y, Y.y, Z.y, px + step, py, a.max_reproj, beta_log2e, a.tau);
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.z, Y.z, Z.z, px + 2 * step, py, a.max_reproj, beta_log2e, a.tau);
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.w, Y.w, Z.w, px + 3 * step, py, a.max_reproj, beta_log2e, a.tau);
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.x - o.x, Y.x - o.y, Z.x - o.z, px, py, a.max_reproj, beta_log2e, a.tau);
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.y - o.x, Y.y - o.y, Z.y - o.z, px + step, py, a.max_reproj, beta_log2e, a.tau);
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.z - o.x, Y.z - o.y, Z.z - o.z, px + 2 * step, py, a.max_reproj, beta_log2e, a.tau);
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.w - o.x, Y.w - o.y, Z.w - o.z, px + 3 * step, py, a.max_reproj, beta_log2e, a.tau);
         }
     } else {
         for (int i = threadIdx.x; i < P; i += B) {
             const int row = i / a.W;
             const int col = i - row * a.W;
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, mx[i], my[i], mz[i], cell_px(a, col), cell_py(a, row),
+            acc += soft_inlier_fast(p, fx, fy, cx, cy, mx[i] - o.x, my[i] - o.y, mz[i] - o.z, cell_px(a, col), cell_py(a, row),
                                     a.max_reproj, beta_log2e, a.tau);
         }
     }
@@ -496,7 +508,43 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a) {
     }
 }
 
+// softMax / entropy (esac_util.h:461-497) over the EXACT scores of all N hypotheses (ESAC_FLAG_EXACT_SCORES: k_rescore
+// has scored every hypothesis in reference arithmetic, all of them are contenders): max, sum exp(s - max), entropy.
+template <int B>
+__global__ __launch_bounds__(B) void k_stats_exact(KArgs a) {
+    __shared__ double s_part[2 * (B / 64)];
+    __shared__ double s_tot[2];
+    __shared__ double s_max[B / 64];
+    frame_view(a);
+    double m = -INFINITY;
+    for (int i = threadIdx.x; i < a.N; i += B) m = fmax(m, a.scores[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = s_max[0];
+#pragma unroll
+    for (int k = 1; k < B / 64; k++) m = fmax(m, s_max[k]);
+    double acc[2] = {0, 0};
+    for (int i = threadIdx.x; i < a.N; i += B) {
+        const double d = a.scores[i] - m;
+        const double ex = exp(d);
+        acc[0] += ex;
+        acc[1] += ex * d;
+    }
+    block_sum<2, B>(acc, s_part, s_tot);
+    if (threadIdx.x == 0) {
+        a.n_contenders[0] = a.N;
+        a.stats[0] = m;
+        a.stats[1] = acc[0];
+        a.stats[2] = log2(acc[0]) - acc[1] / (acc[0] * 0.6931471805599453);  // -sum p log2 p, p = exp(d) / S
+    }
+}
+
 // ---------------------------------------------------------------- launchers
+void launch_stats_exact(const KArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_stats_exact<256>, dim3(1, a.frames), dim3(256), 0, s, a);
+}
 void launch_sample(const KArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.frames;
     if (total <= 1024)  // latency: 64 tries per round, the candidates of a try on four lanes
@@ -521,6 +569,7 @@ void launch_score_fast(const KArgs& a, hipStream_t s) {
     if ((long long)a.N * a.frames <= 2048) hipLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, a);
     else               hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
 }
+void launch_score(const KArgs& a, hipStream_t s) { launch_score_fast(a, s); }
 void launch_select_rescore(const KArgs& a, hipStream_t s) {
     // few contenders, latency matters: 16 wavefronts per workgroup; a single frame spreads its hypotheses over up to
     // 256 workgroups (a contender gets a CU to itself), batched frames over 16 each (the frames fill the chip)

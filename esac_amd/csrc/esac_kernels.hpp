@@ -14,6 +14,8 @@ constexpr int ESAC_BWD_SLOTS_K = 1000;     // = ESAC_BWD_MAX_SLOTS (include/esac
 constexpr int ESAC_REFINE_LDS_CAP = 8192;  // correspondences the refinement kernel stages in LDS (128 KiB of the CU's 160 KiB)
 constexpr int ESAC_REFINE_THREADS = 256;   // 4 wavefronts = one per SIMD of the one CU a refinement occupies
 constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the error pass
+constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result record [32] + epoch word + status word
+constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
 
 // Correspondence list of one refinement: every wavefront owns a region = its share of the cells of each error-pass
 // trip, rounded up to whole trips.  corr_entries(P) is the size of the whole list (>= P, < P + 2048).
@@ -58,6 +60,7 @@ struct KArgs {
     int max_tries, max_ref_steps, hyp_offset;
     int first_try;             // sampling continues from this try (two-phase throughput shape), 0 otherwise
     float margin;
+    int flags;                 // ESAC_FLAG_* (include/esac_hip.h)
     const int32_t* hyp_index;  // optional [N] global hypothesis indices
     // workspaces (device)
     double* hyps;         // [N,6]
@@ -77,10 +80,12 @@ struct KArgs {
     long long* cycles;    // [32] shader-cycle counters of the refinement kernel's sections (profiling aid)
     long long* tstamps;   // [2N] per-workgroup (start,end) wall-clock stamps of the score kernel, or nullptr
     long long* span_acc;  // [2] accumulated score-kernel span (100 MHz ticks) and launch count
+    unsigned long long* status;  // [1] epoch of the last call whose hypAssignment held a value outside [0,E) (0: never)
     // caller-visible outputs written by the kernels themselves (no copy kernels on the critical path)
     double* scores_user;  // optional device [N]: the score vector
     double* result_user;  // optional device [32]: the result record
-    double* result_pin;   // optional pinned HOST memory [33] (device-visible): result record + epoch word
+    double* result_pin;   // optional pinned HOST memory [ESAC_PIN_DOUBLES] (device-visible): result record, epoch word,
+                          // status word (1.0: this call's hypAssignment held an out-of-range value)
     double epoch;         // value stored into result_pin[32] after the record (the host polls it)
     // batched calls: frame b = blockIdx.y works on its own slice of every buffer (device_common.hpp:frame_view)
     int frames;                 // B >= 1
@@ -91,8 +96,10 @@ struct KArgs {
 void launch_sample(const KArgs& a, hipStream_t s);
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s);
 void launch_score_fast(const KArgs& a, hipStream_t s);
+void launch_score(const KArgs& a, hipStream_t s);  // the streaming fp32 score in the shape that suits (N, grid, experts)
 void launch_select_rescore(const KArgs& a, hipStream_t s);
 void launch_rescore_all(const KArgs& a, hipStream_t s);
+void launch_stats_exact(const KArgs& a, hipStream_t s);
 void launch_refine(const KArgs& a, hipStream_t s);
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);

@@ -26,10 +26,86 @@
 
 #include "device_common.hpp"
 #include "esac_kernels.hpp"
+#include "bwd_math.hpp"
 #include "lm_math.hpp"
 #include "pose_math.hpp"
 
 namespace esac {
+
+// The rare branch of an LM step: the damped normal matrix is singular to rounding (lm_solve6 returned false), so the
+// step is pinv(A) * g with eigenvalues below 2 eps sum|w| dropped -- cv::solve(DECOMP_SVD) inside CvLevMarq, the
+// route the CPU library always takes (bwd_math.hpp:pinv_sym6_jacobi is the same algorithm, unrolled into registers).
+// Here it must cost the common path nothing: ONE lane runs rolled loops over matrices in LDS (run-time indices, a few
+// hundred bytes of code, no extra registers), the others wait.  Every lane reaches this together (the LM state is
+// replicated), so the barriers are uniform.  `lds`: >= 84 doubles of scratch nobody else touches meanwhile.
+__device__ __forceinline__ void lm_solve6_pinv(const double (&U21)[21], const double (&g)[6], double lambda, double (&dx)[6], double* lds) {
+    double* A = lds;        // [6][6]
+    double* V = lds + 36;   // [6][6]
+    double* out = lds + 72; // [6]
+    double* gs = lds + 78;  // [6]
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) {
+                const double v = (i == j) ? U21[k] * (1. + lambda) : U21[k];
+                A[i * 6 + j] = v;
+                A[j * 6 + i] = v;
+                k++;
+            }
+#pragma unroll
+        for (int i = 0; i < 6; i++) gs[i] = g[i];
+        for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 60; sweep++) {
+            double off = 0;
+            for (int i = 0; i < 6; i++)
+                for (int j = i + 1; j < 6; j++) off += A[i * 6 + j] * A[i * 6 + j];
+            if (off == 0) break;
+            for (int p = 0; p < 6; p++)
+                for (int q = p + 1; q < 6; q++) {
+                    const double apq = A[p * 6 + q];
+                    const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2 * apq);
+                    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                    if (!(fabs(theta) <= 1.7976931348623157e308)) t = 0;
+                    if (apq == 0) t = 0;
+                    const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                    for (int m = 0; m < 6; m++) {
+                        const double akp = A[m * 6 + p], akq = A[m * 6 + q];
+                        A[m * 6 + p] = c * akp - sn * akq;
+                        A[m * 6 + q] = sn * akp + c * akq;
+                    }
+                    for (int m = 0; m < 6; m++) {
+                        const double apk = A[p * 6 + m], aqk = A[q * 6 + m];
+                        A[p * 6 + m] = c * apk - sn * aqk;
+                        A[q * 6 + m] = sn * apk + c * aqk;
+                    }
+                    for (int m = 0; m < 6; m++) {
+                        const double vkp = V[m * 6 + p], vkq = V[m * 6 + q];
+                        V[m * 6 + p] = c * vkp - sn * vkq;
+                        V[m * 6 + q] = sn * vkp + c * vkq;
+                    }
+                }
+        }
+        double thresh = 0;
+        for (int i = 0; i < 6; i++) thresh += fabs(A[i * 7]);
+        thresh *= 2 * 2.220446049250313e-16;
+        for (int i = 0; i < 6; i++) out[i] = 0;
+        for (int m = 0; m < 6; m++) {
+            const double w = A[m * 7];
+            if (!(fabs(w) > thresh)) continue;
+            double proj = 0;
+            for (int j = 0; j < 6; j++) proj += V[j * 6 + m] * gs[j];
+            proj /= w;
+            for (int i = 0; i < 6; i++) out[i] += V[i * 6 + m] * proj;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 6; i++) dx[i] = out[i];
+    __syncthreads();
+}
 
 constexpr int REFINE_B = ESAC_REFINE_THREADS;  // 4 wavefronts = one per SIMD of the one CU this kernel occupies
 constexpr int LDS_CAP = ESAC_REFINE_LDS_CAP;   // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
@@ -56,7 +132,8 @@ constexpr int LM_NP = ESAC_LM_NP;              // correspondences per lane in fl
 
 struct __attribute__((aligned(16))) Corr {
     float x, y, z;
-    uint32_t px_py;  // pixel position of the cell, two signed 16-bit integers: py << 16 | (px & 0xffff)
+    uint32_t row_col;  // grid cell of the correspondence: row << 16 | col (H, W <= 65535, checked by the C ABI); its pixel
+                       // position is col * sub + sub / 2 - shift_x (createSampling, esac_util.h:64-66), any magnitude
 };
 
 __device__ __forceinline__ int cell_pxi(const KArgs& a, int col) { return col * a.sub + a.sub / 2 - a.shift_x; }
@@ -122,7 +199,7 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
     for (int start = 0; start < P; start += B * U) {
         const bool full = start + B * U <= P;  // wave-uniform: no bounds checks in full trips
         float X[U], Y[U], Z[U], pxf[U], pyf[U], errv[U];
-        int pxi[U], pyi[U], cell[G];
+        int coli[U], rowi[U], cell[G];
         bool flag[U];
         CYC_BEGIN();
 #pragma unroll
@@ -144,10 +221,10 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
             }
 #pragma unroll
             for (int l = 0; l < L; l++) {
-                pxi[g * L + l] = cell_pxi(a, col + l);
-                pyi[g * L + l] = cell_pyi(a, row);
-                pxf[g * L + l] = (float)pxi[g * L + l];
-                pyf[g * L + l] = (float)pyi[g * L + l];
+                coli[g * L + l] = col + l;
+                rowi[g * L + l] = row;
+                pxf[g * L + l] = (float)cell_pxi(a, col + l);
+                pyf[g * L + l] = (float)cell_pyi(a, row);
             }
             col += stepC;
             row += stepR;
@@ -235,7 +312,7 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
             if (flag[u]) {
                 const int slot = wcount + __popcll(m & ((1ull << lane) - 1ull));
                 if (slot < region)
-                    wlist[slot] = Corr{X[u], Y[u], Z[u], ((uint32_t)pyi[u] << 16) | ((uint32_t)pxi[u] & 0xffffu)};
+                    wlist[slot] = Corr{X[u], Y[u], Z[u], ((uint32_t)rowi[u] << 16) | (uint32_t)coli[u]};
             }
             wcount += __popcll(m);
         }
@@ -254,8 +331,12 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
 
 // One pass over the compacted correspondences at `param`: residual norm^2 (returned) and the
 // (rvec,tvec)-space normal equations U21 / g6 at that point.  `list` / `n`: this wavefront's region and its fill.
+// Pixel position of grid cell (col, row): px = col * sub + offx (createSampling, esac_util.h:64-66).
+struct PxMap {
+    int sub, offx, offy;
+};
 template <int B, typename ListPtr>
-__device__ __forceinline__ double lm_pass(ListPtr list, int n, const double param[6], const Cam& cam, double U21[21],
+__device__ __forceinline__ double lm_pass(ListPtr list, int n, const double param[6], const Cam& cam, const PxMap& pm, double U21[21],
                                           double g6[6], double* s_part, double* s_tot, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
@@ -281,8 +362,8 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
             on[p] = jj < n;
             const Corr c = list[min(jj, n - 1)];  // clamped, unconditional: no control flow inside the pipelined body
             X[p] = (double)c.x; Y[p] = (double)c.y; Z[p] = (double)c.z;
-            mxp[p] = (double)(int)(short)(c.px_py & 0xffffu);
-            myp[p] = (double)((int)c.px_py >> 16);
+            mxp[p] = (double)((int)(c.row_col & 0xffffu) * pm.sub + pm.offx);
+            myp[p] = (double)((int)(c.row_col >> 16) * pm.sub + pm.offy);
         }
         lm_point_terms<LM_NP>(R, param + 3, cam, X, Y, Z, mxp, myp, on, out);
     };
@@ -312,12 +393,10 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
 
 // cv::solvePnP(ITERATIVE, useExtrinsicGuess): CvLevMarq with 6 parameters, max_iter 20, eps FLT_EPSILON,
 // lambda = 10^k from k = -3, k++ while a step made the error worse (<= 16), k-- after an accepted step.
-// cv::solvePnP(ITERATIVE, useExtrinsicGuess): CvLevMarq with 6 parameters, max_iter 20, eps FLT_EPSILON,
-// lambda = 10^k from k = -3, k++ while a step made the error worse (<= 16), k-- after an accepted step.
 // Written as ONE loop around ONE lm_pass call site (the kernel must stay inside the instruction cache:
 // with the pass inlined at several sites the code grew to 170 KB and every phase ran from cold code).
 template <int B, typename ListPtr>
-__device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], const Cam& cam, double* s_part,
+__device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], const Cam& cam, const PxMap& pm, double* s_part,
                                         double* s_tot, long long* g_cyc) {
     CYC_DECL;
     double param[6], prev[6];
@@ -330,7 +409,7 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
     bool have_base = false;
     for (;;) {
         // residual norm and (speculatively) the normal equations at `param`
-        const double err_norm = sqrt(lm_pass<B>(list, n, param, cam, U21t, g6t, s_part, s_tot, g_cyc));
+        const double err_norm = sqrt(lm_pass<B>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc));
         bool accept;
         if (!have_base) {
             have_base = true;  // iters == 0: prevErrNorm = |err(initial pose)|
@@ -363,7 +442,7 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
         // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
         double dx[6];
         CYC_BEGIN();
-        lm_solve6(U21, g6, pow10_int(lambda_lg10), dx);
+        if (!lm_solve6(U21, g6, pow10_int(lambda_lg10), dx)) lm_solve6_pinv(U21, g6, pow10_int(lambda_lg10), dx, s_part);
         CYC_END(8);
 #pragma unroll
         for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
@@ -390,6 +469,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     frame_view(a);
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
+    const PxMap pm{a.sub, a.sub / 2 - a.shift_x, a.sub / 2 - a.shift_y};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long g_cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)g_cyc;
@@ -481,7 +561,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         if (!SLOTS && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
         if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
         best_inliers = (unsigned)n_inl;
-        lm_total += lm_refit<B>(my_list, n_wave, pose, cam, s_part, s_tot, g_cyc);
+        lm_total += lm_refit<B>(my_list, n_wave, pose, cam, pm, s_part, s_tot, g_cyc);
         accepted++;
         last_inliers = n_inl;
         map_buf = cur;  // inlierMap = this step's set (esac_util.h:440)
@@ -532,6 +612,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
             // copy kernel + stream-completion signal (saves ~15-20 us of the blocking call's latency)
 #pragma unroll
             for (int k = 0; k < 32; k++) a.result_pin[k] = r[k];
+            a.result_pin[33] = (a.status[0] == (unsigned long long)a.epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment seen by k_sample
             __threadfence_system();
             *reinterpret_cast<volatile double*>(a.result_pin + 32) = a.epoch;
         }

@@ -549,11 +549,11 @@ ESAC_HD void pnp_point_residual(const double R[9], const double t[3], const Cam&
 }
 
 // Damped normal equations of one LM step: (JtJ with diag*(1+lambda)) dx = JtErr.
-// JtJ arrives as the 21 upper-triangle sums.  LDL^T (the matrix is SPD for any
-// non-degenerate inlier set; the CPU library uses an SVD solve, identical there);
-// a non-positive pivot yields a zero step, which ends the LM loop through its
-// relative-change test.
-ESAC_HD void lm_solve6(const double U21[21], const double g[6], double lambda, double dx[6]) {
+// JtJ arrives as the 21 upper-triangle sums.  LDL^T (the matrix is SPD for any non-degenerate inlier set; the CPU
+// library takes an SVD solve, which gives the same step there).  Returns false -- dx is then meaningless -- when a
+// pivot falls below 1e-12 of its diagonal entry (rank-deficient inlier set, e.g. collinear points, once lambda has
+// shrunk): the caller then takes the SVD route itself (lm_solve6_pinv), as the CPU library always does.
+ESAC_HD bool lm_solve6(const double U21[21], const double g[6], double lambda, double dx[6]) {
 #pragma clang fp contract(fast)
     double A[6][6];
     int k = 0;
@@ -575,7 +575,7 @@ ESAC_HD void lm_solve6(const double U21[21], const double g[6], double lambda, d
         double d = A[j][j];
 #pragma unroll
         for (int m = 0; m < j; m++) d -= W[j][m] * L[j][m];
-        if (!(d > 0)) ok = false;
+        if (!(d > 1e-12 * A[j][j])) ok = false;
         const double inv = fast_rcp(d);  // six reciprocals sit on the serial chain of every LM iteration
         Dinv[j] = inv;
 #pragma unroll
@@ -602,10 +602,7 @@ ESAC_HD void lm_solve6(const double U21[21], const double g[6], double lambda, d
         for (int m = i + 1; m < 6; m++) s -= L[m][i] * dx[m];
         dx[i] = s;
     }
-    if (!ok) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) dx[i] = 0;
-    }
+    return ok;
 }
 
 // camera transform = inverse of the scene pose (esac_util.h:537-548), rigid inverse

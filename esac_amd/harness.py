@@ -71,7 +71,8 @@ def localize(image, gating, experts, focal_length, hypotheses=256, threshold=10.
     """One iteration of the reference test loop (test_esac.py:145-207) for `image` [1,3,H,W] on the GPU.
 
     gating(image) -> log-probabilities [1,E]; experts[e](image) -> scene coordinates [1,3,H/s,W/s].
-    Returns dict(pose [4,4] float32 cpu, expert, active_experts, gating_probs (device), time_s)."""
+    Returns dict(pose [4,4] float32 cpu, expert, active_experts, gating_probs (device), time_s, prediction, hyp_assignment
+    -- the two device tensors handed to esac.forward, so a caller can replay the call elsewhere)."""
     dev = image.device
     E = len(experts)
     pp_x = float(image.size(3) / 2)
@@ -98,7 +99,7 @@ def localize(image, gating, experts, focal_length, hypotheses=256, threshold=10.
     winning_expert = api.forward(prediction, e_hyps, out_pose, 0, 0, float(focal_length), pp_x, pp_y, threshold,
                                  inlier_alpha, inlier_beta, max_reprojection, subsample)
     return dict(pose=out_pose, expert=winning_expert, active_experts=int(sum(active)), gating_probs=gating_probs,
-                time_s=time.time() - start)
+                time_s=time.time() - start, prediction=prediction, hyp_assignment=e_hyps)
 
 
 def evaluate(samples, gating, experts, trans_threshold_cm=5.0, rot_threshold_deg=5.0, pose_log=None, **kw):

@@ -5,7 +5,7 @@
  * no torch / pybind types in any signature.  It replaces what the reference
  * binds through pybind11 in code/esac/esac.cpp:513-516
  *     m.def("forward",  &esac_forward)   // esac.cpp:64-190
- *     m.def("backward", &esac_backward)  // esac.cpp:213-511 (row f1, not yet built)
+ *     m.def("backward", &esac_backward)  // esac.cpp:213-511 -> esac_hip_backward
  * The Python module `esac` (esac.py -> esac_amd/api.py) binds these entry points
  * with ctypes and keeps the reference's positional `esac.forward(...)` signature;
  * INTEGRATION.md shows the binding a reference maintainer would add.
@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESAC_HIP_ABI_VERSION 1
+#define ESAC_HIP_ABI_VERSION 2
 
 /* reference compile-time constants (esac.cpp:44-45) */
 #define ESAC_MAX_SAMPLING_TRIES 1000000
@@ -57,11 +57,18 @@ typedef struct esac_hip_params {
     int32_t hyp_offset;       /* global index of local hypothesis 0 (multi-GPU sharding; RNG and
                                  tie-breaks use global indices so results do not depend on the
                                  number of ranks) */
-    float rescore_margin;     /* fast-score band re-scored exactly; <=0 -> alpha*ESAC_DEFAULT_MARGIN */
+    float rescore_margin;     /* fast-score band re-scored exactly; <=0 -> alpha*(ESAC_DEFAULT_MARGIN + 2/(H*W)) */
     const int32_t* d_hyp_index; /* optional DEVICE int32[N]: global index of each local hypothesis, for
                                  shards that are not a contiguous range (expert-sharded multi-GPU);
                                  NULL -> hyp_offset + i */
+    int32_t flags;            /* ESAC_FLAG_* below, 0 = default */
 } esac_hip_params;
+
+/* esac_hip_forward / _batch: score EVERY hypothesis in the reference's mixed float/double arithmetic
+ * (esac_util.h:235-260, 292-360) instead of ranking with the fp32 stream and re-scoring only the contenders.
+ * The score vector, ESAC_RES_PROB and ESAC_RES_ENTROPY are then the reference's own values (softMax / entropy,
+ * esac_util.h:461-497) for every hypothesis; the winner and the pose are the same either way. */
+#define ESAC_FLAG_EXACT_SCORES 1
 
 #define ESAC_DEFAULT_MARGIN 1e-3f
 
@@ -159,12 +166,13 @@ int esac_hip_forward_batch(esac_hip_ctx* ctx, int B, const float* d_scene_coords
 /*
  * esac_backward (esac.cpp:213-520): expected pose loss over the hypothesis distribution and its gradient wrt the
  * scene coordinates, everything on the device.
+ * Status -10: hypAssignment held a value outside [0,E) (the reference reads out of bounds there).
  * d_out_gradients [E,3,H,W] float32 (device), ACCUMULATED into (`+=`, esac.cpp:491-508) -- the caller zeroes it,
  *                 as train_esac.py:176 does.
  * h_gt_pose       host float[16], the ground-truth camera pose (4x4 row-major; gtPose, esac.cpp:219).
  * w_loss_rot / w_loss_trans / loss_cut: wLossRot, wLossTrans, lossCut (esac.cpp:220-222).
  * h_out           optional host double[4]: expected loss (the return value of esac_backward), number of
- *                 hypotheses with p >= PROB_THRESH, entropy of the distribution, 0.  When non-NULL the call
+ *                 hypotheses with p >= PROB_THRESH, entropy of the distribution, 1 if an assignment was out of range.  When non-NULL the call
  *                 blocks on `stream` (the reference call is blocking); otherwise it is asynchronous.
  * Uses the same Philox streams as esac_hip_forward for (seed, call): the hypotheses of a backward call are the
  * hypotheses of the forward call with the same counter.  Hypothesis sharding (hyp_offset / d_hyp_index) is
@@ -189,6 +197,11 @@ int esac_hip_refine(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_
  * and by callers that want scores identical to esac_util.h:235-260 for all N. */
 int esac_hip_score_exact(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
                          const esac_hip_params* p, void* stream);
+
+/* Waits for the device; -10 when the most recent call on this context met a hypAssignment value outside [0,E)
+ * (blocking calls report that themselves; asynchronous ones -- no host result pointer -- cannot), else 0.
+ * Out-of-range values never cause an out-of-bounds read: such hypotheses are evaluated against expert 0. */
+int esac_hip_check(esac_hip_ctx* ctx);
 
 /* Stage buffer access (synchronous). `bytes` must match the buffer size for (which, N, H, W). */
 int esac_hip_read(esac_hip_ctx* ctx, int which, void* h_dst, size_t bytes);

@@ -75,6 +75,9 @@ typedef struct esac_oracle_args {
     /* optional [N]: global index of each hypothesis (keys its RNG stream); NULL -> 0..N-1.
      * Lets a shard of a larger problem be evaluated on its own (multi-GPU tests). */
     const int32_t* hyp_index;
+    /* optional [N,6]: hypotheses (rvec,tvec) to use INSTEAD of sampling (tests that replay the reference's own
+     * hypotheses, or place a pose by hand); out_tries is then all 0 and out_sample_xy all 0. */
+    const double* in_hyps;
 } esac_oracle_args;
 
 /* returns winning expert (>=0) or <0 on argument error */

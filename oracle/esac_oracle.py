@@ -42,6 +42,7 @@ class _Args(C.Structure):
         ("out_phase_ms", C.c_void_p),
         ("out_lm_iters", C.c_void_p),
         ("hyp_index", C.c_void_p),
+        ("in_hyps", C.c_void_p),
     ]
 
 
@@ -98,8 +99,9 @@ def _p(a):
 
 def forward(scene_coords, hyp_assign, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0,
             inlier_thresh=10.0, inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8,
-            seed=1305, call=0, max_tries=0, max_ref_steps=-1, num_threads=0, irand=None, hyp_index=None):
+            seed=1305, call=0, max_tries=0, max_ref_steps=-1, num_threads=0, irand=None, hyp_index=None, in_hyps=None):
     """Run the oracle's esac_forward restatement; returns a dict of every stage output.
+    in_hyps: optional float64 [N,6] hypotheses used instead of sampling (scoring, selection, refinement unchanged).
 
     scene_coords: float32 ndarray [E,3,H,W] (any strides); hyp_assign: int64 ndarray [N] (any stride, 0 ok).
     """
@@ -146,6 +148,11 @@ def forward(scene_coords, hyp_assign, shift_x=0, shift_y=0, focal=525.0, ppx=320
         hi = np.ascontiguousarray(hyp_index, np.int32)
         assert hi.shape == (N,)
         a.hyp_index = _p(hi)
+    ih = None
+    if in_hyps is not None:
+        ih = np.ascontiguousarray(in_hyps, np.float64)
+        assert ih.shape == (N, 6)
+        a.in_hyps = _p(ih)
     for k in ("pose", "sample_xy", "tries", "hyps", "scores", "probs", "entropy", "winner", "refined",
               "ref_steps", "inlier_counts", "inlier_map", "winner_errs", "phase_ms", "lm_iters"):
         setattr(a, "out_" + k, _p(out[k]))

@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
     RESOLVE(esac_hip_backward);
     RESOLVE(esac_hip_read);
     if (p_esac_hip_abi_version() != ESAC_HIP_ABI_VERSION) return 3;
-    if (sizeof(esac_hip_params) != 96) {
+    if (sizeof(esac_hip_params) != 104) {
         fprintf(stderr, "sizeof(esac_hip_params) = %zu\n", sizeof(esac_hip_params));
         return 4;
     }

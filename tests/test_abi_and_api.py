@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), name
     lib.esac_hip_abi_version.restype = C.c_int
-    assert lib.esac_hip_abi_version() == 1
+    assert lib.esac_hip_abi_version() == api.ABI_VERSION == 2
     # no torch / pybind in the ABI: the shared object must not depend on libtorch or libpython
     import subprocess
     deps = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
@@ -53,7 +53,7 @@ def test_params_struct_layout_matches_header():
         names = decl.replace("*", " ").split(None, 1)[1] if not decl.startswith("const") else decl.split("*")[-1]
         fields += [n.strip() for n in names.split(",")]
     assert fields == [f[0] for f in api.Params._fields_]
-    assert C.sizeof(api.Params) == 96
+    assert C.sizeof(api.Params) == 104
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
@@ -171,7 +171,7 @@ def test_header_is_plain_c_and_library_resolves_from_c():
     exe = nb.build_abi_check()
     out = subprocess.run([exe, build.LIB_PATH], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "params 96 bytes" in out.stdout and "no CPU fallback" in out.stdout
+    assert "params 104 bytes" in out.stdout and "no CPU fallback" in out.stdout
 
 
 @pytest.mark.gpu

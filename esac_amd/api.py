@@ -36,9 +36,10 @@ ABI_SYMBOLS = [
     "esac_hip_forward", "esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine",
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
     "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug", "esac_hip_check",
+    "esac_hip_pick_record", "esac_hip_time_stages",
 ]
 ABI_VERSION = 2
-FLAG_EXACT_SCORES = 1
+FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM = 1, 2, 4
 
 
 class Params(C.Structure):
@@ -92,6 +93,8 @@ def load_library():
         lib.esac_hip_set_debug.argtypes = [vp, i32]
         lib.esac_hip_score_span_ms.argtypes = [vp, vp, vp]
         lib.esac_hip_check.argtypes = [vp]
+        lib.esac_hip_pick_record.argtypes = [vp, vp, i32, vp, vp]
+        lib.esac_hip_time_stages.argtypes = [vp, vp, vp, pp, vp, i32, vp]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
                 getattr(lib, name).restype = i32
@@ -143,7 +146,7 @@ class Engine:
 
     def make_params(self, E, H, W, N, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
                     inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0,
-                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0, exact_scores=False):
+                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0, exact_scores=False, score_shape="auto"):
         p = Params()
         p.E, p.H, p.W, p.N = int(E), int(H), int(W), int(N)
         p.shift_x, p.shift_y = int(shift_x), int(shift_y)
@@ -154,7 +157,7 @@ class Engine:
         p.max_tries, p.max_ref_steps, p.hyp_offset = int(max_tries), int(max_ref_steps), int(hyp_offset)
         p.rescore_margin = float(rescore_margin)
         p.d_hyp_index = None
-        p.flags = FLAG_EXACT_SCORES if exact_scores else 0
+        p.flags = (FLAG_EXACT_SCORES if exact_scores else 0) | {"auto": 0, "tiled": FLAG_SCORE_TILED, "stream": FLAG_SCORE_STREAM}[score_shape]
         self._shape = (int(N), int(H), int(W))
         return p
 
@@ -266,6 +269,22 @@ class Engine:
         out = np.zeros(shape, dt)
         _check(self.lib.esac_hip_read(self.ctx, which, out.ctypes.data_as(C.c_void_p), out.nbytes), self.lib)
         return out
+
+    def time_stages(self, scene_coords, hyp_assign, params, reps=20):
+        """Mean GPU time (ms) of sample / score / select / refine for this input (esac_hip_time_stages)."""
+        sc, ha = self._dev_inputs(scene_coords, hyp_assign)
+        out = np.zeros(4, np.float32)
+        self._call(self.lib.esac_hip_time_stages, sc.data_ptr(), ha.data_ptr(), C.byref(params), self._stream(), int(reps),
+                   out.ctypes.data)
+        return dict(zip(("sample", "score", "select_rescore", "refine"), (float(v) for v in out)))
+
+    def pick_record(self, records, world):
+        """Global winner among `world` per-rank records (device float64 [world*32], e.g. the tail of the all-reduced
+        exchange buffer): picked on the device, returned as np.float64[32]."""
+        assert records.is_cuda and records.dtype == torch.float64 and records.is_contiguous() and records.numel() >= 32 * world
+        host = np.zeros(RES_DOUBLES, np.float64)
+        self._call(self.lib.esac_hip_pick_record, records.data_ptr(), int(world), self._stream(), host.ctypes.data)
+        return host
 
     def check(self):
         """Waits for the device; raises if the most recent (asynchronous) call met an out-of-range hypAssignment."""

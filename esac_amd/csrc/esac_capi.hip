@@ -71,6 +71,9 @@ struct esac_hip_ctx {
     BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
     int bN = 0, bP = 0, bcap = 0;
     bool b_lists = false;
+    // tile-stationary score workspace (ensure_tiled_ws)
+    int tN = 0, tChunks = 0;
+    long long tPart = 0;
     bool rt32_stale = false;  // esac_hip_write_hyps ran: the fp32 [R|t] rows are rebuilt by the next esac_hip_score
 };
 
@@ -83,10 +86,12 @@ extern "C" int esac_hip_device_count(void) {
 }
 
 static void free_ws(esac_hip_ctx* c) {
-    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.fast_scores,
+    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.best_try,   c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
-                    c->ws.status};
+                    c->ws.status,     c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials};
+    c->tN = c->tChunks = 0;
+    c->tPart = 0;
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->ws = KArgs{};
@@ -160,6 +165,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.status, (size_t)1);
     rc |= alloc(&c->ws.sample_xy, (size_t)nN * 8);
     rc |= alloc(&c->ws.tries, (size_t)nN);
+    rc |= alloc(&c->ws.best_try, (size_t)nN);
     rc |= alloc(&c->ws.fast_scores, (size_t)nN);
     rc |= alloc(&c->ws.scores, (size_t)nN);
     rc |= alloc(&c->ws.exact_flag, (size_t)nN);
@@ -196,6 +202,44 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     return 0;
 }
 
+// Which shape the fp32 score runs in.  Per-hypothesis stream (k_score_fast): every hypothesis re-reads its expert's map,
+// fine while a map is L2-resident and hypotheses are few.  Tile-stationary (esac_score_tiled.hip): each map tile is read
+// once per chunk of <= 256 hypotheses -- pays when a map no longer fits the caches next to the other experts' maps
+// (full-resolution 480x640 maps: 3.7 MB each) and enough hypotheses share it.  ESAC_FLAG_SCORE_TILED / _STREAM override.
+static bool want_tiled(const esac_hip_params* p, const float* d_sc, int B) {
+    const long long P = (long long)p->H * p->W;
+    const bool legal = B == 1 && (p->W & 3) == 0 && (reinterpret_cast<uintptr_t>(d_sc) & 15) == 0 &&
+                       p->E <= ESAC_TILED_MAX_EXPERTS && P >= 4;
+    if (!legal || (p->flags & ESAC_FLAG_SCORE_STREAM)) return false;
+    if (p->flags & ESAC_FLAG_SCORE_TILED) return true;
+    return P >= 32768 && p->N >= 64;
+}
+
+static int ensure_tiled_ws(esac_hip_ctx* c, int N, int P, int E) {
+    const int n_sub = tiled_sub_tiles(P);
+    const int chunks = N / ESAC_TILED_HC + (E < N ? E : N) + 1;
+    const long long part = (long long)n_sub * N;
+    if (N <= c->tN && chunks <= c->tChunks && part <= c->tPart) return 0;
+    HIP_OK(hipDeviceSynchronize());
+    void* ptrs[] = {c->ws.order, c->ws.rt_sorted, c->ws.chunks, c->ws.n_chunks, c->ws.partials};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    c->ws.order = nullptr; c->ws.rt_sorted = nullptr; c->ws.chunks = nullptr; c->ws.n_chunks = nullptr; c->ws.partials = nullptr;
+    const int nN = N > c->tN ? N : c->tN, nC = chunks > c->tChunks ? chunks : c->tChunks;
+    const long long nP = part > c->tPart ? part : c->tPart;
+    c->tN = c->tChunks = 0;
+    c->tPart = 0;
+    int rc = 0;
+    rc |= alloc(&c->ws.order, (size_t)nN);
+    rc |= alloc(&c->ws.rt_sorted, (size_t)nN * 12);
+    rc |= alloc(&c->ws.chunks, (size_t)nC * 4);
+    rc |= alloc(&c->ws.n_chunks, (size_t)4);
+    rc |= alloc(&c->ws.partials, (size_t)nP);
+    if (rc) return rc;
+    c->tN = nN; c->tChunks = nC; c->tPart = nP;
+    return 0;
+}
+
 // Validation: what the reference leaves to accessor<>() / OpenCV asserts.
 static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, KArgs* out,
                      int B = 1, long long sc_frame_stride = 0) {
@@ -220,7 +264,15 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     if (B < 1 || B > ESAC_MAX_BATCH) return fail(-4, "batch size %d outside [1,%d]", B, ESAC_MAX_BATCH);
     int rc = ensure_ws(c, p->N, P, B);
     if (rc) return rc;
+    const bool tiled = want_tiled(p, d_sc, B);
+    if (tiled && (rc = ensure_tiled_ws(c, p->N, P, p->E))) return rc;
     KArgs a = c->ws;
+    if (tiled) {
+        a.n_sub = tiled_sub_tiles(P);
+        a.n_chunks_max = p->N / ESAC_TILED_HC + (p->E < p->N ? p->E : p->N) + 1;
+    } else {
+        a.partials = nullptr;  // launch_score: per-hypothesis stream
+    }
     a.frames = B;
     a.sc_frame_stride = sc_frame_stride;
     a.sc = d_sc;
@@ -371,6 +423,80 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         if (bad_assign)
             return fail(-10, "hypAssignment holds a value outside [0,%d) (device-resident tensor; such hypotheses were scored against expert 0)", p->E);
     }
+    return 0;
+}
+
+// Mean GPU time of each stage of the forward chain for THIS input: the chain runs once, then every stage is launched
+// `reps` times back to back between one pair of hipEvents on `stream` (stages are idempotent given their inputs).
+// A host-side loop around single launches cannot do this for ~5 us kernels: it is bound by the caller's launch rate.
+extern "C" int esac_hip_time_stages(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p,
+                                    void* stream, int reps, float out_ms[4]) {
+    if (!c || !out_ms || reps < 1) return fail(-1, "esac_hip_time_stages: bad argument");
+    DeviceGuard guard(c->device);
+    KArgs a;
+    int rc = make_args(c, d_sc, d_assign, p, &a);
+    if (rc) return rc;
+    a.tstamps = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    c->rt32_stale = false;
+    const bool exact = (a.flags & ESAC_FLAG_EXACT_SCORES) != 0;
+    auto stage = [&](int k) {
+        switch (k) {
+            case 0: launch_sample(a, s); break;
+            case 1: if (exact) launch_rescore_all(a, s); else launch_score(a, s); break;
+            case 2: if (exact) launch_stats_exact(a, s); else launch_select_rescore(a, s); break;
+            default: launch_refine(a, s); break;
+        }
+    };
+    for (int k = 0; k < 4; k++) stage(k);
+    if ((rc = check_launch("forward chain"))) return rc;
+    hipEvent_t ev[8];
+    for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+    for (int k = 0; k < 4; k++) {
+        stage(k);  // one untimed launch: the timed ones then start from the same (warm) state
+        HIP_OK(hipEventRecord(ev[2 * k], s));
+        for (int r = 0; r < reps; r++) stage(k);
+        HIP_OK(hipEventRecord(ev[2 * k + 1], s));
+    }
+    if ((rc = check_launch("stage timing"))) return rc;
+    HIP_OK(hipEventSynchronize(ev[7]));
+    for (int k = 0; k < 4; k++) {
+        HIP_OK(hipEventElapsedTime(&out_ms[k], ev[2 * k], ev[2 * k + 1]));
+        out_ms[k] /= (float)reps;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return 0;
+}
+
+// Multi-GPU exchange (esac_amd/distributed.py): winner among the per-rank records of the all-reduced buffer.
+extern "C" int esac_hip_pick_record(esac_hip_ctx* c, const double* d_records, int world, void* stream, double* h_record_out) {
+    if (!c || !d_records || !h_record_out || world < 1) return fail(-1, "esac_hip_pick_record: bad argument");
+    DeviceGuard guard(c->device);
+    hipStream_t s = (hipStream_t)stream;
+    c->epoch += 1.0;
+    const double want = c->epoch;
+    launch_pick_record(d_records, world, c->d_pin, want, s);
+    int rc = check_launch("k_pick_record");
+    if (rc) return rc;
+    volatile double* word = c->h_pin + 32;
+    bool landed = false;
+    for (long spins = 0; spins < 200000000L; spins++) {
+        if (*word == want) {
+            landed = true;
+            break;
+        }
+        if ((spins & 1023) == 1023 && hipStreamQuery(s) == hipSuccess) {
+            landed = *word == want;
+            break;
+        }
+    }
+    if (!landed) {
+        HIP_OK(hipStreamSynchronize(s));
+        if (*word != want) return fail(-9, "esac_hip_pick_record: the kernel did not deliver a record");
+    }
+    __sync_synchronize();
+    memcpy(h_record_out, (const void*)c->h_pin, ESAC_RES_DOUBLES * sizeof(double));
+    if (c->h_pin[33] == 2.0) return fail(-11, "esac_hip_pick_record: no rank produced a hypothesis");
     return 0;
 }
 

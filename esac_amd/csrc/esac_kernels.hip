@@ -161,6 +161,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
     } else if ((lane & 15) == 0) {
         a.tries[h] = SAMPLE_PENDING;
+        a.best_try[h] = 0x7fffffff;  // k_sample_search: lowest accepted try found so far
     }
 }
 
@@ -261,6 +262,81 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             return;
         }
     }
+}
+
+// ---- throughput shape, tries >= first_try: search and commit -----------------------------------------------------------
+// A hypothesis of a wrong expert needs ~10^3 tries (its 4 points only pass tau by luck) and now and then 10^4: with one
+// wavefront per hypothesis walking its tries 64 at a time, the launch lasts as long as the unluckiest hypothesis (228
+// sequential rounds on config 5a: 2.1 of the call's 2.25 ms) while most of the chip idles.  Here the search is spread:
+// SEARCH_WPH wavefronts share a pending hypothesis, wavefront w takes rounds w, w + WPH, w + 2 WPH, ... (64 tries each),
+// publishes the lowest accepted try with atomicMin and stops as soon as its next round starts above the published
+// value.  Every try below the final minimum has been evaluated and rejected by someone, so the minimum IS the try the
+// reference's sequential loop stops at (esac_util.h:152-223).  The search keeps no pose: k_sample_commit re-solves
+// exactly that try (same code, same result) and stores the hypothesis -- or the state of the last try when the budget
+// ran out.
+constexpr int SEARCH_WPH = 16;
+#ifndef ESAC_SEARCH_WAVES
+#define ESAC_SEARCH_WAVES 1  // wavefronts per SIMD the search kernel is compiled for (register budget 512 / waves)
+#endif
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ESAC_SEARCH_WAVES, ESAC_SEARCH_WAVES))) void k_sample_search(KArgs a) {
+    frame_view(a);
+    const int h = blockIdx.x, w = blockIdx.z, lane = threadIdx.x;
+    if (a.tries[h] != SAMPLE_PENDING) return;
+    const int e = expert_of(a, h);
+    const int P = a.H * a.W;
+    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
+    const Philox rng(a.seed, a.call);
+    const Cam cam = make_cam(a);
+    const uint32_t gh = (uint32_t)global_hyp(a, h);
+    const double tau = (double)a.tau;
+    int* best = a.best_try + h;
+    for (long long base = (long long)a.first_try + 64LL * w; base < a.max_tries; base += 64LL * SEARCH_WPH) {
+        if (base >= __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // someone accepted an earlier try
+        const int t = (int)base + lane;
+        bool accepted = false;
+        if (t < a.max_tries) {
+            int cx[4], cy[4];
+            V3 Pt[4];
+            float Pf[4][3];
+            double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
+            gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+            if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2) && !cannot_pass(reproj2, tau)) {
+                double rvec[3], T[3], R[9];
+                accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, tau, rvec, T, R);
+            }
+        }
+        const unsigned long long m = __ballot(accepted);
+        if (m) {
+            if (lane == 0) atomicMin(best, (int)base + __ffsll((long long)m) - 1);
+            break;
+        }
+    }
+}
+
+// one lane per pending hypothesis: re-solve the try the search settled on (or the last try of an exhausted budget, whose
+// state remains: esac_util.h:152-223 leaves the pose of the final iteration, a failed solve the zero pose) and store it
+__global__ __launch_bounds__(64) void k_sample_commit(KArgs a) {
+    frame_view(a);
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.N || a.tries[h] != SAMPLE_PENDING) return;
+    const int found = a.best_try[h];
+    const bool exhausted = found == 0x7fffffff;
+    const int t = exhausted ? a.max_tries - 1 : found;
+    const int e = expert_of(a, h);
+    const int P = a.H * a.W;
+    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
+    const Philox rng(a.seed, a.call);
+    const Cam cam = make_cam(a);
+    int cx[4], cy[4];
+    V3 Pt[4];
+    float Pf[4][3];
+    double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
+    double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    gather_sample(a, map, P, rng, (uint32_t)global_hyp(a, h), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+    if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2)) accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
+    store_hypothesis(a, h, map, rvec, T, R, cx, cy, exhausted ? -1 : t);
 }
 
 // (rvec,tvec) -> float [R | t + R c] for the fp32 scoring stream (hypotheses handed in through esac_hip_write_hyps)
@@ -541,6 +617,46 @@ __global__ __launch_bounds__(B) void k_stats_exact(KArgs a) {
     }
 }
 
+// Multi-GPU: the all-reduced exchange buffer ends with one 32-double record per rank (zero where a rank had no
+// hypothesis; ESAC_RES_VALID = slot 31 marks a real one).  Global winner = highest exact score, lowest GLOBAL hypothesis
+// index on ties (esac_util.h:519 "first max") -- picked here and handed to the host through pinned memory, like the
+// single-GPU record.  One wavefront.
+__global__ __launch_bounds__(64) void k_pick_record(const double* __restrict__ records, int world, double* __restrict__ pin, double epoch) {
+    const int lane = threadIdx.x;
+    double bs = -INFINITY, bh = INFINITY;
+    int br = -1;
+    for (int r = lane; r < world; r += 64) {
+        const double* rec = records + (size_t)r * 32;
+        if (rec[31] != 1.0) continue;
+        const double s = rec[0], h = rec[1];
+        if (br < 0 || s > bs || (s == bs && h < bh)) {
+            bs = s;
+            bh = h;
+            br = r;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(bs, o), oh = __shfl_xor(bh, o);
+        const int orr = __shfl_xor(br, o);
+        if (orr >= 0 && (br < 0 || os > bs || (os == bs && oh < bh))) {
+            bs = os;
+            bh = oh;
+            br = orr;
+        }
+    }
+    if (lane < 32) pin[lane] = br >= 0 ? records[(size_t)br * 32 + lane] : 0.0;
+    __threadfence_system();
+    if (lane == 0) {
+        pin[33] = br >= 0 ? 0.0 : 2.0;  // 2: no rank contributed a record
+        __threadfence_system();
+        *reinterpret_cast<volatile double*>(pin + 32) = epoch;
+    }
+}
+void launch_pick_record(const double* records, int world, double* pin, double epoch, hipStream_t s) {
+    hipLaunchKernelGGL(k_pick_record, dim3(1), dim3(64), 0, s, records, world, pin, epoch);
+}
+
 // ---------------------------------------------------------------- launchers
 void launch_stats_exact(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_stats_exact<256>, dim3(1, a.frames), dim3(256), 0, s, a);
@@ -551,13 +667,16 @@ void launch_sample(const KArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, a);
     else if (total <= 4096)
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, a);
-    else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest one wavefront each
+    else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by search + commit
         KArgs b = a;
         for (int pass = 0; pass < FIRST_PHASE_PASSES && b.first_try < a.max_tries; pass++) {
             hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
             b.first_try += FIRST_PHASE_TRIES;
         }
-        if (b.first_try < a.max_tries) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
+        if (b.first_try < a.max_tries) {
+            hipLaunchKernelGGL(k_sample_search, dim3(a.N, a.frames, SEARCH_WPH), dim3(64), 0, s, b);
+            hipLaunchKernelGGL(k_sample_commit, dim3((a.N + 63) / 64, a.frames), dim3(64), 0, s, b);
+        }
     }
 }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
@@ -569,7 +688,10 @@ void launch_score_fast(const KArgs& a, hipStream_t s) {
     if ((long long)a.N * a.frames <= 2048) hipLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, a);
     else               hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
 }
-void launch_score(const KArgs& a, hipStream_t s) { launch_score_fast(a, s); }
+void launch_score(const KArgs& a, hipStream_t s) {
+    if (a.partials) launch_score_tiled(a, s);
+    else            launch_score_fast(a, s);
+}
 void launch_select_rescore(const KArgs& a, hipStream_t s) {
     // few contenders, latency matters: 16 wavefronts per workgroup; a single frame spreads its hypotheses over up to
     // 256 workgroups (a contender gets a CU to itself), batched frames over 16 each (the frames fill the chip)

@@ -16,6 +16,8 @@ constexpr int ESAC_REFINE_THREADS = 256;   // 4 wavefronts = one per SIMD of the
 constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the error pass
 constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result record [32] + epoch word + status word
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
+constexpr int ESAC_TILED_HC = 256;            // hypotheses per chunk of the tile-stationary score kernel
+constexpr int ESAC_TILED_MAX_EXPERTS = 4096;  // experts its bucketing kernel counts in LDS
 
 // Correspondence list of one refinement: every wavefront owns a region = its share of the cells of each error-pass
 // trip, rounded up to whole trips.  corr_entries(P) is the size of the whole list (>= P, < P + 2048).
@@ -67,6 +69,7 @@ struct KArgs {
     float* rt32;          // [N,12] float(R(rvec)), float(t)
     int* sample_xy;       // [N,8]
     int* tries;           // [N]
+    int* best_try;        // [N] lowest accepted try found so far by the spread search (k_sample_search)
     float* fast_scores;   // [N]
     double* scores;       // [N]
     uint8_t* exact_flag;  // [N]
@@ -81,6 +84,13 @@ struct KArgs {
     long long* tstamps;   // [2N] per-workgroup (start,end) wall-clock stamps of the score kernel, or nullptr
     long long* span_acc;  // [2] accumulated score-kernel span (100 MHz ticks) and launch count
     unsigned long long* status;  // [1] epoch of the last call whose hypAssignment held a value outside [0,E) (0: never)
+    // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
+    int* order;           // [N] hypothesis at sorted position pos (sorted by expert)
+    float* rt_sorted;     // [N,12] rt32 rows in sorted order
+    int* chunks;          // [n_chunks_max,4] expert, first sorted position, count (<= ESAC_TILED_HC), 0
+    int* n_chunks;        // [1]
+    float* partials;      // [n_sub,N] partial sums per (sub-tile, sorted position)
+    int n_sub, n_chunks_max;
     // caller-visible outputs written by the kernels themselves (no copy kernels on the critical path)
     double* scores_user;  // optional device [N]: the score vector
     double* result_user;  // optional device [32]: the result record
@@ -96,10 +106,13 @@ struct KArgs {
 void launch_sample(const KArgs& a, hipStream_t s);
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s);
 void launch_score_fast(const KArgs& a, hipStream_t s);
-void launch_score(const KArgs& a, hipStream_t s);  // the streaming fp32 score in the shape that suits (N, grid, experts)
+void launch_score(const KArgs& a, hipStream_t s);  // the fp32 score in the shape the C ABI chose (a.partials != null: tiled)
+void launch_score_tiled(const KArgs& a, hipStream_t s);
+int tiled_sub_tiles(int P);
 void launch_select_rescore(const KArgs& a, hipStream_t s);
 void launch_rescore_all(const KArgs& a, hipStream_t s);
 void launch_stats_exact(const KArgs& a, hipStream_t s);
+void launch_pick_record(const double* records, int world, double* pin, double epoch, hipStream_t s);
 void launch_refine(const KArgs& a, hipStream_t s);
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);

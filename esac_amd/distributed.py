@@ -48,9 +48,18 @@ def pack_local(scores_local, record_local, n_total, global_index, rank, world):
     return buf
 
 
-def pick_global(buf, n_total, world):
-    """(scores_global [n_total], winning record [32]) from the all-reduced buffer."""
+def pick_global(buf, n_total, world, engine=None):
+    """(scores_global [n_total], winning record [32]) from the all-reduced buffer.  With a device buffer and an engine
+    the pick runs on the device (esac_hip_pick_record: one launch, the record lands in pinned host memory); a CPU
+    buffer (gloo tests) is scanned on the host."""
     scores = buf[:n_total]
+    if engine is not None and buf.is_cuda:
+        try:
+            return scores, engine.pick_record(buf[n_total:], world)
+        except RuntimeError as exc:
+            if "no rank produced" in str(exc):
+                raise RuntimeError("esac: no rank produced a hypothesis")
+            raise
     recs = buf[n_total:].view(world, RES_DOUBLES).cpu().numpy()
     best = None
     for r in range(world):
@@ -118,53 +127,89 @@ def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, wor
     return buf
 
 
-def _all_reduce_sum(buf, group):
+def _all_reduce_sum(buf, group, timers=None):
     """The one collective.  RCCL ("nccl") reduces the device buffer in place; a gloo group (CPU tests, or several
-    ranks sharing one GPU) gets the 1-2 KB payload staged through the host."""
+    ranks sharing one GPU) gets the 1-2 KB payload staged through the host.  `timers`: optional list that receives a
+    (start, end) pair of CUDA events around the collective (bench.py splits its time out of the step)."""
+    ev = None
+    if timers is not None and buf.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     if buf.is_cuda and dist.get_backend(group) == "gloo":
         host = buf.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         buf.copy_(host)
     else:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if ev is not None:
+        ev[1].record()
+        timers.append(ev)
 
 
-def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None, policy="range"):
-    """Multi-GPU esac_forward: every rank holds `scene_coords` (or at least its experts' maps) and
-    the full assignment vector; returns (scores_global [N] f64 device tensor, winning record np[32]).
+def owned_experts(E, rank, world):
+    """Experts whose maps rank `rank` holds under policy "expert": e % world == rank (local index e // world)."""
+    return list(range(rank, E, world))
+
+
+def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None, policy="range", maps="full", timers=None):
+    """Multi-GPU esac_forward: every rank holds `scene_coords` (or only its experts' maps) and the full assignment
+    vector; returns (scores_global [N] f64 device tensor, winning record np[32]).
 
     `params_kw` are the keyword arguments of Engine.make_params except N / hyp_offset.
     policy "range": contiguous index ranges -- the kernels write this rank's scores and record straight into its
     slots of the persistent exchange buffer (hyp_offset keys RNG and tie-breaks), so a call is one memset, the
-    forward launches, the all-reduce and one 1 KB read-back.  policy "expert": shard by expert ownership (index lists)."""
+    forward launches, the all-reduce and the winner pick.
+    policy "expert": shard by expert ownership (expert e lives on rank e % world; index lists).  maps="owned":
+    `scene_coords` is [E_local,3,H,W] holding ONLY this rank's experts (owned_experts(E, rank, world), in that
+    order; pass `E` through params_kw["total_experts"]) -- what BASELINE configs[3]/[4] describe: a rank runs and
+    stores only its own experts."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     ha_full = hyp_assign_full
     n_total = int(ha_full.shape[0])
+    params_kw = dict(params_kw)
+    total_experts = params_kw.pop("total_experts", None)
     E, _, H, W = scene_coords.shape
     dev = engine.device
     if policy == "range":
         # the returned score vector is a view of the persistent buffer: valid until the next call on this device
         buf = contribute_range(engine, scene_coords, ha_full, params_kw, rank, world, _exchange_buffer(dev, n_total, world))
         if world > 1:
-            _all_reduce_sum(buf, group)  # the one collective of this path
-        return pick_global(buf, n_total, world)
+            _all_reduce_sum(buf, group, timers)  # the one collective of this path
+        return pick_global(buf, n_total, world, engine)
     if policy != "expert":
         raise ValueError(policy)
-    gidx = torch.from_numpy(shard_by_expert(ha_full.cpu().numpy(), rank, world))
-    n_local = int(gidx.numel())
-    if n_local > 0:
-        ha_local = ha_full.to(dev)[gidx.to(dev, torch.long)].contiguous()
-        p = engine.make_params(E, H, W, n_local, **params_kw)
+    owned = maps == "owned"
+    if owned and total_experts is None:
+        raise ValueError('maps="owned" needs params_kw["total_experts"]')
+    key = ("expert", str(dev), n_total, world, rank, owned, int(ha_full.data_ptr()) if ha_full.is_cuda else id(ha_full))
+    shard = _shard_cache.get(key)
+    if shard is None:  # the shard of an assignment vector: index list + local assignment, built once per vector
+        if len(_shard_cache) > 64:
+            _shard_cache.clear()
+        gidx = torch.from_numpy(shard_by_expert(ha_full.cpu().numpy(), rank, world))
         gidx_dev = gidx.to(dev).contiguous()
+        ha_local = ha_full.to(dev)[gidx_dev.to(torch.long)].contiguous() if gidx.numel() else torch.empty(0, dtype=torch.int64, device=dev)
+        if owned:
+            ha_local = torch.div(ha_local, world, rounding_mode="floor")  # e -> its index among this rank's maps
+        shard = _shard_cache[key] = (gidx_dev, ha_local, ha_full)
+    gidx_dev, ha_local, _ = shard
+    n_local = int(gidx_dev.numel())
+    buf = _exchange_buffer(dev, n_total, world)
+    buf.zero_()
+    if n_local > 0:
+        p = engine.make_params(E, H, W, n_local, **params_kw)
         engine.set_hyp_index(p, gidx_dev)
         scores_local = torch.empty(n_local, dtype=torch.float64, device=dev)
-        record = torch.empty(RES_DOUBLES, dtype=torch.float64, device=dev)
+        rec0 = n_total + rank * RES_DOUBLES
+        record = buf[rec0:rec0 + RES_DOUBLES]  # the refinement kernel writes record + ESAC_RES_VALID marker in place
         engine.forward_device(scene_coords, ha_local, p, scores_out=scores_local, result_out=record, want_host=False)
-    else:
-        scores_local = torch.empty(0, dtype=torch.float64, device=dev)
-        record = torch.zeros(RES_DOUBLES, dtype=torch.float64, device=dev)
-    buf = pack_local(scores_local, record, n_total, gidx, rank, world)
+        buf[gidx_dev.to(torch.long)] = scores_local
+        if owned:
+            record[2] = record[2] * world + rank  # local map index -> global expert id (esac.cpp:189 returns it)
     if world > 1:
-        _all_reduce_sum(buf, group)  # the one collective of this path
-    return pick_global(buf, n_total, world)
+        _all_reduce_sum(buf, group, timers)  # the one collective of this path
+    return pick_global(buf, n_total, world, engine)
+
+
+_shard_cache = {}

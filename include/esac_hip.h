@@ -69,6 +69,11 @@ typedef struct esac_hip_params {
  * The score vector, ESAC_RES_PROB and ESAC_RES_ENTROPY are then the reference's own values (softMax / entropy,
  * esac_util.h:461-497) for every hypothesis; the winner and the pose are the same either way. */
 #define ESAC_FLAG_EXACT_SCORES 1
+/* Shape of the fp32 ranking score (results are the same to fp32 rounding; default: chosen from grid size and N).
+ * TILED: map tiles stationary in registers, hypotheses bucketed by expert stream past them (large maps);
+ * STREAM: one hypothesis per workgroup streams its expert's whole map (small, cache-resident maps). */
+#define ESAC_FLAG_SCORE_TILED 2
+#define ESAC_FLAG_SCORE_STREAM 4
 
 #define ESAC_DEFAULT_MARGIN 1e-3f
 
@@ -164,6 +169,15 @@ int esac_hip_forward_batch(esac_hip_ctx* ctx, int B, const float* d_scene_coords
                            double* d_scores_out, double* d_result_out, double* h_result_out);
 
 /*
+ * Multi-GPU exchange (new; the reference has no multi-device path): d_records = `world` result records of
+ * ESAC_RES_DOUBLES doubles each (device), e.g. the tail of the all-reduced buffer [N scores | world records] with
+ * all-zero records for ranks without hypotheses (ESAC_RES_VALID marks real ones).  Picks the global winner -- highest
+ * exact score, lowest global hypothesis index on ties (esac_util.h:519) -- on the device and delivers it to
+ * h_record_out (blocking, through pinned memory).  -11: no rank contributed a record.
+ */
+int esac_hip_pick_record(esac_hip_ctx* ctx, const double* d_records, int world, void* stream, double* h_record_out);
+
+/*
  * esac_backward (esac.cpp:213-520): expected pose loss over the hypothesis distribution and its gradient wrt the
  * scene coordinates, everything on the device.
  * Status -10: hypAssignment held a value outside [0,E) (the reference reads out of bounds there).
@@ -217,6 +231,12 @@ int esac_hip_phase_ms(esac_hip_ctx* ctx, float out[6]);
  * rocprofv3's kernel trace reports (hipEvents around one ~3 us launch also contain the launch gap).
  * Synchronises the device. */
 int esac_hip_score_span_ms(esac_hip_ctx* ctx, float* mean_ms, int* launches);
+/* Mean GPU time (ms) of each stage -- sample, score, select(+re-score), refine -- for this input: the chain runs once,
+ * then each stage is launched `reps` times back to back between one pair of hipEvents on `stream` (includes the ~1.5 us
+ * dependent-kernel boundary per launch, excludes the per-event overhead that brackets around single launches carry).
+ * Blocking.  out_ms[0..3]. */
+int esac_hip_time_stages(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
+                         const esac_hip_params* p, void* stream, int reps, float out_ms[4]);
 /* enable/disable the per-phase events (off by default: zero overhead).  enabled = k > 1 samples every k-th forward
  * call only, starting with the next one (the events themselves cost GPU time: an empty pair reads ~5 us). */
 int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);

@@ -86,17 +86,25 @@ def _two_rank_worker(rank, world, port, policy, q):
         eng = api.Engine(0)
         f = S.make_frame(62, E=3, true_expert=1)
         ha = torch.from_numpy(S.gating_assignment(f, 250, mode="gating")).cuda()
-        sc = torch.from_numpy(f["coords"]).cuda()
+        maps = "full"
+        if policy == "expert-owned":  # this rank holds ONLY its experts' maps (e % world == rank)
+            policy, maps = "expert", "owned"
+            sc = torch.from_numpy(np.ascontiguousarray(f["coords"][D.owned_experts(3, rank, world)])).cuda()
+        else:
+            sc = torch.from_numpy(f["coords"]).cuda()
         out = []
         for call in (20, 21):  # two frames: the persistent exchange buffer is re-zeroed between calls
-            scores_g, best = D.forward_sharded(eng, sc, ha, dict(seed=1305, call=call), policy=policy)
+            kw = dict(seed=1305, call=call)
+            if maps == "owned":
+                kw["total_experts"] = 3
+            scores_g, best = D.forward_sharded(eng, sc, ha, kw, policy=policy, maps=maps)
             out.append((scores_g.cpu().numpy().copy(), best.copy()))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,policy", [(2, "range"), (3, "range"), (2, "expert")])
+@pytest.mark.parametrize("world,policy", [(2, "range"), (3, "range"), (2, "expert"), (2, "expert-owned"), (3, "expert-owned")])
 def test_forward_sharded_across_processes_on_one_device(engine, world, policy):
     """The whole multi-rank path as the bench drives it -- forward_sharded in `world` processes, one collective per
     frame -- with gloo standing in for RCCL: every rank ends with the same winner, and it is the unsharded winner."""
@@ -127,10 +135,7 @@ def test_forward_sharded_across_processes_on_one_device(engine, world, policy):
             np.testing.assert_array_equal(scores_g, results[0][i][0])  # every rank holds the same global score vector
 
 
-def test_bench_multi_rank_path_on_one_device():
-    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with
-    two ranks sharing the one GPU through the ESAC_BENCH_ONE_DEVICE test hook (gloo instead of RCCL): barrier-bracketed
-    timing, max over ranks, ONE JSON line from rank 0 with the whole-job aggregate."""
+def _run_bench(world, extra):
     import json
     import subprocess
     import sys
@@ -140,14 +145,33 @@ def test_bench_multi_rank_path_on_one_device():
     s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ESAC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "30",
-                          "--warmup", "4"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world)] + extra,
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_multi_rank_path_on_one_device():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), here with
+    two ranks sharing the one GPU through the ESAC_BENCH_ONE_DEVICE test hook (gloo instead of RCCL): barrier-bracketed
+    timing, max over ranks, ONE JSON line from rank 0 with the whole-job aggregate."""
+    d = _run_bench(2, ["--steps", "30", "--warmup", "4"])
     assert d["n_gpus"] == 2 and d["steps"] == 30 and d["warmup"] == 4 and d["scaling"] == "weak"
-    assert d["config"]["hypotheses_total"] == 512 and d["config"]["hypotheses_per_gpu"] == 256
+    assert d["config"]["hypotheses_total"] == 512 and d["config"]["shard_sizes"] == [256, 256] and d["config"]["policy"] == "range"
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "batched" not in d and "cpu_baseline" not in d  # single-GPU extras only
+    assert d["allreduce_ms"] is not None and d["allreduce_ms"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_expert_sharded_strong_scaling_on_one_device(world):
+    """BASELINE configs[3] as the driver would run it on several GPUs: experts (and their maps) owned by rank e % world,
+    hypotheses sharded by expert ownership, strong scaling -- here 2 and 3 ranks on the one GPU."""
+    d = _run_bench(world, ["--config", "cfg4", "--steps", "6", "--warmup", "2"])
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["policy"] == "expert"
+    assert d["config"]["hypotheses_total"] == 4096 and sum(d["config"]["shard_sizes"]) == 4096 and len(d["config"]["shard_sizes"]) == world
+    assert d["value"] > 0 and abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "only its own experts' maps" in d["config"]["parallelism"]

@@ -72,3 +72,33 @@ def test_world_frame_coordinates_far_from_the_origin(engine, oracle):
     np.testing.assert_array_equal(engine.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
     r, t = S.pose_errors(res[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
     assert r <= 1e-4 and t <= 1e-3, (r, t)
+
+
+@pytest.mark.parametrize("shape", [(60, 80, 8, 5, 700), (45, 64, 10, 1, 300), (128, 160, 4, 70, 2500)])
+def test_tiled_score_equals_the_per_hypothesis_stream(engine, oracle, shape):
+    """The two shapes of the fp32 ranking score (tile-stationary with hypotheses bucketed by expert vs one hypothesis per
+    workgroup) on grids whose last sub-tile is partly filled (4800, 2880 cells) or exactly filled (20480), with empty
+    experts and experts of several chunks: same scores to fp32 rounding, both within the band of the reference arithmetic."""
+    H, W, sub, E, N = shape
+    f = S.make_frame(210, E=E, true_expert=E // 2, H=H, W=W, sub=sub)
+    ha = S.gating_assignment(f, N, mode="dirichlet" if E > 1 else "single")
+    ha[::3] = E // 2
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    kw = dict(shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=sub, seed=3, call=9)
+    ref = oracle.forward(f["coords"], ha, **kw)
+    out = {}
+    for mode in ("stream", "tiled"):
+        p = engine.make_params(E, H, W, N, score_shape=mode, **kw)
+        engine.sample(sc, hat, p)
+        engine.score(sc, hat, p)
+        engine.select(sc, hat, p)
+        out[mode] = (engine.read(api.BUF_SCORES), engine.read(api.BUF_EXACT_FLAGS).astype(bool))
+        res = engine.forward_device(sc, hat, p)
+        assert int(res[api.RES_HYP]) == ref["winner"], mode
+    (s_s, f_s), (s_t, f_t) = out["stream"], out["tiled"]
+    both = ~f_s & ~f_t
+    assert both.sum() > N // 2
+    assert np.abs(s_s[both] - s_t[both]).max() <= 2e-4
+    d = np.abs(s_t[~f_t] - ref["scores"][~f_t])
+    assert np.sort(d)[-3:].max() <= 2 * 100.0 / (H * W) + 2e-3 and np.median(d) <= 1e-4
+    np.testing.assert_allclose(s_t[f_t], ref["scores"][f_t], rtol=0, atol=1e-7)

@@ -86,10 +86,10 @@ extern "C" int esac_hip_device_count(void) {
 }
 
 static void free_ws(esac_hip_ctx* c) {
-    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.best_try,   c->ws.fast_scores,
+    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
-                    c->ws.status,     c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials};
+                    c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials};
     c->tN = c->tChunks = 0;
     c->tPart = 0;
     for (void* p : ptrs)
@@ -163,9 +163,10 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.hyps, (size_t)nN * 6);
     rc |= alloc(&c->ws.rt32, (size_t)nN * 12);
     rc |= alloc(&c->ws.status, (size_t)1);
+    rc |= alloc(&c->ws.coop_partials, (size_t)2 * ESAC_REFINE_COOP_MAX * 32);
+    rc |= alloc(&c->ws.coop_counter, (size_t)2);
     rc |= alloc(&c->ws.sample_xy, (size_t)nN * 8);
     rc |= alloc(&c->ws.tries, (size_t)nN);
-    rc |= alloc(&c->ws.best_try, (size_t)nN);
     rc |= alloc(&c->ws.fast_scores, (size_t)nN);
     rc |= alloc(&c->ws.scores, (size_t)nN);
     rc |= alloc(&c->ws.exact_flag, (size_t)nN);
@@ -418,8 +419,11 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         for (int b = 0; b < B; b++) {
             memcpy(h_result_out + (size_t)b * ESAC_RES_DOUBLES, (const void*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES),
                    ESAC_RES_DOUBLES * sizeof(double));
-            bad_assign |= c->h_pin[(size_t)b * ESAC_PIN_DOUBLES + 33] != 0.0;
+            bad_assign |= c->h_pin[(size_t)b * ESAC_PIN_DOUBLES + 33] == 1.0;
         }
+        for (int b = 0; b < B; b++)
+            if (c->h_pin[(size_t)b * ESAC_PIN_DOUBLES + 33] == 3.0)
+                return fail(-12, "esac_hip_forward: the cooperating refinement workgroups could not synchronise (not all of them became resident)");
         if (bad_assign)
             return fail(-10, "hypAssignment holds a value outside [0,%d) (device-resident tensor; such hypotheses were scored against expert 0)", p->E);
     }

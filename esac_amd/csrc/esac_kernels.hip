@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "pose_math.hpp"
+#include "p3p_screen.hpp"
 #include "rng.hpp"
 #include "esac_kernels.hpp"
 #include "device_common.hpp"
@@ -161,7 +162,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
     } else if ((lane & 15) == 0) {
         a.tries[h] = SAMPLE_PENDING;
-        a.best_try[h] = 0x7fffffff;  // k_sample_search: lowest accepted try found so far
     }
 }
 
@@ -264,25 +264,29 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     }
 }
 
-// ---- throughput shape, tries >= first_try: search and commit -----------------------------------------------------------
-// A hypothesis of a wrong expert needs ~10^3 tries (its 4 points only pass tau by luck) and now and then 10^4: with one
-// wavefront per hypothesis walking its tries 64 at a time, the launch lasts as long as the unluckiest hypothesis (228
-// sequential rounds on config 5a: 2.1 of the call's 2.25 ms) while most of the chip idles.  Here the search is spread:
-// SEARCH_WPH wavefronts share a pending hypothesis, wavefront w takes rounds w, w + WPH, w + 2 WPH, ... (64 tries each),
-// publishes the lowest accepted try with atomicMin and stops as soon as its next round starts above the published
-// value.  Every try below the final minimum has been evaluated and rejected by someone, so the minimum IS the try the
-// reference's sequential loop stops at (esac_util.h:152-223).  The search keeps no pose: k_sample_commit re-solves
-// exactly that try (same code, same result) and stores the hypothesis -- or the state of the last try when the budget
-// ran out.
-constexpr int SEARCH_WPH = 16;
-#ifndef ESAC_SEARCH_WAVES
-#define ESAC_SEARCH_WAVES 1  // wavefronts per SIMD the search kernel is compiled for (register budget 512 / waves)
-#endif
+// ---- throughput shape, tries >= first_try: screened sampling -----------------------------------------------------------
+// A hypothesis of a wrong expert needs ~10^3 tries (its 4 points only pass tau by luck), and half of the fp64 work of a
+// try -- per candidate root the least-squares triangle alignment with its Newton iterations, the pose conversion and
+// the reprojections -- is spent on candidates whose 4th point misses its pixel by hundreds of pixels.  Here every try
+// first runs the roots and depths of the fp64 route (p3p_setup, p3p_candidate_lengths: the same doubles) and then the fp32
+// SCREEN of p3p_screen.hpp instead of the alignment; only a try the screen cannot rule out ("maybe": 4th point within
+// tau + SCREEN_MARGIN, or a numerically delicate configuration) gets the full fp64 decision, exactly as before.  The
+// screen is one-sided (calibrated on 4e7 tries: scripts/dev/p3p_screen_probe.py), so the accepted try is still the try
+// the reference's sequential loop stops at (esac_util.h:152-223).
+// One wavefront per hypothesis, 64 tries per round.  "Maybe" tries are queued in LDS (in try order) and decided 64 lanes
+// wide: a lone maybe would otherwise cost the whole wavefront a full fp64 solve.  The queue is flushed when it holds
+// SCREEN_FLUSH tries, when the screen itself sees a 4th point within tau (almost certainly the accepted try), and at
+// the end of the budget.
+constexpr float SCREEN_MARGIN = 3.0f;  // pixels; the largest screen error of an fp64-accepted try in calibration: tau + 0.008
+constexpr int SCREEN_FLUSH = 8;
+constexpr int SCREEN_QUEUE = 128;
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ESAC_SEARCH_WAVES, ESAC_SEARCH_WAVES))) void k_sample_search(KArgs a) {
+__global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
+    __shared__ int s_queue[SCREEN_QUEUE];
     frame_view(a);
-    const int h = blockIdx.x, w = blockIdx.z, lane = threadIdx.x;
-    if (a.tries[h] != SAMPLE_PENDING) return;
+    const int h = blockIdx.x, lane = threadIdx.x;
+    if (a.first_try > 0 && a.tries[h] != SAMPLE_PENDING) return;
+    if (a.first_try == 0 && lane == 0) flag_bad_assignment(a, h);
     const int e = expert_of(a, h);
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
@@ -290,53 +294,70 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ESAC_SEARCH_
     const Cam cam = make_cam(a);
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const double tau = (double)a.tau;
-    int* best = a.best_try + h;
-    for (long long base = (long long)a.first_try + 64LL * w; base < a.max_tries; base += 64LL * SEARCH_WPH) {
-        if (base >= __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;  // someone accepted an earlier try
-        const int t = (int)base + lane;
-        bool accepted = false;
-        if (t < a.max_tries) {
-            int cx[4], cy[4];
-            V3 Pt[4];
-            float Pf[4][3];
-            double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
-            gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-            if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2) && !cannot_pass(reproj2, tau)) {
-                double rvec[3], T[3], R[9];
-                accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, tau, rvec, T, R);
+    const float thr = a.tau + SCREEN_MARGIN;
+    int qcount = 0;  // wave-uniform
+    for (long long base = a.first_try;; base += 64) {
+        const bool more = base < a.max_tries;
+        bool strong = false;
+        if (more) {
+            const int t = (int)base + lane;
+            bool maybe = false;
+            if (t < a.max_tries) {
+                int cx[4], cy[4];
+                V3 Pt[4];
+                float Pf[4][3];
+                double mu[4], mv[4];
+                gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+                P3PSetup S;
+                if (p3p_setup(Pt, mu, mv, cam, S)) {
+                    const float err = p3p_screen_roots(S, Pf, (float)mu[3], (float)mv[3], a.focal, a.ppx, a.ppy);
+                    maybe = !(err > thr);                        // delicate (-1) and NaN included
+                    strong = maybe && err >= 0.0f && err <= a.tau;  // the screen itself sees an inlier
+                }
+            }
+            const unsigned long long m = __ballot(maybe);
+            if (maybe) s_queue[qcount + __popcll(m & ((1ull << lane) - 1ull))] = t;  // try order: lanes ascend, rounds ascend
+            qcount += __popcll(m);
+        }
+        if (!(!more || __any(strong) || qcount >= SCREEN_FLUSH)) continue;
+        // ---- decide the queued tries in the fp64 route, 64 at a time (the queue never holds more than 7 + 64); ONE code
+        // site (the kernel must stay inside the instruction cache): when the budget is exhausted without an accepted
+        // try, a last pass re-solves the final try, whose state remains (esac_util.h:152-223 leaves the pose of the last
+        // iteration, a failed solve the zero pose)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        bool final_pass = false;
+        for (int q0 = 0;; q0 += 64) {
+            if (!final_pass && q0 >= qcount) {
+                if (more) break;
+                final_pass = true;
+            }
+            const bool mine = final_pass ? lane == 0 : q0 + lane < qcount;
+            int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
+            double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
+            double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            bool accepted = false;
+            int t = 0;
+            if (mine) {
+                t = final_pass ? a.max_tries - 1 : s_queue[q0 + lane];
+                V3 Pt[4];
+                float Pf[4][3];
+                double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
+                gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+                if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2) && (final_pass || !cannot_pass(reproj2, tau)))
+                    accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, tau, rvec, T, R);
+            }
+            const unsigned long long am = __ballot(accepted);
+            if (am) {  // lowest queue position = lowest try index
+                if (lane == __ffsll((long long)am) - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, t);
+                return;
+            }
+            if (final_pass) {
+                if (lane == 0) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);
+                return;
             }
         }
-        const unsigned long long m = __ballot(accepted);
-        if (m) {
-            if (lane == 0) atomicMin(best, (int)base + __ffsll((long long)m) - 1);
-            break;
-        }
+        qcount = 0;
     }
-}
-
-// one lane per pending hypothesis: re-solve the try the search settled on (or the last try of an exhausted budget, whose
-// state remains: esac_util.h:152-223 leaves the pose of the final iteration, a failed solve the zero pose) and store it
-__global__ __launch_bounds__(64) void k_sample_commit(KArgs a) {
-    frame_view(a);
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= a.N || a.tries[h] != SAMPLE_PENDING) return;
-    const int found = a.best_try[h];
-    const bool exhausted = found == 0x7fffffff;
-    const int t = exhausted ? a.max_tries - 1 : found;
-    const int e = expert_of(a, h);
-    const int P = a.H * a.W;
-    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
-    const Philox rng(a.seed, a.call);
-    const Cam cam = make_cam(a);
-    int cx[4], cy[4];
-    V3 Pt[4];
-    float Pf[4][3];
-    double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
-    double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
-    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    gather_sample(a, map, P, rng, (uint32_t)global_hyp(a, h), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-    if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2)) accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
-    store_hypothesis(a, h, map, rvec, T, R, cx, cy, exhausted ? -1 : t);
 }
 
 // (rvec,tvec) -> float [R | t + R c] for the fp32 scoring stream (hypotheses handed in through esac_hip_write_hyps)
@@ -667,16 +688,17 @@ void launch_sample(const KArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, a);
     else if (total <= 4096)
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, a);
-    else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by search + commit
+    else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest one wavefront each, screened
         KArgs b = a;
         for (int pass = 0; pass < FIRST_PHASE_PASSES && b.first_try < a.max_tries; pass++) {
             hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
             b.first_try += FIRST_PHASE_TRIES;
         }
-        if (b.first_try < a.max_tries) {
-            hipLaunchKernelGGL(k_sample_search, dim3(a.N, a.frames, SEARCH_WPH), dim3(64), 0, s, b);
-            hipLaunchKernelGGL(k_sample_commit, dim3((a.N + 63) / 64, a.frames), dim3(64), 0, s, b);
-        }
+#ifdef ESAC_SAMPLE_UNSCREENED  // A/B switch (scripts/dev/variants.sh): the round-1 kernel, every try solved in full
+        if (b.first_try < a.max_tries) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
+#else
+        if (b.first_try < a.max_tries) hipLaunchKernelGGL(k_sample_screened, dim3(a.N, a.frames), dim3(64), 0, s, b);
+#endif
     }
 }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {

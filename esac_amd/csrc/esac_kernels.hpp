@@ -14,6 +14,7 @@ constexpr int ESAC_BWD_SLOTS_K = 1000;     // = ESAC_BWD_MAX_SLOTS (include/esac
 constexpr int ESAC_REFINE_LDS_CAP = 8192;  // correspondences the refinement kernel stages in LDS (128 KiB of the CU's 160 KiB)
 constexpr int ESAC_REFINE_THREADS = 256;   // 4 wavefronts = one per SIMD of the one CU a refinement occupies
 constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the error pass
+constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refinement (one per CU: all must be resident)
 constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result record [32] + epoch word + status word
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
 constexpr int ESAC_TILED_HC = 256;            // hypotheses per chunk of the tile-stationary score kernel
@@ -69,7 +70,6 @@ struct KArgs {
     float* rt32;          // [N,12] float(R(rvec)), float(t)
     int* sample_xy;       // [N,8]
     int* tries;           // [N]
-    int* best_try;        // [N] lowest accepted try found so far by the spread search (k_sample_search)
     float* fast_scores;   // [N]
     double* scores;       // [N]
     uint8_t* exact_flag;  // [N]
@@ -84,6 +84,10 @@ struct KArgs {
     long long* tstamps;   // [2N] per-workgroup (start,end) wall-clock stamps of the score kernel, or nullptr
     long long* span_acc;  // [2] accumulated score-kernel span (100 MHz ticks) and launch count
     unsigned long long* status;  // [1] epoch of the last call whose hypAssignment held a value outside [0,E) (0: never)
+    // cooperating refinement workgroups (esac_refine.hip, struct Coop); coop_slice is set by the launcher
+    double* coop_partials;              // [2][ESAC_REFINE_COOP_MAX][32]
+    unsigned long long* coop_counter;   // [2] arrival counter, "a barrier timed out" flag
+    int coop_slice;
     // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
     int* order;           // [N] hypothesis at sorted position pos (sorted by expert)
     float* rt_sorted;     // [N,12] rt32 rows in sorted order

@@ -152,6 +152,81 @@ __device__ __forceinline__ double pow10_int(int k) {
     return k < 0 ? 1.0 / r : r;
 }
 
+// ---- cooperating workgroups (large grids) --------------------------------------------------------------------------------
+// At 60x80 a refinement is one workgroup: its ~35 reduction points carry ~3.5 us of work each, less than a round through
+// global memory costs.  At 480x640 a pass over the grid is ~700 us of one CU's time and the same round (~4 us) is noise:
+// G workgroups then share the refinement.  Workgroup g owns the cells [g * slice, (g+1) * slice) -- its part of every
+// error pass and, in its own LDS, the correspondences found there -- and every reduction (inlier count, the 24 moments of
+// an LM pass) becomes: block sum -> partial[g] in global memory -> barrier -> every workgroup adds the G partials in the
+// same fixed order.  All workgroups then hold bitwise identical sums, take the same LM / stopping decisions and carry
+// the same pose: nothing is ever broadcast.  The barrier is one monotonic counter: release fence + atomic arrive by one
+// lane, relaxed device-scope polling with s_sleep, ONE acquire fence, __syncthreads (MI355X_MICROARCH.md, "Workgroup
+// dispatch ... inter-workgroup visibility"); partial sums are double-buffered by phase parity, so one barrier per
+// reduction suffices.  All G workgroups must be resident (G <= 256 one-per-CU workgroups); the spin is bounded and a
+// timeout marks the call as failed instead of hanging it.
+struct Coop {
+    int G, g;                      // number of cooperating workgroups, this one's index (G == 1: no cooperation)
+    double* partials;              // [2][G][32]
+    unsigned long long* counter;   // monotonic arrival counter, zeroed by the launcher
+    unsigned long long* failed;    // set when a barrier timed out
+    unsigned long long arrivals;   // barriers passed so far (same in every thread of every workgroup)
+};
+
+// v[0..NV) <- sum over the G workgroups of their v (every thread of a workgroup enters with the same v, leaves with the
+// same total; s_tot: >= 28 doubles of LDS scratch).  No-op for G == 1.
+template <int NV>
+__device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double* s_tot, double* s_part) {
+    static_assert(NV <= 28, "partials hold 32 doubles per workgroup");
+    if (co.G == 1) return;
+    double* buf = co.partials + (size_t)(co.arrivals & 1ull) * co.G * 32;
+    __syncthreads();
+    // publish: NV lanes store this workgroup's sums, ONE lane releases them at device scope and arrives
+    if (threadIdx.x < NV) {
+        double mine = v[0];
+#pragma unroll
+        for (int k = 1; k < NV; k++) mine = (int)threadIdx.x == k ? v[k] : mine;
+        buf[(size_t)co.g * 32 + threadIdx.x] = mine;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(co.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (co.arrivals + 1ull) * (unsigned long long)co.G;
+        long spins = 0;
+        while (__hip_atomic_load(co.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1L << 25)) {  // ~seconds: a workgroup of this launch never became resident
+                __hip_atomic_store(co.failed, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    // gather: 8 groups of 32 lanes, group j adds the partials of workgroups j, j+8, j+16, ... (loads independent of each
+    // other), then value k adds its 8 group sums -- one fixed order for every workgroup: bitwise identical totals
+    {
+        const int k = threadIdx.x & 31, j = threadIdx.x >> 5;
+        double t = 0;
+        if (k < NV)
+            for (int w = j; w < co.G; w += 8) t += buf[(size_t)w * 32 + k];
+        s_part[j * 32 + k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) t += s_part[j * 32 + threadIdx.x];
+        s_tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = s_tot[k];
+    __syncthreads();
+    co.arrivals += 1ull;
+}
+
 // Fused pass over the whole grid at `pose`:
 //   a.errs[i]  = min(reprojection error, maxReproj)                (getReproErrs, esac_util.h:292-360);
 //                reference-exact near tau, fp32-accurate (~1e-3 px) elsewhere -- see the screening below;
@@ -159,10 +234,14 @@ __device__ __forceinline__ double pow10_int(int k) {
 //   map_out[i] = err < tau                                         (localInlierMap, esac_util.h:401-414)
 //   list[...]  = the inliers, compacted per wavefront: wavefront w owns list[w * corr_region(P) ...], n_wave entries
 // Returns the inlier count (same value in every thread).
+// Cooperative form: this workgroup handles the cells [cell0, cell0 + Pn) of the P-cell grid (cell0 a multiple of the
+// trip size); the returned count is the total over all workgroups.
 template <int B, bool VEC, typename ListPtr>
 __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __restrict__ mx, int P, const double pose[6],
                                                const Cam& cam, ListPtr list, int& n_wave, uint8_t* __restrict__ map_out,
-                                               int* s_wcnt, long long* g_cyc) {
+                                               int* s_wcnt, long long* g_cyc, int cell0 = 0, int Pn = -1, Coop* co = nullptr,
+                                               double* s_tot = nullptr, double* s_part = nullptr) {
+    if (Pn < 0) Pn = P;
     CYC_DECL;
     // VEC: every lane owns G groups of 4 CONSECUTIVE cells per trip (W % 4 == 0: a group never straddles a
     // row, planes are 16-byte aligned) -> float4 loads, one float4 + one packed-byte store per group.
@@ -192,12 +271,13 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
     const float tau_below = nextafterf(a.tau, -INFINITY);
     // a lane's groups advance by B*L cells per step: (row, col) kept incrementally, one division in total
     const int stepR = (B * L) / a.W, stepC = B * L - stepR * a.W;
-    int row = ((int)threadIdx.x * L) / a.W, col = (int)threadIdx.x * L - row * a.W;
-    const int region = corr_region(P);  // list entries per wavefront
+    int row = (cell0 + (int)threadIdx.x * L) / a.W, col = cell0 + (int)threadIdx.x * L - row * a.W;
+    const int region = corr_region(Pn);  // list entries per wavefront
     const auto wlist = list + (size_t)wave * region;
     int wcount = 0;
-    for (int start = 0; start < P; start += B * U) {
-        const bool full = start + B * U <= P;  // wave-uniform: no bounds checks in full trips
+    const int cell_end = cell0 + Pn;
+    for (int start = cell0; start < cell_end; start += B * U) {
+        const bool full = start + B * U <= cell_end;  // wave-uniform: no bounds checks in full trips
         float X[U], Y[U], Z[U], pxf[U], pyf[U], errv[U];
         int coli[U], rowi[U], cell[G];
         bool flag[U];
@@ -206,7 +286,7 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
         for (int g = 0; g < G; g++) {  // all loads first: one memory latency for the U cells
             const int i = start + (g * B + (int)threadIdx.x) * L;
             cell[g] = i;
-            const int ic = full ? i : (i < P ? i : P - L);
+            const int ic = full ? i : (i < cell_end ? i : cell_end - L);
             if (VEC) {
                 const float4 vx = *reinterpret_cast<const float4*>(mx + ic);
                 const float4 vy = *reinterpret_cast<const float4*>(mx + P + ic);
@@ -285,7 +365,7 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
         CYC_BEGIN();
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            const bool in_range = full || cell[g] < P;
+            const bool in_range = full || cell[g] < cell_end;
 #pragma unroll
             for (int l = 0; l < L; l++) {
                 const int u = g * L + l;
@@ -325,6 +405,11 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
 #pragma unroll
     for (int w = 0; w < NW; w++) base += s_wcnt[w];
     n_wave = wcount < region ? wcount : region;
+    if (co && co->G > 1) {  // total over the cooperating workgroups (exact in double: counts < 2^28)
+        double cnt[1] = {(double)base};
+        coop_allreduce<1>(cnt, *co, s_tot, s_part);
+        base = (int)cnt[0];
+    }
     CYC_END(14);
     return base;
 }
@@ -337,7 +422,7 @@ struct PxMap {
 };
 template <int B, typename ListPtr>
 __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double param[6], const Cam& cam, const PxMap& pm, double U21[21],
-                                          double g6[6], double* s_part, double* s_tot, long long* g_cyc) {
+                                          double g6[6], double* s_part, double* s_tot, long long* g_cyc, Coop* co = nullptr) {
     CYC_DECL;
     CYC_BEGIN();
     double R[9];
@@ -381,6 +466,7 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
     CYC_END(5);
     CYC_BEGIN();
     block_sum28<LM_NMOM, B>(mom, s_part, s_tot);
+    if (co) coop_allreduce<LM_NMOM>(mom, *co, s_tot, s_part);
     CYC_END(6);
     CYC_BEGIN();
     double acc[LM_NACC];
@@ -397,7 +483,7 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
 // with the pass inlined at several sites the code grew to 170 KB and every phase ran from cold code).
 template <int B, typename ListPtr>
 __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], const Cam& cam, const PxMap& pm, double* s_part,
-                                        double* s_tot, long long* g_cyc) {
+                                        double* s_tot, long long* g_cyc, Coop* co = nullptr) {
     CYC_DECL;
     double param[6], prev[6];
 #pragma unroll
@@ -409,7 +495,7 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
     bool have_base = false;
     for (;;) {
         // residual norm and (speculatively) the normal equations at `param`
-        const double err_norm = sqrt(lm_pass<B>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc));
+        const double err_norm = sqrt(lm_pass<B>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc, co));
         bool accept;
         if (!have_base) {
             have_base = true;  // iters == 0: prevErrNorm = |err(initial pose)|
@@ -456,10 +542,14 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
 // VEC: 16-byte accesses in the error pass (W % 4 == 0 and a 16-byte aligned coordinate tensor).
 // SLOTS: training path -- workgroup b refines the hypothesis of selection slot b (esac.cpp:328-347) and leaves
 // its refined pose and inlier maps in the BwdArgs buffers instead of picking the winner and writing the record.
-template <int B, bool GLOBAL_LIST, bool VEC, bool SLOTS>
+// COOP: gridDim.x workgroups share one refinement (see struct Coop): workgroup g owns the cells [g * coop_slice, ...), its
+// correspondences live in its own LDS list (GLOBAL_LIST must be false: a slice never exceeds LDS_CAP cells), workgroup 0
+// writes the outputs.
+template <int B, bool GLOBAL_LIST, bool VEC, bool SLOTS, bool COOP = false>
 __global__ __launch_bounds__(B) void k_refine(KArgs a) {
+    static_assert(!COOP || (!GLOBAL_LIST && !SLOTS), "cooperating workgroups keep their slices' lists in LDS; winner refinement only");
     __shared__ Corr s_list[GLOBAL_LIST ? 1 : LDS_CAP];
-    __shared__ double s_part[28 * (B / 64)];
+    __shared__ double s_part[COOP ? 256 : 28 * (B / 64)];  // block reductions; the cooperative gather uses 8 x 32
     __shared__ double s_tot[28];
     __shared__ double s_best[B / 64];
     __shared__ int s_besti[B / 64];
@@ -479,6 +569,17 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
 #endif
     CYC_BEGIN();
     if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
+    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull};
+    if (COOP) {
+        co.G = (int)gridDim.x;
+        co.g = (int)blockIdx.x;
+        co.partials = a.coop_partials;
+        co.counter = a.coop_counter;
+        co.failed = a.coop_counter + 1;
+    }
+    const bool writer = !COOP || co.g == 0;          // the workgroup that owns the outputs
+    const int cell0 = COOP ? co.g * a.coop_slice : 0;  // this workgroup's cells: [cell0, cell0 + Pn)
+    const int Pn = COOP ? (P - cell0 < a.coop_slice ? P - cell0 : a.coop_slice) : P;
 
     // ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties
     //      (esac_util.h:512-529; softmax is monotone, so the argmax of the scores is the argmax of the probabilities)
@@ -534,7 +635,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     double pose[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
-    if (!SLOTS)
+    if (!SLOTS && writer)
         for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;
     __syncthreads();
     CYC_END(1);
@@ -544,7 +645,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
                        : SLOTS      ? reinterpret_cast<Corr*>(a.bwd.corr_lists) + (size_t)blockIdx.x * corr_entries(P)
                                     : reinterpret_cast<Corr*>(a.corr_list);
     uint8_t* const maps = SLOTS ? a.bwd.maps + (size_t)blockIdx.x * 2 * P : a.inlier_map;
-    const Corr* const my_list = list + (size_t)wave * corr_region(P);  // the region this wavefront fills and reads
+    const Corr* const my_list = list + (size_t)wave * corr_region(Pn);  // the region this wavefront fills and reads
     int n_wave = 0;
     int accepted = 0, last_inliers = 0, lm_total = 0, map_buf = -1;
     int cur = 0;  // map buffer the next error pass writes
@@ -554,14 +655,15 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         // this step's inlier set and its compacted correspondence list
         CYC_BEGIN();
         __syncthreads();  // every lane is done reading the list before it is rebuilt
-        const int n_inl = error_pass_impl<B, VEC>(a, mx, P, pose, cam, list, n_wave, maps + (size_t)cur * P, s_wcnt, g_cyc);
+        const int n_inl = error_pass_impl<B, VEC>(a, mx, P, pose, cam, list, n_wave, maps + (size_t)cur * P, s_wcnt, g_cyc, cell0, Pn,
+                                                  COOP ? &co : nullptr, s_tot, s_part);
         __syncthreads();
         CYC_END(2);
         if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
-        if (!SLOTS && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
+        if (!SLOTS && writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
         if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
         best_inliers = (unsigned)n_inl;
-        lm_total += lm_refit<B>(my_list, n_wave, pose, cam, pm, s_part, s_tot, g_cyc);
+        lm_total += lm_refit<B>(my_list, n_wave, pose, cam, pm, s_part, s_tot, g_cyc, COOP ? &co : nullptr);
         accepted++;
         last_inliers = n_inl;
         map_buf = cur;  // inlierMap = this step's set (esac_util.h:440)
@@ -581,7 +683,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         return;
     }
     // ---- pose2trans (esac_util.h:537-548) and the result record
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && writer) {
         double R[9];
         rodrigues_vec2mat<false>(pose, R, nullptr);
         double T[16];
@@ -613,6 +715,8 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
 #pragma unroll
             for (int k = 0; k < 32; k++) a.result_pin[k] = r[k];
             a.result_pin[33] = (a.status[0] == (unsigned long long)a.epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment seen by k_sample
+            if (COOP && __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)
+                a.result_pin[33] = 3.0;  // a barrier between the cooperating workgroups timed out: the record is not to be trusted
             __threadfence_system();
             *reinterpret_cast<volatile double*>(a.result_pin + 32) = a.epoch;
         }
@@ -623,11 +727,32 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     }
 }
 
+// Slice of cells per cooperating workgroup (0: the refinement stays in one workgroup): grids beyond the LDS list whose
+// rows vectorise, single frames; 4096 cells (two trips of the error pass) unless that needs more than 256 workgroups.
+int refine_coop_slice(const KArgs& a) {
+    const int P = a.H * a.W;
+    const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
+    if (P <= LDS_CAP || !vec || a.frames != 1 || !a.coop_partials) return 0;
+    constexpr int trip = REFINE_B * ERR_UNROLL;
+    int slice = 2 * trip;
+    if ((P + slice - 1) / slice > ESAC_REFINE_COOP_MAX) slice = ((P + ESAC_REFINE_COOP_MAX - 1) / ESAC_REFINE_COOP_MAX + trip - 1) / trip * trip;
+    return slice <= LDS_CAP ? slice : 0;
+}
+
 void launch_refine(const KArgs& a, hipStream_t s) {
     constexpr int B = REFINE_B;
     const bool global_list = a.H * a.W > LDS_CAP;
     // 16-byte accesses: W % 4 == 0 keeps every row, plane (P % 4 == 0) and expert map 16-byte aligned
     const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
+    const int slice = refine_coop_slice(a);
+    if (slice > 0) {
+        KArgs b = a;
+        b.coop_slice = slice;
+        const int G = (a.H * a.W + slice - 1) / slice;
+        (void)hipMemsetAsync(a.coop_counter, 0, 2 * sizeof(unsigned long long), s);
+        hipLaunchKernelGGL((k_refine<B, false, true, false, true>), dim3(G), dim3(B), 0, s, b);
+        return;
+    }
     if (global_list) {
         if (vec) hipLaunchKernelGGL((k_refine<B, true, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
         else     hipLaunchKernelGGL((k_refine<B, true, false, false>), dim3(1, a.frames), dim3(B), 0, s, a);

@@ -1,0 +1,278 @@
+// p3p_screen.hpp -- fp32 SCREEN for one sampling try (esac_util.h:152-223): can this try possibly be accepted?
+//
+// A hypothesis on a wrong expert's map needs ~10^3 tries before four random cells happen to be consistent with one
+// pose; each try is a 4-point P3P solve in fp64 (pose_math.hpp: ~700-3000 dependent fp64 operations at ~40 cycles of
+// latency each) whose 4th point then misses tau by hundreds of pixels.  The screen runs the same algebra in fp32 --
+// dependent fp32 operations cost a fraction of the fp64 latency and need half the registers, so several wavefronts fit a
+// SIMD -- and answers a ONE-SIDED question: `false` only when every candidate pose puts the 4th point so far from its
+// pixel that no rounding of the fp32 route can bridge the gap; `true` ("maybe") for everything else, including every
+// numerically delicate configuration (near-double roots, tiny pivots, non-finite intermediates).  A "maybe" try is then
+// decided by the fp64 route exactly as before, so the accepted try -- the one the reference's sequential loop stops at --
+// is unchanged; only the work spent on hopeless tries shrinks.  The margin and the delicate-case triggers were
+// calibrated against the fp64 route on 10^8+ tries of all frame kinds (scripts/dev/p3p_screen_probe.cpp,
+// tests/test_device_math_host.py::test_fp32_screen_never_rejects_an_accepted_try).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+
+#include "pose_math.hpp"
+
+namespace esac {
+
+struct V3f {
+    float x, y, z;
+};
+ESAC_HD V3f operator-(V3f a, V3f b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+ESAC_HD V3f operator*(float s, V3f a) { return {s * a.x, s * a.y, s * a.z}; }
+ESAC_HD float dotf(V3f a, V3f b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+ESAC_HD V3f crossf(V3f a, V3f b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+// Real roots of a x^4 + b x^3 + c x^2 + d x + e (Ferrari, same route as quartic_real_roots).  `delicate` is raised
+// whenever a branch is taken within rounding distance of its threshold: the fp64 route may then see a different root set.
+ESAC_HD int quartic_roots_f32(float a, float b, float c, float d, float e, float (&x)[4], int& delicate) {
+    const float kPi = 3.14159265358979f;
+    const float tol = 2e-3f;  // relative width of "within rounding distance" for this fp32 evaluation
+    if (!(fabsf(a) > 1e-20f)) {
+        delicate = 1;
+        return 0;
+    }
+    const float ia = 1.0f / a;
+    b *= ia; c *= ia; d *= ia; e *= ia;
+    const float b2 = b * b, bc = b * c, b3 = b2 * b;
+    // resolvent cubic y^3 - c y^2 + (d b - 4 e) y + (4 c e - d^2 - b^2 e), first real root
+    const float cb = -c, cc = d * b - 4 * e, cd = 4 * c * e - d * d - b2 * e;
+    const float Q = (3 * cc - cb * cb) * (1.0f / 9), R = (9 * cb * cc - 27 * cd - 2 * cb * cb * cb) * (1.0f / 54);
+    const float Q3 = Q * Q * Q, D = Q3 + R * R;
+    const float cb3 = cb * (1.0f / 3);
+    const float mag = fabsf(Q3) + R * R;
+    if (fabsf(D) <= tol * mag) delicate = 2;  // branch of the cubic undecided at fp32
+    float r0;
+    if (D <= 0) {
+        const float sq = sqrtf(fmaxf(-Q3, 0.0f));
+        float arg = sq > 0 ? R / sq : 0.0f;
+        arg = fminf(1.0f, fmaxf(-1.0f, arg));
+        r0 = 2 * sqrtf(fmaxf(-Q, 0.0f)) * cosf(acosf(arg) * (1.0f / 3)) - cb3;
+    } else {
+        const float AD = cbrtf(fabsf(R) + sqrtf(D)) * (R > 0 ? 1.0f : (R < 0 ? -1.0f : 0.0f));
+        const float BD = (AD == 0) ? 0 : -Q / AD;
+        r0 = AD + BD - cb3;
+    }
+    const float R2 = 0.25f * b2 - c + r0;
+    const float scale = 0.25f * b2 + fabsf(c) + fabsf(r0);
+    if (fabsf(R2) <= tol * scale) delicate = 3;
+    if (R2 < 0) return 0;
+    const float Rr = sqrtf(R2);
+    float D2, E2;
+    if (Rr < 1e-5f * (1.0f + sqrtf(scale))) {
+        delicate = 4;
+        const float t = r0 * r0 - 4 * e;
+        if (t < 0) return 0;
+        const float sq = sqrtf(t);
+        D2 = 0.75f * b2 - 2 * c + 2 * sq;
+        E2 = D2 - 4 * sq;
+    } else {
+        const float u = 0.75f * b2 - 2 * c - R2, v = 0.25f * (4 * bc - 8 * d - b3) / Rr;
+        D2 = u + v;
+        E2 = u - v;
+        const float s2 = fabsf(u) + fabsf(v);
+        if (fabsf(D2) <= tol * s2 || fabsf(E2) <= tol * s2) delicate = 5;
+    }
+    const float b4 = 0.25f * b, R_2 = 0.5f * Rr;
+    int n = 0;
+    if (D2 >= 0) {
+        const float Ds = sqrtf(D2);
+        x[0] = R_2 + 0.5f * Ds - b4;
+        x[1] = x[0] - Ds;
+        n = 2;
+    }
+    if (E2 >= 0) {
+        const float Es = sqrtf(E2);
+        x[n] = -R_2 + 0.5f * Es - b4;
+        x[n + 1] = x[n] - Es;
+        n += 2;
+    }
+    return n;
+}
+
+// Smallest 4th-point reprojection error (pixels) over the candidate poses of this try, evaluated in fp32;
+// -1 when the configuration is numerically delicate (the caller must treat the try as "maybe"), +inf without candidate.
+// Pf: the 4 scene points, (mu, mv): their pixel positions.
+#define ESAC_SCREEN_MAYBE (-1.0f)
+#ifndef ESAC_SCREEN_CONGRUENCE
+#define ESAC_SCREEN_CONGRUENCE 1e-3f
+#endif
+#define SCREEN_BAIL(code) do { if (reason) *reason = (code); return ESAC_SCREEN_MAYBE; } while (0)
+ESAC_HD float p3p_screen_err(const float (&Pf)[4][3], const float (&mu_px)[4], const float (&mv_px)[4], float f, float cx, float cy,
+                             int* reason = nullptr) {
+    int delicate = 0;
+    const float inv_f = 1.0f / f;
+    float mu[4], mv[4], mk[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float u = (mu_px[i] - cx) * inv_f, v = (mv_px[i] - cy) * inv_f;
+        const float k = 1.0f / sqrtf(u * u + v * v + 1.0f);
+        mu[i] = u * k; mv[i] = v * k; mk[i] = k;
+    }
+    const V3f P0{Pf[0][0], Pf[0][1], Pf[0][2]}, P1{Pf[1][0], Pf[1][1], Pf[1][2]}, P2{Pf[2][0], Pf[2][1], Pf[2][2]},
+        P3{Pf[3][0], Pf[3][1], Pf[3][2]};
+    const V3f d12 = P1 - P2, d02 = P0 - P2, d01 = P0 - P1;
+    const float s0 = dotf(d12, d12), s1 = dotf(d02, d02), s2 = dotf(d01, d01);
+    if (!(s2 > 1e-12f) || !(s0 > 1e-12f) || !(s1 > 1e-12f)) SCREEN_BAIL(10);  // coincident points: let fp64 decide
+    const float cos0 = mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2];
+    const float cos1 = mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2];
+    const float cos2 = mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1];
+    const float p = 2 * cos0, q = 2 * cos1, r = 2 * cos2;
+    const float inv_d22 = 1.0f / s2;
+    const float a = inv_d22 * s0, b = inv_d22 * s1;
+    const float a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+    const float pr = p * r, pqr = q * pr;
+    const float ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
+    const float A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    const float B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    const float C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    const float Dq = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    const float E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    const float temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+    const float b0 = b * temp * temp;
+    // coefficient magnitudes: a coefficient that is small against the terms it was summed from carries no digits
+    const float cmag = 1.0f + a2 + b2 + ab;
+    if (!(fabsf(A) > 1e-4f * cmag) || !(fabsf(b0) > 1e-7f * b * (p2 + r2 + fabsf(pqr)) * (p2 + r2 + fabsf(pqr)) * (1 + a + b) * (1 + a + b))) SCREEN_BAIL(11);
+    float xr[4] = {0, 0, 0, 0};
+    const int n = quartic_roots_f32(A, B, C, Dq, E, xr, delicate);
+    if (delicate) SCREEN_BAIL(delicate);
+    float best = INFINITY;
+    if (n == 0) return best;
+    const float dist2 = sqrtf(s2);
+    const float inv_b0 = 1.0f / b0;
+    const float r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i >= n) break;
+        const float x = xr[i];
+        if (!(x == x)) SCREEN_BAIL(12);
+        if (x <= 0) {
+            if (x > -1e-3f) SCREEN_BAIL(13);  // sign of a root at rounding distance from zero
+            continue;
+        }
+        const float xx = x * x;
+        const float b1 =
+            ((1 - a - b) * xx + (q * a - q) * x + 1 - a + b) *
+            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * xx +
+             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+             2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+        // b1 is the difference of large products: its sign (validity of the root) and its value (the depth ratio y) are
+        // only as good as fp32 cancellation allows -- the calibration decides how much of that the margin absorbs
+        const float y = inv_b0 * b1;
+        if (!(y == y)) SCREEN_BAIL(14);
+        if (b1 <= 0) continue;
+        const float v = xx + y * y - x * y * r;
+        if (v <= 0) {
+            if (v > -1e-3f * (xx + y * y)) SCREEN_BAIL(15);
+            continue;
+        }
+        const float Z = dist2 / sqrtf(v);
+        const float X = x * Z, Y = y * Z;
+        // camera-frame positions of the three base points and the rigid motion taking the scene triangle onto them
+        // (orthonormal triads: exact for congruent triangles, which is what an accurate root gives)
+        const V3f Q0{X * mu[0], X * mv[0], X * mk[0]}, Q1{Y * mu[1], Y * mv[1], Y * mk[1]}, Q2{Z * mu[2], Z * mv[2], Z * mk[2]};
+        const V3f pe1 = P1 - P0, pe2 = P2 - P0, qe1 = Q1 - Q0, qe2 = Q2 - Q0;
+        const float ip1 = 1.0f / sqrtf(dotf(pe1, pe1)), iq1 = 1.0f / sqrtf(dotf(qe1, qe1));
+        const V3f e1 = ip1 * pe1, f1 = iq1 * qe1;
+        V3f e3 = crossf(e1, pe2), f3 = crossf(f1, qe2);
+        const float n3 = dotf(e3, e3), m3 = dotf(f3, f3);
+        if (!(n3 > 1e-12f * dotf(pe2, pe2)) || !(m3 > 1e-12f * dotf(qe2, qe2))) SCREEN_BAIL(16);  // collinear sample
+        e3 = (1.0f / sqrtf(n3)) * e3;
+        f3 = (1.0f / sqrtf(m3)) * f3;
+        const V3f e2 = crossf(e3, e1), f2 = crossf(f3, f1);
+        // 4th point in the scene triad, carried over to the camera triad
+        const V3f w = P3 - P0;
+        const float c1 = dotf(w, e1), c2 = dotf(w, e2), c3 = dotf(w, e3);
+        const float Xc = Q0.x + c1 * f1.x + c2 * f2.x + c3 * f3.x;
+        const float Yc = Q0.y + c1 * f1.y + c2 * f2.y + c3 * f3.y;
+        const float Zc = Q0.z + c1 * f1.z + c2 * f2.z + c3 * f3.z;
+        if (!(fabsf(Zc) > 1e-3f * (fabsf(Xc) + fabsf(Yc) + 1e-6f))) SCREEN_BAIL(17);  // 4th point next to the camera plane
+        const float iz = 1.0f / Zc;
+        const float du = cx + f * Xc * iz - mu_px[3], dv = cy + f * Yc * iz - mv_px[3];
+        const float epx = sqrtf(du * du + dv * dv);
+        if (!(epx == epx)) SCREEN_BAIL(18);
+        best = fminf(best, epx);
+    }
+    return best;
+}
+
+// true = "maybe acceptable": hand the try to the fp64 route.  false = no candidate of this try can pass.
+// thr = tau + screening margin (pixels).
+ESAC_HD bool p3p_screen_f32(const float (&Pf)[4][3], const float (&mu_px)[4], const float (&mv_px)[4], float f, float cx, float cy,
+                            float thr) {
+    const float e = p3p_screen_err(Pf, mu_px, mv_px, f, cx, cy);
+    return !(e > thr);  // delicate (-1), NaN and anything within the threshold: maybe
+}
+
+// ---- screen over the fp64 roots and depths --------------------------------------------------------------------------------
+// fp32 Ferrari is too fragile to screen with (the probe finds ~40 % of random tries within rounding distance of a branch
+// threshold), and the depth ratio y must be the fp64 route's own b1 / b0 -- on ill-conditioned samples (base points a few
+// cells apart) that quotient is set by cancellation, not by the P3P equations, and it is what the reference accepts or
+// rejects.  So roots (p3p_setup) and depths (p3p_candidate_lengths) stay the fp64 route's, same doubles, same validity
+// tests.  What the screen replaces is the rest of every candidate: the least-squares triangle alignment with its Newton
+// iterations and the fp64 projection of the 4th point (~350 dependent fp64 operations) by orthonormal triads and an fp32
+// projection (~90 fp32 operations).  Triads give the alignment exactly when the two triangles are congruent; how far
+// they are from that is measured, and a candidate whose camera-frame triangle misses the scene triangle's side lengths
+// by more than 1e-3 is reported as "maybe" instead of being judged.
+// Returns the smallest 4th-point error over the candidates (+inf: none), or ESAC_SCREEN_MAYBE.
+ESAC_HD float p3p_screen_roots(const P3PSetup& S, const float (&Pf)[4][3], float mu3_px, float mv3_px, float f, float cx, float cy) {
+    const float mu[3] = {(float)S.mu[0], (float)S.mu[1], (float)S.mu[2]}, mv[3] = {(float)S.mv[0], (float)S.mv[1], (float)S.mv[2]},
+                mk[3] = {(float)S.mk[0], (float)S.mk[1], (float)S.mk[2]};
+    const V3f P0{Pf[0][0], Pf[0][1], Pf[0][2]}, P1{Pf[1][0], Pf[1][1], Pf[1][2]}, P2{Pf[2][0], Pf[2][1], Pf[2][2]},
+        P3{Pf[3][0], Pf[3][1], Pf[3][2]};
+    // scene triad (shared by all candidates)
+    const V3f pe1 = P1 - P0, pe2 = P2 - P0, pe3 = P2 - P1;
+    const float l1 = dotf(pe1, pe1), l2 = dotf(pe2, pe2), l3 = dotf(pe3, pe3);
+    if (!(l1 > 0) || !(l2 > 0) || !(l3 > 0)) return ESAC_SCREEN_MAYBE;
+    const V3f e1 = (1.0f / sqrtf(l1)) * pe1;
+    V3f e3 = crossf(e1, pe2);
+    const float n3 = dotf(e3, e3);
+    if (!(n3 > 1e-8f * l2)) return ESAC_SCREEN_MAYBE;  // (near-)collinear sample
+    e3 = (1.0f / sqrtf(n3)) * e3;
+    const V3f e2 = crossf(e3, e1);
+    const V3f w = P3 - P0;
+    const float c1 = dotf(w, e1), c2 = dotf(w, e2), c3 = dotf(w, e3);
+    float best = INFINITY;
+    // not unrolled: four inlined copies of the b1 polynomial push the sampling kernel out of the instruction cache
+#pragma nounroll
+    for (int i = 0; i < S.n; i++) {
+        const double x = i == 0 ? S.x[0] : i == 1 ? S.x[1] : i == 2 ? S.x[2] : S.x[3];
+        double Xd, Yd, Zd;
+        if (!p3p_candidate_lengths(S, x, Xd, Yd, Zd)) continue;  // exactly the candidates the fp64 route skips
+        const float X = (float)Xd, Y = (float)Yd, Z = (float)Zd;
+        if (!(fabsf(X) < 1e18f && fabsf(Y) < 1e18f && fabsf(Z) < 1e18f)) return ESAC_SCREEN_MAYBE;  // NaN / overflow
+        const V3f Q0{X * mu[0], X * mv[0], X * mk[0]}, Q1{Y * mu[1], Y * mv[1], Y * mk[1]}, Q2{Z * mu[2], Z * mv[2], Z * mk[2]};
+        const V3f qe1 = Q1 - Q0, qe2 = Q2 - Q0, qe3 = Q2 - Q1;
+        const float m1 = dotf(qe1, qe1), m2 = dotf(qe2, qe2), m3s = dotf(qe3, qe3);
+        // congruence of the two triangles (side lengths squared): beyond 1e-3 the least-squares alignment of the fp64
+        // route and the triads below are different rigid motions
+        if (!(fabsf(m1 - l1) <= ESAC_SCREEN_CONGRUENCE * l1) || !(fabsf(m2 - l2) <= ESAC_SCREEN_CONGRUENCE * l2) ||
+            !(fabsf(m3s - l3) <= ESAC_SCREEN_CONGRUENCE * l3))
+            return ESAC_SCREEN_MAYBE;
+        const V3f f1 = (1.0f / sqrtf(m1)) * qe1;
+        V3f f3 = crossf(f1, qe2);
+        const float m3 = dotf(f3, f3);
+        if (!(m3 > 1e-8f * m2)) return ESAC_SCREEN_MAYBE;
+        f3 = (1.0f / sqrtf(m3)) * f3;
+        const V3f f2 = crossf(f3, f1);
+        const float Xc = Q0.x + c1 * f1.x + c2 * f2.x + c3 * f3.x;
+        const float Yc = Q0.y + c1 * f1.y + c2 * f2.y + c3 * f3.y;
+        const float Zc = Q0.z + c1 * f1.z + c2 * f2.z + c3 * f3.z;
+        if (!(fabsf(Zc) > 1e-3f * (fabsf(Xc) + fabsf(Yc) + 1e-6f))) return ESAC_SCREEN_MAYBE;  // 4th point next to the camera plane
+        const float iz = 1.0f / Zc;
+        const float du = cx + f * Xc * iz - mu3_px, dv = cy + f * Yc * iz - mv3_px;
+        const float epx = sqrtf(du * du + dv * dv);
+        if (!(epx == epx)) return ESAC_SCREEN_MAYBE;
+        best = fminf(best, epx);
+    }
+    return best;
+}
+
+}  // namespace esac

@@ -441,9 +441,10 @@ ESAC_HD bool p3p_setup(const V3 P[4], const double mu_px[4], const double mv_px[
     return true;
 }
 
-// candidate of root x: false when it is not a valid solution
-ESAC_HD bool p3p_candidate(const P3PSetup& S, double x, const V3 P[4], const double mu3_px, const double mv3_px,
-                           const Cam& cam, double R[9], double T[3], double& reproj) {
+// Depths (X, Y, Z along the three viewing rays) of the candidate of root x: false when it is not a valid solution.
+// (Split out of p3p_candidate so that the fp32 sampling screen, p3p_screen.hpp, evaluates exactly the candidates the
+// fp64 route evaluates -- same doubles, same validity tests.)
+ESAC_HD bool p3p_candidate_lengths(const P3PSetup& S, double x, double& X, double& Y, double& Z) {
     const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
     const double a2 = S.a2, b2 = S.b2, p2 = S.p2, q2 = S.q2, r2 = S.r2, pqr = S.pqr, ab = S.ab, a_2 = S.a_2, a_4 = S.a_4;
     const double r3 = S.r3, pr2 = S.pr2, r3q = S.r3q;
@@ -467,9 +468,17 @@ ESAC_HD bool p3p_candidate(const P3PSetup& S, double x, const V3 P[4], const dou
     const double y = S.inv_b0 * b1;
     const double v = xx + y * y - x * y * r;
     if (v <= 0) return false;
-    const double Z = S.dist2 / sqrt(v);
-    const double X = x * Z;
-    const double Y = y * Z;
+    Z = S.dist2 / sqrt(v);
+    X = x * Z;
+    Y = y * Z;
+    return true;
+}
+
+// candidate of root x: false when it is not a valid solution
+ESAC_HD bool p3p_candidate(const P3PSetup& S, double x, const V3 P[4], const double mu3_px, const double mv3_px,
+                           const Cam& cam, double R[9], double T[3], double& reproj) {
+    double X, Y, Z;
+    if (!p3p_candidate_lengths(S, x, X, Y, Z)) return false;
     const V3 Q0 = {X * S.mu[0], X * S.mv[0], X * S.mk[0]};
     const V3 Q1 = {Y * S.mu[1], Y * S.mv[1], Y * S.mk[1]};
     const V3 Q2 = {Z * S.mu[2], Z * S.mv[2], Z * S.mk[2]};

@@ -1,0 +1,10 @@
+R=$GRAFT_REPO_ROOT
+cd $R
+O=gpurun_out/${1:-r02g}
+mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_edge.py tests/test_gpu_parity_large.py tests/test_gpu_parity.py tests/test_gpu_semantics.py -m gpu -q -x > $O/pytest.log 2>&1; tail -15 $O/pytest.log | cut -c1-200
+for cfg in cfg5b; do
+timeout 600 python bench.py --config $cfg --no-cpu-baseline --no-extras --steps 5 --warmup 2 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); print('$cfg value %.0f ms/step %.4f' % (d['value'], d['ms_per_step']), {k: round(v,4) for k,v in d.get('phase_ms',{}).items() if k in ('sample_p3p','score','select_rescore','refine')}, [(k['stage'], round(k['avg_us'],1)) for k in d.get('kernels',[])])"
+done

@@ -1,0 +1,139 @@
+// p3p_screen_probe.cpp -- TEST-ONLY host build of the fp32 sampling screen (esac_amd/csrc/p3p_screen.hpp) next to the fp64
+// route: random 4-cell tries on a given map, decision of the fp64 route (P3P + the 4-point tau test exactly as k_sample's
+// accept_sample) vs the screen's smallest 4th-point error.  Built by tests/native/build.py:build_screen_probe();
+// used by tests/test_device_math_host.py (the screen must never reject a try the fp64 route accepts) and by the
+// calibration run scripts/dev/p3p_screen_probe.py.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+
+#include "../../esac_amd/csrc/p3p_screen.hpp"
+#include "../../esac_amd/csrc/pose_math.hpp"
+using namespace esac;
+
+static inline uint64_t splitmix(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static bool accept64(const double Rp[9], const double Tp[3], const float Pf[4][3], const double mu[4], const double mv[4], const Cam& cam, double tau) {
+    double rvec[3], R[9];
+    rodrigues_mat2vec(Rp, rvec);
+    rodrigues_vec2mat<false>(rvec, R, nullptr);
+    for (int j = 0; j < 4; j++) {
+        const double Xd = Pf[j][0], Yd = Pf[j][1], Zd = Pf[j][2];
+        double x = R[0] * Xd + R[1] * Yd + R[2] * Zd + Tp[0];
+        double y = R[3] * Xd + R[4] * Yd + R[5] * Zd + Tp[1];
+        double z = R[6] * Xd + R[7] * Yd + R[8] * Zd + Tp[2];
+        z = z ? 1. / z : 1;
+        x *= z; y *= z;
+        const float u = (float)(x * cam.fx + cam.cx), v = (float)(y * cam.fy + cam.cy);
+        const float dx = (float)mu[j] - u, dy = (float)mv[j] - v;
+        if (!(sqrt((double)dx * dx + (double)dy * dy) < tau)) return false;
+    }
+    return true;
+}
+
+// out[0] tries, [1] accepted by fp64, [2] screen "delicate", [3] largest screen error among fp64-accepted tries,
+// [4 + k] tries the screen keeps ("maybe") at margin margins[k], [12 + k] fp64-accepted tries it would REJECT there;
+// [20] largest |screen err - fp64 4th-point err| over solved tries with fp64 err < 200 px; [21] fp64-solved tries
+extern "C" void probe_screen(const float* coords, int H, int W, int sub, int shx, int shy, float f, float cx, float cy, float tau,
+                             uint64_t seed, long long n_tries, const float* margins, int n_margins, int mode, double* out) {
+    const int P = H * W;
+    const Cam cam{(double)f, (double)f, (double)cx, (double)cy};
+    double acc[40];
+    memset(acc, 0, sizeof(acc));
+#pragma omp parallel
+    {
+        double loc[40];
+        memset(loc, 0, sizeof(loc));
+        uint64_t s = seed;
+#ifdef _OPENMP
+        s += 7919ull * (uint64_t)omp_get_thread_num();
+#endif
+#pragma omp for schedule(static)
+        for (long long it = 0; it < n_tries; it++) {
+            int cxs[4], cys[4];
+            for (int j = 0; j < 4; j++) {
+                for (;;) {
+                    const uint64_t r = splitmix(s);
+                    const int x = (int)((r & 0xffffffffu) % (uint32_t)(W - 1)), y = (int)((r >> 32) % (uint32_t)(H - 1));
+                    bool dup = false;
+                    for (int k = 0; k < j; k++) dup |= cxs[k] == x && cys[k] == y;
+                    if (!dup) { cxs[j] = x; cys[j] = y; break; }
+                }
+            }
+            float Pf[4][3], muf[4], mvf[4];
+            V3 Pt[4];
+            double mu[4], mv[4];
+            for (int j = 0; j < 4; j++) {
+                const int idx = cys[j] * W + cxs[j];
+                Pf[j][0] = coords[idx]; Pf[j][1] = coords[P + idx]; Pf[j][2] = coords[2 * P + idx];
+                Pt[j] = V3{(double)Pf[j][0], (double)Pf[j][1], (double)Pf[j][2]};
+                muf[j] = (float)(cxs[j] * sub + sub / 2 - shx); mvf[j] = (float)(cys[j] * sub + sub / 2 - shy);
+                mu[j] = muf[j]; mv[j] = mvf[j];
+            }
+            double Rp[9], Tp[3], reproj2 = 0;
+            const bool solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2);
+            const bool ok = solved && accept64(Rp, Tp, Pf, mu, mv, cam, (double)tau);
+            int reason = 0;
+            float e;
+            if (mode == 0) {
+                e = p3p_screen_err(Pf, muf, mvf, f, cx, cy, &reason);
+            } else {  // mode 1 / 2 (2 = also print false rejects): the shipped form: fp64 roots (p3p_setup), fp32 per-root work
+                P3PSetup S;
+                e = p3p_setup(Pt, mu, mv, cam, S) ? p3p_screen_roots(S, Pf, muf[3], mvf[3], f, cx, cy) : INFINITY;
+            }
+            if (reason > 0 && reason < 10) loc[22 + (reason > 5 ? 5 : reason)] += 1; else if (reason >= 10) loc[28] += 1;
+            if (mode == 2 && ok && !(e <= tau + 20.0f) && e != ESAC_SCREEN_MAYBE) {
+#pragma omp critical
+                {
+                    static int shown = 0;
+                    if (shown++ < 12) {
+                        P3PSetup S;
+                        p3p_setup(Pt, mu, mv, cam, S);
+                        const double t1 = S.p2 * (S.a - 1 + S.b), t2 = S.r2 * (S.a - 1 - S.b), t3 = S.pqr, t4 = S.a * S.pqr;
+                        const double temp = t1 + t2 + t3 - t4;
+                        printf("FALSE REJECT screen e=%g fp64 e=%g n=%d roots %g %g %g %g  a=%g b=%g p=%g q=%g r=%g temp=%g (terms %g) dist %g\n", e, sqrt(reproj2), S.n,
+                               S.x[0], S.x[1], S.x[2], S.x[3], S.a, S.b, S.p, S.q, S.r, temp, fabs(t1) + fabs(t2) + fabs(t3) + fabs(t4), S.dist2);
+                        for (int i = 0; i < S.n; i++) {
+                            const double x = S.x[i], xx = x * x, v = (xx + 1 - S.q * x) / S.b, disc = S.p * S.p - 4 * (1 - S.a * v);
+                            double R[9], T[3], rp = -1;
+                            const bool val = p3p_candidate(S, x, Pt, mu[3], mv[3], cam, R, T, rp);
+                            printf("   root %d x=%g v=%g disc=%g  fp64 candidate valid=%d reproj=%g\n", i, x, v, disc, (int)val, val ? sqrt(rp) : -1.0);
+                        }
+                    }
+                }
+            }
+            loc[0] += 1;
+            loc[1] += ok;
+            const bool delicate = e == ESAC_SCREEN_MAYBE || !(e == e);
+            loc[2] += delicate;
+            if (ok && !delicate && e > loc[3]) loc[3] = e;
+            for (int k = 0; k < n_margins && k < 8; k++) {
+                const bool maybe = !(e > tau + margins[k]);
+                loc[4 + k] += maybe;
+                loc[12 + k] += ok && !maybe;
+            }
+            if (solved) {
+                loc[21] += 1;
+                const double e64 = sqrt(reproj2);
+                if (!delicate && e64 < 200 && e < 1e30f) {
+                    const double d = fabs((double)e - e64);
+                    if (d > loc[20]) loc[20] = d;
+                }
+            }
+        }
+#pragma omp critical
+        {
+            for (int k = 0; k < 40; k++) {
+                if (k == 3 || k == 20) acc[k] = loc[k] > acc[k] ? loc[k] : acc[k];
+                else acc[k] += loc[k];
+            }
+        }
+    }
+    memcpy(out, acc, sizeof(acc));  // out: 40 doubles; [23..27] delicate by quartic trigger 1..5, [28] other bail-outs
+}

@@ -325,3 +325,38 @@ def test_closed_form_lm_chain_equals_the_rodrigues_jacobian_chain(probe):
                   + (1 / 6 - th2 / 120 + th2 ** 2 / 5040 - th2 ** 3 / 362880) * S2)
             np.testing.assert_allclose(Mw.reshape(3, 3), Jl, rtol=0, atol=2e-14)
             np.testing.assert_allclose(K.reshape(3, 3), skew(pose[3:]) @ Jl, rtol=0, atol=5e-13)
+
+
+def test_fp32_screen_never_rejects_an_accepted_try():
+    """The one-sided contract of the sampling screen (esac_amd/csrc/p3p_screen.hpp, used by k_sample_screened): on the
+    kernels' own source compiled for the host, over 1.5e6 random tries on true-expert, garbage-expert, noise-free,
+    coarse-grid and far-from-origin maps, no try the fp64 route ACCEPTS is ruled out by the screen at HALF the margin the
+    kernel uses, the screen's error of every accepted try stays within 0.1 px of tau, and on a garbage map it clears
+    more than 99 % of the tries (which is the point of it)."""
+    import ctypes as C
+    from esac_amd import synthetic as S
+    from tests.native import build as nb
+    lib = C.CDLL(nb.build_screen_probe())
+    margins = np.array([1.5, 3.0], np.float32)  # the kernel: SCREEN_MARGIN = 3 px
+
+    def run(coords, f, n, seed):
+        out = np.zeros(40)
+        c = np.ascontiguousarray(coords, np.float32)
+        _, H, W = c.shape
+        lib.probe_screen(c.ctypes.data_as(C.c_void_p), H, W, f["sub"], f["shift"][0], f["shift"][1], C.c_float(f["focal"]),
+                         C.c_float(f["ppx"]), C.c_float(f["ppy"]), C.c_float(10.0), C.c_uint64(seed), C.c_longlong(n),
+                         margins.ctypes.data_as(C.c_void_p), 2, 1, out.ctypes.data_as(C.c_void_p))
+        return out
+
+    f = S.make_frame(3, E=2, true_expert=0)
+    off = np.array([1200.0, -800.0, 950.0], np.float32)[:, None, None]
+    cases = [("true expert", f["coords"][0], f), ("garbage expert", f["coords"][1], f),
+             ("noise-free", S.make_frame(7, noise=0.0, outlier_frac=0.0)["coords"][0], f),
+             ("coarse grid", None, S.make_frame(8, H=24, W=32, sub=20)), ("far from the origin", f["coords"][0] + off, f)]
+    for k, (name, coords, fr) in enumerate(cases):
+        out = run(fr["coords"][0] if coords is None else coords, fr, 300000, 40 + k)
+        tries, accepted = out[0], out[1]
+        assert out[12] == 0 and out[13] == 0, (name, out[12:14])      # fp64-accepted tries the screen would have rejected
+        assert accepted > 0 and out[3] <= 10.0 + 0.1, (name, out[3])  # largest screen error among accepted tries
+        if name == "garbage expert":
+            assert out[5] / tries < 0.01, out[5] / tries              # "maybe" fraction at the kernel's margin

@@ -180,13 +180,14 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
     if (co.G == 1) return;
     double* buf = co.partials + (size_t)(co.arrivals & 1ull) * co.G * 32;
     __syncthreads();
-    // publish: NV lanes store this workgroup's sums, ONE lane releases them at device scope and arrives
-    if (threadIdx.x < NV) {
-        double mine = v[0];
+    // publish: the sums go through LDS (static register indices only), NV lanes store them, ONE lane releases them at
+    // device scope and arrives
+    if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 1; k < NV; k++) mine = (int)threadIdx.x == k ? v[k] : mine;
-        buf[(size_t)co.g * 32 + threadIdx.x] = mine;
+        for (int k = 0; k < NV; k++) s_tot[k] = v[k];
     }
+    __syncthreads();
+    if (threadIdx.x < NV) buf[(size_t)co.g * 32 + threadIdx.x] = s_tot[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -17,3 +17,5 @@ done
 cd $R
 python scripts/profile_to_json.py --config $CFG --round $RND --stats $(find $O/stats -name "*.db" | head -1) \
    --pmc $(find $O/pmc* -name "*.db") --command "bench.py --config $CFG --no-cpu-baseline --no-extras $*" --out-dir gpurun_out/profiles_$RND
+tail -1 $O/bench_under_rocprof.json > gpurun_out/profiles_$RND/${RND}_${CFG}_bench_under_rocprof.json
+rm -rf $O/stats $O/pmc*   # the rocpd databases are tens of MB each: only the summaries travel back

@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "esac_hip_pick_record", "esac_hip_time_stages",
 ]
 ABI_VERSION = 2
-FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM = 1, 2, 4
+FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS = 1, 2, 4, 8
 
 
 class Params(C.Structure):
@@ -146,7 +146,7 @@ class Engine:
 
     def make_params(self, E, H, W, N, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
                     inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0,
-                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0, exact_scores=False, score_shape="auto"):
+                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0, exact_scores=False, score_shape="auto", pack_maps=False):
         p = Params()
         p.E, p.H, p.W, p.N = int(E), int(H), int(W), int(N)
         p.shift_x, p.shift_y = int(shift_x), int(shift_y)
@@ -157,7 +157,8 @@ class Engine:
         p.max_tries, p.max_ref_steps, p.hyp_offset = int(max_tries), int(max_ref_steps), int(hyp_offset)
         p.rescore_margin = float(rescore_margin)
         p.d_hyp_index = None
-        p.flags = (FLAG_EXACT_SCORES if exact_scores else 0) | {"auto": 0, "tiled": FLAG_SCORE_TILED, "stream": FLAG_SCORE_STREAM}[score_shape]
+        p.flags = (FLAG_EXACT_SCORES if exact_scores else 0) | {"auto": 0, "tiled": FLAG_SCORE_TILED, "stream": FLAG_SCORE_STREAM}[score_shape] | \
+            (FLAG_PACK_MAPS if pack_maps else 0)
         self._shape = (int(N), int(H), int(W))
         return p
 

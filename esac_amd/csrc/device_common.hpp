@@ -165,6 +165,8 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     a.rt32 += f * N * 12;
     a.sample_xy += f * N * 8;
     a.tries += f * N;
+    a.samp_resume += f * N;
+    a.best_try += f * N;
     a.fast_scores += f * N;
     a.scores += f * N;
     a.exact_flag += f * N;

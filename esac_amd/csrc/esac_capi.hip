@@ -71,6 +71,8 @@ struct esac_hip_ctx {
     BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
     int bN = 0, bP = 0, bcap = 0;
     bool b_lists = false;
+    float4* sc4 = nullptr;  // packed copy of the maps for the sampler (ensure_pack_ws)
+    long long sc4_cells = 0;
     // tile-stationary score workspace (ensure_tiled_ws)
     int tN = 0, tChunks = 0;
     long long tPart = 0;
@@ -86,7 +88,7 @@ extern "C" int esac_hip_device_count(void) {
 }
 
 static void free_ws(esac_hip_ctx* c) {
-    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.fast_scores,
+    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.best_try, c->ws.samp_entries, c->ws.samp_count, c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
                     c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials};
@@ -132,6 +134,7 @@ extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     DeviceGuard guard(c->device);
     free_ws(c);
     free_bws(c);
+    if (c->sc4) (void)hipFree(c->sc4);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -167,6 +170,10 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.coop_counter, (size_t)2);
     rc |= alloc(&c->ws.sample_xy, (size_t)nN * 8);
     rc |= alloc(&c->ws.tries, (size_t)nN);
+    rc |= alloc(&c->ws.samp_resume, (size_t)nN);
+    rc |= alloc(&c->ws.best_try, (size_t)nN);
+    rc |= alloc(&c->ws.samp_entries, (size_t)nN * 2 * ESAC_SAMPLE_LIST_PER_HYP);  // (hypothesis, try) pairs
+    rc |= alloc(&c->ws.samp_count, (size_t)4);
     rc |= alloc(&c->ws.fast_scores, (size_t)nN);
     rc |= alloc(&c->ws.scores, (size_t)nN);
     rc |= alloc(&c->ws.exact_flag, (size_t)nN);
@@ -214,6 +221,25 @@ static bool want_tiled(const esac_hip_params* p, const float* d_sc, int B) {
     if (!legal || (p->flags & ESAC_FLAG_SCORE_STREAM)) return false;
     if (p->flags & ESAC_FLAG_SCORE_TILED) return true;
     return P >= 32768 && p->N >= 64;
+}
+
+// Packed (x,y,z,0) copy of the maps for the sampler: worth one extra pass over the maps when they are far beyond the L2s
+// (every random 4-byte gather would otherwise fetch its own cache line, three per cell) and hypotheses of several experts
+// will need many tries.  Single frames only.
+static bool want_pack(const esac_hip_params* p, int B) {
+    if (B != 1) return false;
+    if (p->flags & ESAC_FLAG_PACK_MAPS) return true;
+    return p->E > 1 && (long long)p->E * p->H * p->W * 12 >= (32LL << 20) && p->N >= 256;
+}
+static int ensure_pack_ws(esac_hip_ctx* c, long long cells) {
+    if (cells <= c->sc4_cells) return 0;
+    HIP_OK(hipDeviceSynchronize());
+    if (c->sc4) (void)hipFree(c->sc4);
+    c->sc4 = nullptr;
+    c->sc4_cells = 0;
+    HIP_OK(hipMalloc((void**)&c->sc4, (size_t)cells * sizeof(float4)));
+    c->sc4_cells = cells;
+    return 0;
 }
 
 static int ensure_tiled_ws(esac_hip_ctx* c, int N, int P, int E) {
@@ -267,7 +293,10 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     if (rc) return rc;
     const bool tiled = want_tiled(p, d_sc, B);
     if (tiled && (rc = ensure_tiled_ws(c, p->N, P, p->E))) return rc;
+    const bool pack = want_pack(p, B);
+    if (pack && (rc = ensure_pack_ws(c, (long long)p->E * P))) return rc;
     KArgs a = c->ws;
+    a.sc4 = pack ? c->sc4 : nullptr;
     if (tiled) {
         a.n_sub = tiled_sub_tiles(P);
         a.n_chunks_max = p->N / ESAC_TILED_HC + (p->E < p->N ? p->E : p->N) + 1;
@@ -288,6 +317,7 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
                                             : ESAC_MAX_REF_STEPS;
     a.hyp_offset = p->hyp_offset;
     a.hyp_index = p->d_hyp_index;
+    a.samp_cap = (int)(((long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP) > 0x7fffffffLL ? 0x7fffffff : (long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP);
     a.flags = p->flags;
     c->epoch += 1.0;  // every call gets its own epoch: result hand-off word and the tag of the status word
     a.epoch = c->epoch;

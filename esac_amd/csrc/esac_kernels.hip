@@ -68,20 +68,39 @@ __device__ __forceinline__ bool cannot_pass(double reproj2, double tau) {
     return reproj2 > lim * lim;  // NaN: false -> the full test decides
 }
 
-// the 4 cells of try t of hypothesis gh, their scene points and pixel positions
+// the 4 cells of try t of hypothesis gh, their scene points and pixel positions.  With the planar [E,3,H,W] layout a
+// cell is three 4-byte reads from three cache lines; when the maps are too large for the caches (KArgs::sc4, see
+// k_pack_cells) the sampler reads one 16-byte (x, y, z, -) record per cell instead.
 __device__ __forceinline__ void gather_sample(const KArgs& a, const float* __restrict__ map, int P, const Philox& rng, uint32_t gh,
                                               uint32_t t, int (&cx)[4], int (&cy)[4], V3 (&Pt)[4], float (&Pf)[4][3],
                                               double (&mu)[4], double (&mv)[4]) {
     draw_cells(rng, gh, t, a.W, a.H, cx, cy);
+    const float4* __restrict__ map4 = a.sc4 ? a.sc4 + (size_t)(map - a.sc) / 3 : nullptr;  // (map - sc) / 3 = expert * P
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int idx = cy[j] * a.W + cx[j];
-        Pf[j][0] = map[idx];
-        Pf[j][1] = map[P + idx];
-        Pf[j][2] = map[2 * P + idx];
+        if (map4) {
+            const float4 v = map4[idx];
+            Pf[j][0] = v.x; Pf[j][1] = v.y; Pf[j][2] = v.z;
+        } else {
+            Pf[j][0] = map[idx];
+            Pf[j][1] = map[P + idx];
+            Pf[j][2] = map[2 * P + idx];
+        }
         Pt[j] = V3{(double)Pf[j][0], (double)Pf[j][1], (double)Pf[j][2]};
         mu[j] = (double)cell_px(a, cx[j]);
         mv[j] = (double)cell_py(a, cy[j]);
+    }
+}
+
+// planar [E,3,H,W] -> [E,H*W] records (x, y, z, 0): one coalesced pass (12 B read, 16 B written per cell), paid once per
+// call when the sampler's random 4-byte gathers would otherwise pull three cache lines per cell from HBM / Infinity Cache
+__global__ __launch_bounds__(256) void k_pack_cells(KArgs a) {
+    const size_t P = (size_t)a.H * a.W, total = P * a.E;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t e = i / P, c = i - e * P;
+        const float* m = a.sc + e * 3 * P;
+        const_cast<float4*>(a.sc4)[i] = make_float4(m[c], m[P + c], m[2 * P + c], 0.0f);
     }
 }
 
@@ -162,6 +181,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
     } else if ((lane & 15) == 0) {
         a.tries[h] = SAMPLE_PENDING;
+        a.best_try[h] = 0x7fffffff;  // k_sample_decide: lowest accepted try
     }
 }
 
@@ -279,8 +299,133 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
 // the end of the budget.
 constexpr float SCREEN_MARGIN = 3.0f;  // pixels; the largest screen error of an fp64-accepted try in calibration: tau + 0.008
 constexpr int SCREEN_FLUSH = 8;
-constexpr int SCREEN_QUEUE = 128;
+constexpr int SCREEN_QUEUE = 128;  // >= SCREEN_FLUSH - 1 + 64
 
+// The screening loop alone, for TWO wavefronts per SIMD: the full fp64 decision (alignment, pose conversion, best-candidate
+// bookkeeping) is what pushes k_sample_screened to ~400 registers and one wavefront per SIMD, where every dependent fp64
+// operation is paid at its full ~40-cycle latency.  The throughput shape therefore runs as a chain of four launches:
+//   k_sample_prescreen  no decision code (256 registers, two wavefronts per SIMD): walks the tries of a pending
+//                       hypothesis, appends every "maybe" try to ONE global list (h, try) and stops after the first
+//                       round in which the screen itself sees the 4th point within tau (that try is accepted in all
+//                       but a handful of cases), or when the budget is spent;
+//   k_sample_decide     one LANE per listed try, all hypotheses together (a wrong-expert hypothesis lists 2-3 tries out
+//                       of ~10^3): the full fp64 decision, atomicMin of the accepted try per hypothesis;
+//   k_sample_commit     one lane per pending hypothesis: re-solves the accepted try (same code, same result) and stores
+//                       the hypothesis -- or the state of the last try when the budget ran out without one;
+//   k_sample_screened<true>  the rare hypothesis whose stop turned out a false alarm continues from its resume round,
+//                       screening and deciding in one kernel as before.
+// Every try below a hypothesis' resume point has been screened, every "maybe" among them decided: the minimum accepted
+// try is the try the reference's sequential loop stops at (esac_util.h:152-223).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_prescreen(KArgs a) {
+    frame_view(a);
+    const int h = blockIdx.x, lane = threadIdx.x;
+    if (a.tries[h] != SAMPLE_PENDING) return;
+    const int e = expert_of(a, h);
+    const int P = a.H * a.W;
+    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
+    const Philox rng(a.seed, a.call);
+    const Cam cam = make_cam(a);
+    const uint32_t gh = (uint32_t)global_hyp(a, h);
+    const float thr = a.tau + SCREEN_MARGIN;
+    long long base = a.first_try;
+    for (; base < a.max_tries; base += 64) {
+        const int t = (int)base + lane;
+        bool maybe = false, strong = false;
+        if (t < a.max_tries) {
+            int cx[4], cy[4];
+            V3 Pt[4];
+            float Pf[4][3];
+            double mu[4], mv[4];
+            gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+            P3PSetup S;
+            if (p3p_setup(Pt, mu, mv, cam, S)) {
+                const float err = p3p_screen_roots(S, Pf, (float)mu[3], (float)mv[3], a.focal, a.ppx, a.ppy);
+                maybe = !(err > thr);
+                strong = maybe && err >= 0.0f && err <= a.tau;
+            }
+        }
+        const unsigned long long m = __ballot(maybe);
+        if (m) {
+            const int cnt = __popcll(m);
+            int pos0 = 0;
+            if (lane == 0) pos0 = atomicAdd(a.samp_count, cnt);
+            pos0 = __shfl(pos0, 0);
+            const int pos = pos0 + __popcll(m & ((1ull << lane) - 1ull));
+            if (maybe && pos < a.samp_cap) reinterpret_cast<int2*>(a.samp_entries)[pos] = make_int2(blockIdx.y * a.N + h, t);
+            // list full (the counter stays beyond the capacity, readers clamp; every slot below the capacity is written by
+            // exactly one lane): this round is not fully listed, so the hypothesis resumes AT it
+            if (pos0 + cnt > a.samp_cap) break;
+            if (__any(strong)) {
+                base += 64;
+                break;
+            }
+        }
+    }
+    if (lane == 0) a.samp_resume[h] = (int)(base < a.max_tries ? base : a.max_tries);
+}
+
+// one lane per listed try: the fp64 route's decision, lowest accepted try per hypothesis
+__global__ __launch_bounds__(64) void k_sample_decide(KArgs a0) {
+    const int n = min(a0.samp_count[0], a0.samp_cap);
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (blockIdx.x * 64 >= n) return;
+    bool accepted = false;
+    int hg = 0, t = 0;
+    if (i < n) {
+        const int2 ent = reinterpret_cast<const int2*>(a0.samp_entries)[i];
+        hg = ent.x;
+        t = ent.y;
+        const int fr = hg / a0.N, h = hg - fr * a0.N;
+        // the frame's view of the inputs, by hand (this kernel's grid is not per frame)
+        const float* sc = a0.sc + (size_t)fr * a0.sc_frame_stride;
+        const int64_t* assign = a0.assign + (size_t)fr * a0.N;
+        const long long ev = a0.E == 1 ? 0 : assign[h];
+        const int e = (unsigned long long)ev < (unsigned long long)a0.E ? (int)ev : 0;
+        const int P = a0.H * a0.W;
+        const float* __restrict__ map = sc + (size_t)e * 3 * P;
+        const Philox rng(a0.seed, a0.call + (uint64_t)fr);
+        const Cam cam = make_cam(a0);
+        const uint32_t gh = (uint32_t)global_hyp(a0, h);
+        int cx[4], cy[4];
+        V3 Pt[4];
+        float Pf[4][3];
+        double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
+        gather_sample(a0, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+        if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2) && !cannot_pass(reproj2, (double)a0.tau)) {
+            double rvec[3], T[3], R[9];
+            accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a0.tau, rvec, T, R);
+        }
+    }
+    if (accepted) atomicMin(a0.best_try + hg, t);
+}
+
+// one lane per pending hypothesis: store the accepted try (re-solved), or the last try's state when the budget is spent
+__global__ __launch_bounds__(64) void k_sample_commit(KArgs a) {
+    frame_view(a);
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= a.N || a.tries[h] != SAMPLE_PENDING) return;
+    const int found = a.best_try[h];
+    const bool have = found != 0x7fffffff;
+    if (!have && a.samp_resume[h] < a.max_tries) return;  // false alarm / full list: k_sample_screened<true> continues
+    const int t = have ? found : a.max_tries - 1;
+    const int e = expert_of(a, h);
+    const int P = a.H * a.W;
+    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
+    const Philox rng(a.seed, a.call);
+    const Cam cam = make_cam(a);
+    int cx[4], cy[4];
+    V3 Pt[4];
+    float Pf[4][3];
+    double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
+    double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    gather_sample(a, map, P, rng, (uint32_t)global_hyp(a, h), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+    if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2)) accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
+    store_hypothesis(a, h, map, rvec, T, R, cx, cy, have ? t : -1);
+}
+
+// RESUME: continue where k_sample_prescreen stopped (its parked tries preloaded into the queue).
+template <bool RESUME>
 __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
     __shared__ int s_queue[SCREEN_QUEUE];
     frame_view(a);
@@ -296,7 +441,9 @@ __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
     const double tau = (double)a.tau;
     const float thr = a.tau + SCREEN_MARGIN;
     int qcount = 0;  // wave-uniform
-    for (long long base = a.first_try;; base += 64) {
+    long long first = a.first_try;
+    if (RESUME) first = a.samp_resume[h];  // everything below it has been screened and decided (k_sample_decide)
+    for (long long base = first;; base += 64) {
         const bool more = base < a.max_tries;
         bool strong = false;
         if (more) {
@@ -684,6 +831,7 @@ void launch_stats_exact(const KArgs& a, hipStream_t s) {
 }
 void launch_sample(const KArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.frames;
+    if (a.sc4) hipLaunchKernelGGL(k_pack_cells, dim3(2048), dim3(256), 0, s, a);
     if (total <= 1024)  // latency: 64 tries per round, the candidates of a try on four lanes
         hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, a);
     else if (total <= 4096)
@@ -697,7 +845,17 @@ void launch_sample(const KArgs& a, hipStream_t s) {
 #ifdef ESAC_SAMPLE_UNSCREENED  // A/B switch (scripts/dev/variants.sh): the round-1 kernel, every try solved in full
         if (b.first_try < a.max_tries) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
 #else
-        if (b.first_try < a.max_tries) hipLaunchKernelGGL(k_sample_screened, dim3(a.N, a.frames), dim3(64), 0, s, b);
+        if (b.first_try < a.max_tries) {
+#ifdef ESAC_SAMPLE_SINGLE_KERNEL  // A/B switch: screening and decision in one kernel (one wavefront per SIMD throughout)
+            hipLaunchKernelGGL(k_sample_screened<false>, dim3(a.N, a.frames), dim3(64), 0, s, b);
+#else
+            (void)hipMemsetAsync(a.samp_count, 0, sizeof(int), s);
+            hipLaunchKernelGGL(k_sample_prescreen, dim3(a.N, a.frames), dim3(64), 0, s, b);
+            hipLaunchKernelGGL(k_sample_decide, dim3((a.samp_cap + 63) / 64), dim3(64), 0, s, b);
+            hipLaunchKernelGGL(k_sample_commit, dim3((a.N + 63) / 64, a.frames), dim3(64), 0, s, b);
+            hipLaunchKernelGGL(k_sample_screened<true>, dim3(a.N, a.frames), dim3(64), 0, s, b);
+#endif
+        }
 #endif
     }
 }

@@ -74,6 +74,9 @@ typedef struct esac_hip_params {
  * STREAM: one hypothesis per workgroup streams its expert's whole map (small, cache-resident maps). */
 #define ESAC_FLAG_SCORE_TILED 2
 #define ESAC_FLAG_SCORE_STREAM 4
+/* Sampling reads the maps through a packed (x,y,z,0)-per-cell copy made at the start of the call (default: only when
+ * the maps are far larger than the caches and several experts are in play).  Results are unchanged. */
+#define ESAC_FLAG_PACK_MAPS 8
 
 #define ESAC_DEFAULT_MARGIN 1e-3f
 

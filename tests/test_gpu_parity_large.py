@@ -102,3 +102,22 @@ def test_tiled_score_equals_the_per_hypothesis_stream(engine, oracle, shape):
     d = np.abs(s_t[~f_t] - ref["scores"][~f_t])
     assert np.sort(d)[-3:].max() <= 2 * 100.0 / (H * W) + 2e-3 and np.median(d) <= 1e-4
     np.testing.assert_allclose(s_t[f_t], ref["scores"][f_t], rtol=0, atol=1e-7)
+
+
+def test_packed_map_copy_for_the_sampler(engine, oracle):
+    """ESAC_FLAG_PACK_MAPS (taken by default for maps far beyond the caches): the sampler gathers (x,y,z) records from a
+    packed copy of the maps -- sampled cells, accepted tries and everything downstream must not change.  5000 hypotheses
+    over 3 experts: first-phase passes, prescreen / decide / commit and the resume kernel all read through the copy."""
+    f = S.make_frame(220, E=3, true_expert=1, H=120, W=160, sub=4)
+    ha = S.gating_assignment(f, 5000, mode="dirichlet")
+    ha[::5] = 1
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    kw = dict(shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=4, seed=5, call=1)
+    ref = oracle.forward(f["coords"], ha, **kw)
+    res = engine.forward_device(sc, hat, engine.make_params(3, 120, 160, 5000, pack_maps=True, **kw))
+    _check_full(engine, res, ref)
+    # and on a small single-frame call (the latency-shaped sampler)
+    ha2 = ha[:300].copy()
+    ref2 = oracle.forward(f["coords"], ha2, **kw)
+    res2 = engine.forward_device(sc, torch.from_numpy(ha2).cuda(), engine.make_params(3, 120, 160, 300, pack_maps=True, **kw))
+    _check_full(engine, res2, ref2)

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
     } else if ((lane & 15) == 0) {
         a.tries[h] = SAMPLE_PENDING;
-        a.best_try[h] = 0x7fffffff;  // k_sample_decide: lowest accepted try
+        a.best_try[h] = ~0ull;          // k_sample_decide: lowest accepted try << 32 | its list position
+        a.samp_resume[h] = 0x7fffffff;  // k_sample_prescreen: first try not screened yet
     }
 }
 
@@ -281,6 +282,14 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             if (t == writer && holder) store_hypothesis(a, h, map, rvec, T, R, cx, cy, tries_val);
             return;
         }
+        if (base + TRIES >= a.handover) {  // a straggler (wrong expert): the spread, screened search takes over from here
+            if (threadIdx.x == 0) {
+                a.tries[h] = SAMPLE_PENDING;
+                a.best_try[h] = ~0ull;
+                a.samp_resume[h] = 0x7fffffff;
+            }
+            return;
+        }
     }
 }
 
@@ -316,6 +325,10 @@ constexpr int SCREEN_QUEUE = 128;  // >= SCREEN_FLUSH - 1 + 64
 //                       screening and deciding in one kernel as before.
 // Every try below a hypothesis' resume point has been screened, every "maybe" among them decided: the minimum accepted
 // try is the try the reference's sequential loop stops at (esac_util.h:152-223).
+// gridDim.z wavefronts share a hypothesis: wavefront w screens rounds w, w + Z, w + 2Z, ... (64 tries each) and leaves as
+// soon as its next round starts at or beyond samp_resume[h] -- the lowest point at which some wavefront saw a strong
+// candidate (atomicMin; 0x7fffffff until then).  With few hypotheses in flight (a single frame with some wrong-expert
+// stragglers) that divides the length of the tail by Z.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_prescreen(KArgs a) {
     frame_view(a);
     const int h = blockIdx.x, lane = threadIdx.x;
@@ -327,8 +340,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const Cam cam = make_cam(a);
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const float thr = a.tau + SCREEN_MARGIN;
-    long long base = a.first_try;
-    for (; base < a.max_tries; base += 64) {
+    int* resume = a.samp_resume + h;
+    const long long stride = 64LL * gridDim.z;
+    for (long long base = a.first_try + 64LL * blockIdx.z; base < a.max_tries; base += stride) {
+        if (base >= __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         const int t = (int)base + lane;
         bool maybe = false, strong = false;
         if (t < a.max_tries) {
@@ -354,14 +369,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (maybe && pos < a.samp_cap) reinterpret_cast<int2*>(a.samp_entries)[pos] = make_int2(blockIdx.y * a.N + h, t);
             // list full (the counter stays beyond the capacity, readers clamp; every slot below the capacity is written by
             // exactly one lane): this round is not fully listed, so the hypothesis resumes AT it
-            if (pos0 + cnt > a.samp_cap) break;
-            if (__any(strong)) {
-                base += 64;
+            if (pos0 + cnt > a.samp_cap) {
+                if (lane == 0) atomicMin(resume, (int)base);
+                break;
+            }
+            if (__any(strong)) {  // everything up to and including this round is listed: resume after it
+                if (lane == 0) atomicMin(resume, (int)(base + 64 < a.max_tries ? base + 64 : a.max_tries));
                 break;
             }
         }
     }
-    if (lane == 0) a.samp_resume[h] = (int)(base < a.max_tries ? base : a.max_tries);
 }
 
 // one lane per listed try: the fp64 route's decision, lowest accepted try per hypothesis
@@ -394,20 +411,56 @@ __global__ __launch_bounds__(64) void k_sample_decide(KArgs a0) {
         if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2) && !cannot_pass(reproj2, (double)a0.tau)) {
             double rvec[3], T[3], R[9];
             accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a0.tau, rvec, T, R);
+            if (accepted) {  // park the solved hypothesis with its list entry: the commit kernel only copies the winner's
+                double* cd = a0.samp_cand + (size_t)i * 16;
+                cd[0] = rvec[0]; cd[1] = rvec[1]; cd[2] = rvec[2]; cd[3] = T[0]; cd[4] = T[1]; cd[5] = T[2];
+                const Centre c = map_centre(a0, map);
+                float* cf = reinterpret_cast<float*>(cd + 6);  // 12 floats: [R | t + R c] (store_rt32)
+#pragma unroll
+                for (int k = 0; k < 9; k++) cf[k] = (float)R[k];
+                cf[9] = (float)(R[0] * (double)c.x + R[1] * (double)c.y + R[2] * (double)c.z + T[0]);
+                cf[10] = (float)(R[3] * (double)c.x + R[4] * (double)c.y + R[5] * (double)c.z + T[1]);
+                cf[11] = (float)(R[6] * (double)c.x + R[7] * (double)c.y + R[8] * (double)c.z + T[2]);
+                int* ci = reinterpret_cast<int*>(cd + 12);     // 8 ints: the sampled cells
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    ci[2 * j] = cx[j];
+                    ci[2 * j + 1] = cy[j];
+                }
+            }
         }
     }
-    if (accepted) atomicMin(a0.best_try + hg, t);
+    // lowest accepted try per hypothesis; the list position rides in the low word so that the winner's record is found
+    if (accepted) atomicMin(a0.best_try + hg, ((unsigned long long)(unsigned)t << 32) | (unsigned)i);
 }
 
-// one lane per pending hypothesis: store the accepted try (re-solved), or the last try's state when the budget is spent
-__global__ __launch_bounds__(64) void k_sample_commit(KArgs a) {
+// one lane per pending hypothesis: copy the accepted try's record, or re-solve the last try when the budget is spent
+// without one (its state remains: esac_util.h:152-223 leaves the pose of the final iteration, a failed solve the zero pose)
+__global__ __launch_bounds__(64) void k_sample_commit(KArgs a0) {
+    KArgs a = a0;
     frame_view(a);
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= a.N || a.tries[h] != SAMPLE_PENDING) return;
-    const int found = a.best_try[h];
-    const bool have = found != 0x7fffffff;
-    if (!have && a.samp_resume[h] < a.max_tries) return;  // false alarm / full list: k_sample_screened<true> continues
-    const int t = have ? found : a.max_tries - 1;
+    const unsigned long long found = a.best_try[h];
+    if (found != ~0ull) {
+        const double* cd = a0.samp_cand + (size_t)(unsigned)found * 16;
+        double* hp = a.hyps + (size_t)h * 6;
+#pragma unroll
+        for (int k = 0; k < 6; k++) hp[k] = cd[k];
+        const float* cf = reinterpret_cast<const float*>(cd + 6);
+        float* rt = a.rt32 + (size_t)h * 12;
+#pragma unroll
+        for (int k = 0; k < 12; k++) rt[k] = cf[k];
+        const int* ci = reinterpret_cast<const int*>(cd + 12);
+        int* sx = a.sample_xy + (size_t)h * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sx[k] = ci[k];
+        a.tries[h] = (int)(found >> 32);
+        return;
+    }
+    if (a.samp_resume[h] > a.max_tries) a.samp_resume[h] = a.max_tries;  // no stop: the whole budget has been screened
+    if (a.samp_resume[h] < a.max_tries) return;  // false alarm / full list: k_sample_screened<true> continues
+    const int t = a.max_tries - 1;
     const int e = expert_of(a, h);
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
@@ -421,7 +474,7 @@ __global__ __launch_bounds__(64) void k_sample_commit(KArgs a) {
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     gather_sample(a, map, P, rng, (uint32_t)global_hyp(a, h), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
     if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2)) accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
-    store_hypothesis(a, h, map, rvec, T, R, cx, cy, have ? t : -1);
+    store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);
 }
 
 // RESUME: continue where k_sample_prescreen stopped (its parked tries preloaded into the queue).
@@ -829,34 +882,48 @@ void launch_pick_record(const double* records, int world, double* pin, double ep
 void launch_stats_exact(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_stats_exact<256>, dim3(1, a.frames), dim3(256), 0, s, a);
 }
+// the chain that finishes hypotheses left SAMPLE_PENDING at try b.first_try (see k_sample_prescreen)
+static void launch_sample_stragglers(const KArgs& b, int waves_per_hyp, hipStream_t s) {
+    (void)hipMemsetAsync(b.samp_count, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_sample_prescreen, dim3(b.N, b.frames, waves_per_hyp), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_sample_decide, dim3((b.samp_cap + 63) / 64), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_sample_commit, dim3((b.N + 63) / 64, b.frames), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_sample_screened<true>, dim3(b.N, b.frames), dim3(64), 0, s, b);
+}
+
 void launch_sample(const KArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.frames;
     if (a.sc4) hipLaunchKernelGGL(k_pack_cells, dim3(2048), dim3(256), 0, s, a);
-    if (total <= 1024)  // latency: 64 tries per round, the candidates of a try on four lanes
-        hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, a);
-    else if (total <= 4096)
-        hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, a);
-    else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest one wavefront each, screened
-        KArgs b = a;
+    KArgs b = a;
+    b.handover = 0x7fffffff;
+    // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on four lanes at first)
+    // settles a hypothesis of the right expert within its first round; with several experts the stragglers are handed to
+    // the spread, screened search after `handover` tries, 32768 / total (at most 64) wavefronts each.
+    const bool handover = a.E > 1 && a.max_tries > 1024;
+    if (total <= 1024) {
+        if (handover) b.handover = 128;
+        hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, b);
+    } else if (total <= 4096) {
+        if (handover) b.handover = 128;
+        hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, b);
+    } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
         for (int pass = 0; pass < FIRST_PHASE_PASSES && b.first_try < a.max_tries; pass++) {
             hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
             b.first_try += FIRST_PHASE_TRIES;
         }
-#ifdef ESAC_SAMPLE_UNSCREENED  // A/B switch (scripts/dev/variants.sh): the round-1 kernel, every try solved in full
-        if (b.first_try < a.max_tries) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
-#else
         if (b.first_try < a.max_tries) {
-#ifdef ESAC_SAMPLE_SINGLE_KERNEL  // A/B switch: screening and decision in one kernel (one wavefront per SIMD throughout)
-            hipLaunchKernelGGL(k_sample_screened<false>, dim3(a.N, a.frames), dim3(64), 0, s, b);
+#ifdef ESAC_SAMPLE_UNSCREENED  // A/B switch (scripts/dev/variants.sh): the round-1 kernel, every try solved in full
+            hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
 #else
-            (void)hipMemsetAsync(a.samp_count, 0, sizeof(int), s);
-            hipLaunchKernelGGL(k_sample_prescreen, dim3(a.N, a.frames), dim3(64), 0, s, b);
-            hipLaunchKernelGGL(k_sample_decide, dim3((a.samp_cap + 63) / 64), dim3(64), 0, s, b);
-            hipLaunchKernelGGL(k_sample_commit, dim3((a.N + 63) / 64, a.frames), dim3(64), 0, s, b);
-            hipLaunchKernelGGL(k_sample_screened<true>, dim3(a.N, a.frames), dim3(64), 0, s, b);
+            launch_sample_stragglers(b, 1, s);
 #endif
         }
-#endif
+        return;
+    }
+    if (handover) {
+        b.first_try = b.handover;
+        const int wph = (int)(32768 / total) < 1 ? 1 : (int)(32768 / total) > 64 ? 64 : (int)(32768 / total);
+        launch_sample_stragglers(b, wph, s);
     }
 }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {

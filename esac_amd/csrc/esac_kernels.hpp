@@ -63,6 +63,7 @@ struct KArgs {
     uint64_t seed, call;
     int max_tries, max_ref_steps, hyp_offset;
     int first_try;             // sampling continues from this try (two-phase throughput shape), 0 otherwise
+    int handover;              // k_sample leaves a hypothesis SAMPLE_PENDING once it has spent this many tries
     float margin;
     int flags;                 // ESAC_FLAG_* (include/esac_hip.h)
     const int32_t* hyp_index;  // optional [N] global hypothesis indices
@@ -73,7 +74,8 @@ struct KArgs {
     int* tries;           // [N]
     const float4* sc4;    // [E,H*W] (x,y,z,0) records of the maps for the sampler's gathers, or null (small maps: planar reads hit L2)
     int* samp_resume;     // [N] k_sample_prescreen: first try it did NOT screen (k_sample_screened<true> resumes there)
-    int* best_try;        // [N] k_sample_decide: lowest accepted try among the listed ones (0x7fffffff: none)
+    unsigned long long* best_try;  // [N] k_sample_decide: (lowest accepted try << 32 | list position) among the listed ones, ~0: none
+    double* samp_cand;    // [samp_cap,16] solved hypothesis of an accepted list entry: rvec,tvec | 12 floats rt32 | 8 ints cells
     int* samp_entries;    // [samp_cap] (frame * N + hypothesis, try) pairs: the tries the screen could not rule out
     int* samp_count;      // [1] entries appended (may exceed samp_cap: clamp)
     int samp_cap;

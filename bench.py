@@ -49,6 +49,8 @@ from esac_amd import distributed as D  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBPS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector), an FMA counted as 2
+SCORE_FLOPS_PER_CELL = 35  # soft-inlier term of one cell: 3x4 transform (18), projection (4+1), distance (3+1), clamp, sigmoid (6), sum (2)
 
 PRESETS = {
     "cfg2": dict(experts=1, hyps=256, grid="60x80", gating="single", policy="range", scaling="weak"),
@@ -367,8 +369,8 @@ def main():
             alg_bytes = n_total * 12.0 * H * W
             achieved = alg_bytes / (score_ms * 1e-3) / 1e9
             traffic = rp_ms = None
+            srow = next(r for r in kernels if r["stage"] == "score")
             if prof:
-                srow = next(r for r in kernels if r["stage"] == "score")
                 if srow.get("rocprofv3"):
                     fb = [k.get("fetch_bytes_x2corr") for k in srow["rocprofv3"]]
                     wb = [k.get("write_bytes") or 0 for k in srow["rocprofv3"]]
@@ -388,8 +390,17 @@ def main():
                 "rocprofv3_kernel_ms": rp_ms,
                 "frac_at_rocprofv3_duration": alg_bytes / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if rp_ms else None,
                 "frac_of_l2_peak": achieved / L2_PEAK_GBPS,
-                "note": "algorithmic bytes = every hypothesis reads x,y,z of its expert's map once (12*H*W); physical HBM traffic is `traffic`. "
-                        "The score is VALU-bound by design (~21 fp32 ops + 4 transcendentals per cell): see DESIGN.md section 5",
+                "cache_served": achieved > HBM_PEAK_GBPS,
+                # what actually limits the kernel: fp32 VALU issue (21 instructions per cell, 4 of them transcendental)
+                "valu": {"bound": "fp32 vector", "achieved": n_total * float(H * W) * SCORE_FLOPS_PER_CELL / (score_ms * 1e-3) / 1e12,
+                         "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": n_total * float(H * W) * SCORE_FLOPS_PER_CELL / (score_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                         "flops_per_cell": SCORE_FLOPS_PER_CELL,
+                         "frac_of_issue_bound_rocprofv3": (srow.get("rocprofv3") or [{}])[0].get("frac_of_issue_bound") if prof else None},
+                "hbm_physical_frac": (traffic / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "note": "algorithmic bytes = every hypothesis reads x,y,z of its expert's map once (12*H*W, SURVEY 8d); `traffic` is what reached "
+                        "the fabric.  A fraction above 1 (`cache_served`) means the re-reads never leave L2 / the registers of the tile-"
+                        "stationary kernel -- by design; the limiter is then VALU issue, see `valu` and DESIGN.md section 5",
             }
         if not args.no_extras and world == 1 and not big:
             # the reference's calling convention: CPU tensors in (test_esac.py:187 `.cpu()`), so every call pays the H2D hop

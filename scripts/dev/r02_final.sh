@@ -1,0 +1,25 @@
+# round 2 measurement set -> gpurun_out/profiles_r02 (copied to profiles/ afterwards)
+R=$GRAFT_REPO_ROOT
+cd $R
+P=gpurun_out/profiles_r02
+mkdir -p $P
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 scripts/dev/valu_rate.hip -o /tmp/valu_rate 2>/dev/null && /tmp/valu_rate > $P/r02_valu_rate.txt
+timeout 900 python bench.py 2> $P/err_cfg2.txt | tail -1 > $P/r02_bench_cfg2.json
+timeout 600 python bench.py --config cfg3 --steps 200 --warmup 20 --no-extras 2>/dev/null | tail -1 > $P/r02_bench_cfg3.json
+timeout 600 python bench.py --config cfg4 --steps 100 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $P/r02_bench_cfg4.json
+timeout 600 python bench.py --config cfg5a --steps 30 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $P/r02_bench_cfg5a.json
+timeout 600 python bench.py --config cfg5b --steps 8 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $P/r02_bench_cfg5b.json
+for b in 16 256; do timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-training --batch $b 2>/dev/null | tail -1 > $P/r02_bench_batch$b.json; done
+for f in cfg2 cfg3 cfg4 cfg5a cfg5b batch16 batch256; do python - $P/r02_bench_$f.json $f <<'PY'
+import json,sys
+d=json.load(open(sys.argv[1]))
+print(sys.argv[2], "hyp/s %.0f ms/step %.4f" % (d["value"], d["ms_per_step"]), [(k["stage"], round(k["avg_us"],1)) for k in d.get("kernels",[])], "roofline frac", round(d["roofline"]["frac"],3), "cpu", d.get("cpu_baseline",{}).get("value"), d.get("cpu_baseline",{}).get("cores"), "acc", (d.get("accuracy") or {}).get("median_rot_err_rad"), (d.get("accuracy") or {}).get("winner_match"), "batched", d.get("batched",{}).get("value"), "training", d.get("training",{}).get("ms_per_call"), "h2d", d.get("with_h2d",{}).get("value"))
+PY
+done
+bash scripts/dev/profile_cfg.sh cfg2 r02 > $P/log_cfg2.txt 2>&1
+bash scripts/dev/profile_cfg.sh cfg3 r02 --steps 100 --warmup 10 > $P/log_cfg3.txt 2>&1
+bash scripts/dev/profile_cfg.sh cfg4 r02 --steps 60 --warmup 6 > $P/log_cfg4.txt 2>&1
+bash scripts/dev/profile_cfg.sh cfg5a r02 --steps 12 --warmup 2 > $P/log_cfg5a.txt 2>&1
+bash scripts/dev/profile_cfg.sh cfg5b r02 --steps 4 --warmup 1 > $P/log_cfg5b.txt 2>&1
+cat $P/r02_cfg*_kernels.txt
+rm -rf gpurun_out/prof_r02_*

@@ -352,8 +352,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             float Pf[4][3];
             double mu[4], mv[4];
             gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-            P3PSetup S;
-            if (p3p_setup(Pt, mu, mv, cam, S)) {
+            ScreenSetup S;  // the screen's private (contracted, fast-cubic) copy of the roots and depths
+            if (screen_setup(Pt, mu, mv, cam, S)) {
                 const float err = p3p_screen_roots(S, Pf, (float)mu[3], (float)mv[3], a.focal, a.ppx, a.ppy);
                 maybe = !(err > thr);
                 strong = maybe && err >= 0.0f && err <= a.tau;
@@ -508,8 +508,8 @@ __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
                 float Pf[4][3];
                 double mu[4], mv[4];
                 gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-                P3PSetup S;
-                if (p3p_setup(Pt, mu, mv, cam, S)) {
+                ScreenSetup S;  // the screen's private (contracted, fast-cubic) copy of the roots and depths
+                if (screen_setup(Pt, mu, mv, cam, S)) {
                     const float err = p3p_screen_roots(S, Pf, (float)mu[3], (float)mv[3], a.focal, a.ppx, a.ppy);
                     maybe = !(err > thr);                        // delicate (-1) and NaN included
                     strong = maybe && err >= 0.0f && err <= a.tau;  // the screen itself sees an inlier

@@ -211,6 +211,205 @@ ESAC_HD bool p3p_screen_f32(const float (&Pf)[4][3], const float (&mu_px)[4], co
     return !(e > thr);  // delicate (-1), NaN and anything within the threshold: maybe
 }
 
+// ---- the screen's private copy of the roots and depths ------------------------------------------------------------------------
+// p3p_setup / p3p_candidate_lengths (pose_math.hpp) follow the CPU solver operation by operation -- IEEE mul and add, the
+// library's acos / cos / pow -- because the DECISION must round like the reference's on ill-conditioned samples.  The
+// screen only needs the same roots and depths to ~1e-13: a "maybe" is decided by that exact route anyway, and a rejected
+// try has its 4th point hundreds of pixels out.  So this copy lets the compiler contract mul + add into FMAs (a quarter
+// fewer fp64 instructions in the coefficient polynomials) and replaces the fp64 library calls of the resolvent cubic
+// (~300 dependent instructions for acos + cos, or pow) by an fp32 seed polished with Newton steps in fp64.  Candidate
+// validity (x > 0, b1 > 0, v > 0) can differ from the exact route only where those quantities are within ~1e-13 of
+// zero relative to their terms; the calibration probe runs THIS code against the exact route.
+struct ScreenSetup {
+    double mu[3], mv[3], mk[3];
+    double dist2, a, b, p, q, r, inv_b0;
+    double x[4];
+    int n;
+};
+
+// cos(acos(c) / 3), |c| <= 1: fp32 seed, Newton on 4u^3 - 3u - c = 0 (the seed is ~1e-7 off: two steps reach rounding);
+// next to c = -1 (u = 1/2 is a double root there) the library route is kept
+ESAC_HD double cos_third_acos(double c) {
+#pragma clang fp contract(fast)
+    if (c < -0.999) return cos(acos(c) * (1.0 / 3.0));
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cos_f32 on an argument in [0, pi/3]: the library cosf carries a large-argument reduction with a stack array
+    double u = (double)__cosf(acosf((float)c) * (1.0f / 3.0f));
+#else
+    double u = (double)cosf(acosf((float)c) * (1.0f / 3.0f));
+#endif
+#pragma unroll
+    for (int it = 0; it < 3; it++) {  // the fast fp32 cosine seeds to ~1e-6: three steps reach rounding with margin
+        const double u2 = u * u;
+        const double fv = (4.0 * u2 - 3.0) * u - c, df = 12.0 * u2 - 3.0;
+        u -= fv / df;
+    }
+    return u;
+}
+// a^(1/3), a > 0: fp32 seed, two Newton steps on u^3 = a
+ESAC_HD double cbrt_pos(double a) {
+#pragma clang fp contract(fast)
+    if (!(a > 1e-300 && a < 1e300)) return pow(a, 1.0 / 3.0);
+    // scale into float range through the exponent: a = m * 8^k
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int ex = __builtin_amdgcn_frexp_exp(a);  // a = m * 2^ex, m in [0.5, 1); no out-parameter (= no stack slot)
+    const double m = __builtin_amdgcn_frexp_mant(a);
+#else
+    int ex;
+    const double m = frexp(a, &ex);
+#endif
+    const int k = (ex - (ex < 0 ? 2 : 0)) / 3;  // floor-ish division by 3
+    const double ms = ldexp(m, ex - 3 * k);  // in [2^-3, 2^3)
+    double u = (double)cbrtf((float)ms);
+#pragma unroll
+    for (int it = 0; it < 2; it++) u -= (u * u * u - ms) / (3.0 * u * u);
+    return ldexp(u, k);
+}
+
+// real roots of the quartic, Ferrari through the first real root of the resolvent cubic: the branch structure of
+// quartic_real_roots / cubic_first_roots (pose_math.hpp), contracted arithmetic, fast cubic root
+ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e, double& x0, double& x1, double& x2, double& x3) {
+#pragma clang fp contract(fast)
+    if (a == 0) return -1;  // degenerate quartic: the caller reports "maybe"
+    const double inv_a = 1. / a;
+    b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+    const double b2 = b * b, bc = b * c, b3 = b2 * b;
+    // resolvent: y^3 - c y^2 + (d b - 4 e) y + (4 c e - d^2 - b^2 e)
+    const double cb = -c, cc = d * b - 4 * e, cd = 4 * c * e - d * d - b2 * e;
+    const double Q = (3 * cc - cb * cb) / 9, R = (9 * cb * cc - 27 * cd - 2 * cb * cb * cb) / 54;
+    const double Q3 = Q * Q * Q, D = Q3 + R * R;
+    const double cb3 = (1. / 3.) * cb;
+    double r0;
+    if (Q == 0) {
+        if (R == 0) r0 = -cb3;
+        else r0 = (R > 0 ? cbrt_pos(2 * R) : -cbrt_pos(-2 * R)) - cb3;  // pow(2R, 1/3) is NaN for R < 0 in the exact route: rare, harmless here
+    } else if (D <= 0) {
+        const double sq = sqrt(-Q3);
+        double arg = R / sq;
+        arg = arg > 1. ? 1. : (arg < -1. ? -1. : arg);
+        r0 = 2 * sqrt(-Q) * cos_third_acos(arg) - cb3;
+    } else {
+        const double AD = cbrt_pos(fabs(R) + sqrt(D)) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+        const double BD = (AD == 0) ? 0 : -Q / AD;
+        r0 = AD + BD - cb3;
+    }
+    const double R2 = 0.25 * b2 - c + r0;
+    if (R2 < 0) return 0;
+    const double Rr = sqrt(R2);
+    double D2, E2;
+    if (Rr < 10E-12) {
+        const double temp = r0 * r0 - 4 * e;
+        if (temp < 0) D2 = E2 = -1;
+        else {
+            const double sq = sqrt(temp);
+            D2 = 0.75 * b2 - 2 * c + 2 * sq;
+            E2 = D2 - 4 * sq;
+        }
+    } else {
+        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * (4 * bc - 8 * d - b3) / Rr;
+        D2 = u + v;
+        E2 = u - v;
+    }
+    const double b_4 = 0.25 * b, R_2 = 0.5 * Rr;
+    // scalars, not an indexed array: a run-time index (or an array the optimiser cannot split) ends up in scratch memory
+    int nb = 0;
+    if (D2 >= 0) {
+        const double Ds = sqrt(D2);
+        x0 = R_2 + 0.5 * Ds - b_4;
+        x1 = x0 - Ds;
+        nb = 2;
+    }
+    if (E2 >= 0) {
+        const double Es = sqrt(E2);
+        const double xa = -R_2 + 0.5 * Es - b_4, xb = xa - Es;
+        if (nb == 0) {
+            x0 = xa;
+            x1 = xb;
+            nb = 2;
+        } else {
+            x2 = xa;
+            x3 = xb;
+            nb = 4;
+        }
+    }
+    return nb;
+}
+
+// p3p_setup for the screen: false = no candidate at all (the exact route returns false on the same conditions);
+// n < 0 marks a degenerate configuration the caller must treat as "maybe"
+ESAC_HD bool screen_setup(const V3 P[4], const double mu_px[4], const double mv_px[4], const Cam& cam, ScreenSetup& S) {
+#pragma clang fp contract(fast)
+    const double inv_fx = 1. / cam.fx, inv_fy = 1. / cam.fy, cx_fx = cam.cx * inv_fx, cy_fy = cam.cy * inv_fy;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        S.mu[i] = inv_fx * mu_px[i] - cx_fx;
+        S.mv[i] = inv_fy * mv_px[i] - cy_fy;
+        S.mk[i] = 1. / sqrt(S.mu[i] * S.mu[i] + S.mv[i] * S.mv[i] + 1);
+        S.mu[i] *= S.mk[i];
+        S.mv[i] *= S.mk[i];
+    }
+    const double* mu = S.mu;
+    const double* mv = S.mv;
+    const double* mk = S.mk;
+    const V3 d12 = P[1] - P[2], d02 = P[0] - P[2], d01 = P[0] - P[1];
+    const double s0 = d12.x * d12.x + d12.y * d12.y + d12.z * d12.z;
+    const double s1 = d02.x * d02.x + d02.y * d02.y + d02.z * d02.z;
+    const double s2 = d01.x * d01.x + d01.y * d01.y + d01.z * d01.z;
+    const double p = 2 * (mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2]);
+    const double q = 2 * (mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2]);
+    const double r = 2 * (mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1]);
+    const double inv_d22 = 1. / s2;
+    const double a = inv_d22 * s0, b = inv_d22 * s1;
+    const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+    const double pr = p * r, pqr = q * pr;
+    S.n = 0;
+    if (p2 + q2 + r2 - pqr - 1 == 0) return false;
+    const double ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
+    const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    if (A == 0) return false;
+    const double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    const double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    const double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    const double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+    const double b0 = b * temp * temp;
+    if (b0 == 0) return false;
+    double x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+    const int n = quartic_roots_fast(A, B, C, D, E, x0, x1, x2, x3);
+    if (n == 0) return false;
+    S.n = n;  // -1: degenerate
+    S.x[0] = x0; S.x[1] = x1; S.x[2] = x2; S.x[3] = x3;
+    S.dist2 = sqrt(s2); S.a = a; S.b = b; S.p = p; S.q = q; S.r = r;
+    S.inv_b0 = 1. / b0;
+    return true;
+}
+
+// p3p_candidate_lengths for the screen (same polynomial, contracted)
+ESAC_HD bool screen_lengths(const ScreenSetup& S, double x, double& X, double& Y, double& Z) {
+#pragma clang fp contract(fast)
+    const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
+    const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
+    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+    if (x <= 0) return false;
+    const double xx = x * x;
+    const double b1 =
+        ((1 - a - b) * xx + (q * a - q) * x + 1 - a + b) *
+        (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+          (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * xx +
+         (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+          pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+         2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+         p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+    if (b1 <= 0) return false;
+    const double y = S.inv_b0 * b1;
+    const double v = xx + y * y - x * y * r;
+    if (v <= 0) return false;
+    Z = S.dist2 / sqrt(v);
+    X = x * Z;
+    Y = y * Z;
+    return true;
+}
+
 // ---- screen over the fp64 roots and depths --------------------------------------------------------------------------------
 // fp32 Ferrari is too fragile to screen with (the probe finds ~40 % of random tries within rounding distance of a branch
 // threshold), and the depth ratio y must be the fp64 route's own b1 / b0 -- on ill-conditioned samples (base points a few
@@ -222,7 +421,10 @@ ESAC_HD bool p3p_screen_f32(const float (&Pf)[4][3], const float (&mu_px)[4], co
 // they are from that is measured, and a candidate whose camera-frame triangle misses the scene triangle's side lengths
 // by more than 1e-3 is reported as "maybe" instead of being judged.
 // Returns the smallest 4th-point error over the candidates (+inf: none), or ESAC_SCREEN_MAYBE.
-ESAC_HD float p3p_screen_roots(const P3PSetup& S, const float (&Pf)[4][3], float mu3_px, float mv3_px, float f, float cx, float cy) {
+template <typename Setup, typename Lengths>
+ESAC_HD float p3p_screen_roots_t(const Setup& S, Lengths lengths, const float (&Pf)[4][3], float mu3_px, float mv3_px, float f, float cx,
+                               float cy) {
+    if (S.n < 0) return ESAC_SCREEN_MAYBE;  // degenerate quartic
     const float mu[3] = {(float)S.mu[0], (float)S.mu[1], (float)S.mu[2]}, mv[3] = {(float)S.mv[0], (float)S.mv[1], (float)S.mv[2]},
                 mk[3] = {(float)S.mk[0], (float)S.mk[1], (float)S.mk[2]};
     const V3f P0{Pf[0][0], Pf[0][1], Pf[0][2]}, P1{Pf[1][0], Pf[1][1], Pf[1][2]}, P2{Pf[2][0], Pf[2][1], Pf[2][2]},
@@ -245,7 +447,7 @@ ESAC_HD float p3p_screen_roots(const P3PSetup& S, const float (&Pf)[4][3], float
     for (int i = 0; i < S.n; i++) {
         const double x = i == 0 ? S.x[0] : i == 1 ? S.x[1] : i == 2 ? S.x[2] : S.x[3];
         double Xd, Yd, Zd;
-        if (!p3p_candidate_lengths(S, x, Xd, Yd, Zd)) continue;  // exactly the candidates the fp64 route skips
+        if (!lengths(S, x, Xd, Yd, Zd)) continue;  // the candidates the fp64 route skips
         const float X = (float)Xd, Y = (float)Yd, Z = (float)Zd;
         if (!(fabsf(X) < 1e18f && fabsf(Y) < 1e18f && fabsf(Z) < 1e18f)) return ESAC_SCREEN_MAYBE;  // NaN / overflow
         const V3f Q0{X * mu[0], X * mv[0], X * mk[0]}, Q1{Y * mu[1], Y * mv[1], Y * mk[1]}, Q2{Z * mu[2], Z * mv[2], Z * mk[2]};
@@ -273,6 +475,16 @@ ESAC_HD float p3p_screen_roots(const P3PSetup& S, const float (&Pf)[4][3], float
         best = fminf(best, epx);
     }
     return best;
+}
+
+// the screen on the exact route's own setup (same doubles), and on its private fast copy
+ESAC_HD float p3p_screen_roots(const P3PSetup& S, const float (&Pf)[4][3], float mu3_px, float mv3_px, float f, float cx, float cy) {
+    return p3p_screen_roots_t(S, [](const P3PSetup& s, double x, double& X, double& Y, double& Z) { return p3p_candidate_lengths(s, x, X, Y, Z); },
+                              Pf, mu3_px, mv3_px, f, cx, cy);
+}
+ESAC_HD float p3p_screen_roots(const ScreenSetup& S, const float (&Pf)[4][3], float mu3_px, float mv3_px, float f, float cx, float cy) {
+    return p3p_screen_roots_t(S, [](const ScreenSetup& s, double x, double& X, double& Y, double& Z) { return screen_lengths(s, x, X, Y, Z); },
+                              Pf, mu3_px, mv3_px, f, cx, cy);
 }
 
 }  // namespace esac

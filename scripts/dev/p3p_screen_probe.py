@@ -19,7 +19,8 @@ def build():
     return C.CDLL(nb.build_screen_probe())
 
 
-def run(lib, name, coords, f, n, seed=1, mode=1):
+def run(lib, name, coords, f, n, seed=1, mode=None):
+    mode = MODE if mode is None else mode
     margins = np.array([0.5, 1, 2, 5, 10, 20, 40, 80], np.float32)
     out = np.zeros(40)
     c = np.ascontiguousarray(coords, np.float32)
@@ -39,6 +40,7 @@ def run(lib, name, coords, f, n, seed=1, mode=1):
 
 if __name__ == "__main__":
     n = float(sys.argv[1]) if len(sys.argv) > 1 else 2e6
+    MODE = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 3
     lib = build()
     if len(sys.argv) > 2 and sys.argv[2] == "debug":
         f = S.make_frame(0, E=2, true_expert=0)

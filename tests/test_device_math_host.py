@@ -328,8 +328,8 @@ def test_closed_form_lm_chain_equals_the_rodrigues_jacobian_chain(probe):
 
 
 def test_fp32_screen_never_rejects_an_accepted_try():
-    """The one-sided contract of the sampling screen (esac_amd/csrc/p3p_screen.hpp, used by k_sample_screened): on the
-    kernels' own source compiled for the host, over 1.5e6 random tries on true-expert, garbage-expert, noise-free,
+    """The one-sided contract of the sampling screen (esac_amd/csrc/p3p_screen.hpp: screen_setup + p3p_screen_roots, as
+    k_sample_prescreen / k_sample_screened run it): on the kernels' own source compiled for the host, over 1.5e6 random tries on true-expert, garbage-expert, noise-free,
     coarse-grid and far-from-origin maps, no try the fp64 route ACCEPTS is ruled out by the screen at HALF the margin the
     kernel uses, the screen's error of every accepted try stays within 0.1 px of tau, and on a garbage map it clears
     more than 99 % of the tries (which is the point of it)."""
@@ -345,7 +345,7 @@ def test_fp32_screen_never_rejects_an_accepted_try():
         _, H, W = c.shape
         lib.probe_screen(c.ctypes.data_as(C.c_void_p), H, W, f["sub"], f["shift"][0], f["shift"][1], C.c_float(f["focal"]),
                          C.c_float(f["ppx"]), C.c_float(f["ppy"]), C.c_float(10.0), C.c_uint64(seed), C.c_longlong(n),
-                         margins.ctypes.data_as(C.c_void_p), 2, 1, out.ctypes.data_as(C.c_void_p))
+                         margins.ctypes.data_as(C.c_void_p), 2, 3, out.ctypes.data_as(C.c_void_p))  # mode 3: what the kernels run
         return out
 
     f = S.make_frame(3, E=2, true_expert=0)

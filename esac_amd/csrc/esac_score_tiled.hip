@@ -8,8 +8,8 @@
 // distinct data.  Here the loop nest is turned inside out:
 //   1. k_bucket: counting sort of the hypotheses by expert (the histogram test_esac.py:178 also takes), a table of
 //      chunks (expert, first position, count <= TILE_HC) and the fp32 poses copied into sorted order;
-//   2. k_score_tiled: ONE WAVEFRONT owns (chunk, sub-tile of 512 cells): it loads its 512 cells once -- 16-byte
-//      coalesced loads, 8 cells per lane kept in registers together with their pixel positions -- and walks the
+//   2. k_score_tiled: ONE WAVEFRONT owns (chunk, sub-tile of 768 cells): it loads its 768 cells once -- 16-byte
+//      coalesced loads, 12 cells per lane kept in registers together with their pixel positions -- and walks the
 //      chunk's hypotheses: pose through scalar loads into SGPRs (the next pose is fetched while the current one is
 //      evaluated), ~22 fp32 VALU ops per cell, DPP/permlane wavefront reduction, one partial sum per (hypothesis,
 //      sub-tile); 64 partials are gathered across the lanes and stored with one coalesced 256-byte write;
@@ -27,7 +27,10 @@
 
 namespace esac {
 
-constexpr int TILE_CPT = 8;                 // cells per lane
+#ifndef ESAC_TILE_CPT
+#define ESAC_TILE_CPT 12
+#endif
+constexpr int TILE_CPT = ESAC_TILE_CPT;     // cells per lane (a multiple of 4)
 constexpr int TILE_CELLS = 64 * TILE_CPT;   // cells per sub-tile (one wavefront)
 constexpr int BUCKET_B = 1024;
 
@@ -163,8 +166,8 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
     const int P = a.H * a.W;
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
     const Centre o = map_centre(a, mx);
-    // this lane's 8 cells: two groups of 4 consecutive cells (W % 4 == 0: a group never straddles a row)
-    float X[TILE_CPT], Y[TILE_CPT], Z[TILE_CPT], px[TILE_CPT], py[TILE_CPT], m[TILE_CPT];
+    // this lane's TILE_CPT cells: groups of 4 consecutive cells (W % 4 == 0: a group never straddles a row), group g of lane l = group g * 64 + l of the sub-tile
+    float X[TILE_CPT], Y[TILE_CPT], Z[TILE_CPT], px[TILE_CPT], py[TILE_CPT / 4], m[TILE_CPT / 4];  // py, weight: per group of 4
     const float step = (float)a.sub;
 #pragma unroll
     for (int g = 0; g < TILE_CPT / 4; g++) {
@@ -182,9 +185,9 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
 #pragma unroll
         for (int l = 0; l < 4; l++) {
             px[4 * g + l] = pxf + (float)l * step;
-            py[4 * g + l] = pyf;
-            m[4 * g + l] = valid ? 1.0f : 0.0f;
         }
+        py[g] = pyf;
+        m[g] = valid ? 1.0f : 0.0f;
     }
     const float kb = a.beta * 1.4426950408889634f, k0 = -a.tau * kb;
     const float maxr = a.max_reproj;
@@ -201,8 +204,8 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
         float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
         for (int u = 0; u < TILE_CPT; u += 2) {
-            acc0 = fmaf(m[u], soft_inlier_tile(cur, X[u], Y[u], Z[u], px[u], py[u], maxr, kb, k0), acc0);
-            acc1 = fmaf(m[u + 1], soft_inlier_tile(cur, X[u + 1], Y[u + 1], Z[u + 1], px[u + 1], py[u + 1], maxr, kb, k0), acc1);
+            acc0 = fmaf(m[u >> 2], soft_inlier_tile(cur, X[u], Y[u], Z[u], px[u], py[u >> 2], maxr, kb, k0), acc0);
+            acc1 = fmaf(m[u >> 2], soft_inlier_tile(cur, X[u + 1], Y[u + 1], Z[u + 1], px[u + 1], py[u >> 2], maxr, kb, k0), acc1);
         }
         const float tot = wave_sum(acc0 + acc1);  // the same total in every lane
         if ((i & 63) == lane) res = tot;

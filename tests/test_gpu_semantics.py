@@ -226,3 +226,52 @@ def test_rank_deficient_refit_follows_the_svd_route(engine, oracle, noise):
     assert np.abs(uv_dev - uv_ref).max() <= 2e-3, np.abs(uv_dev - uv_ref).max()
     r, tt = S.pose_errors(res[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
     assert r <= 1e-4 and tt <= 1e-3, (r, tt)
+
+
+def test_stage_timing_entry_point(engine):
+    """esac_hip_time_stages (what bench.py's `kernels` / `roofline` use): four positive stage times whose sum is close to
+    the blocking call, and the chain it runs leaves the same result as a plain forward."""
+    import time
+    f = S.make_frame(50)
+    ha = S.gating_assignment(f, 256)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    p = engine.make_params(1, 60, 80, 256, seed=8, call=3)
+    res = engine.forward_device(sc, hat, p)
+    st = engine.time_stages(sc, hat, p, reps=8)
+    assert set(st) == {"sample", "score", "select_rescore", "refine"} and all(v > 0 for v in st.values())
+    np.testing.assert_array_equal(engine.read(api.BUF_RESULT)[:31], res[:31])
+    t0 = time.perf_counter()
+    for _ in range(20):
+        engine.forward_device(sc, hat, p)
+    call_ms = (time.perf_counter() - t0) / 20 * 1e3
+    assert 0.5 * call_ms < sum(st.values()) < 1.2 * call_ms, (st, call_ms)
+    assert st["refine"] > st["sample"] > st["score"]  # the single frame's profile: one-CU refinement dominates
+
+
+def test_bench_default_line_has_the_contract_fields():
+    """`python bench.py --steps 30 --warmup 5` (what the driver runs, shortened): ONE JSON line with the contract's keys,
+    the workload of BASELINE configs[1], roofline + per-stage kernels + cpu_baseline + accuracy."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "30", "--warmup", "5", "--batch", "4"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "kernels", "accuracy"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5 and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["config"]["name"] == "cfg2" and d["config"]["hypotheses_total"] == 256 and d["config"]["grid"] == [60, 80]
+    assert "model" not in d["config"] and "workload" in d["config"]
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["algorithmic_bytes_per_launch"] == 256 * 12 * 60 * 80
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] in ("port", "reference")
+    assert d["accuracy"]["winner_match"] == 1.0 and d["accuracy"]["max_rot_err_rad"] <= 1e-4 and d["accuracy"]["max_trans_err_m"] <= 1e-3
+    assert [k["stage"] for k in d["kernels"]] == ["sample", "score", "select_rescore", "refine"]

@@ -220,6 +220,25 @@ ESAC_HD bool p3p_screen_f32(const float (&Pf)[4][3], const float (&mu_px)[4], co
 // (~300 dependent instructions for acos + cos, or pow) by an fp32 seed polished with Newton steps in fp64.  Candidate
 // validity (x > 0, b1 > 0, v > 0) can differ from the exact route only where those quantities are within ~1e-13 of
 // zero relative to their terms; the calibration probe runs THIS code against the exact route.
+// 1/d and sqrt(d) to ~1 ulp without the IEEE division / square-root sequences (v_div_scale + v_div_fmas + v_div_fixup,
+// the exponent-scaled v_rsq iteration: ~10-15 dependent instructions each, ~40 of them per try): reciprocal / reciprocal
+// square root estimate + Newton steps.  Arguments here are squared lengths, cosines and polynomial coefficients of
+// ordinary magnitude; zero, negative and non-finite arguments give what the callers' tests expect (inf / NaN / 0).
+ESAC_HD double scr_rcp(double d) { return fast_rcp(d); }
+ESAC_HD double scr_sqrt(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang fp contract(fast)
+    if (!(d > 0)) return d == 0 ? 0.0 : sqrt(d);  // 0 -> 0, negative / NaN -> NaN as the library
+    double y = __builtin_amdgcn_rsq(d);            // ~1e-8 relative
+    y = y * (1.5 - 0.5 * d * y * y);               // Newton on 1/sqrt: ~1e-16
+    double s = d * y;
+    s = __builtin_fma(0.5 * y, __builtin_fma(-s, s, d), s);  // one correction of the root itself
+    return s;
+#else
+    return sqrt(d);
+#endif
+}
+
 struct ScreenSetup {
     double mu[3], mv[3], mk[3];
     double dist2, a, b, p, q, r, inv_b0;
@@ -242,7 +261,7 @@ ESAC_HD double cos_third_acos(double c) {
     for (int it = 0; it < 3; it++) {  // the fast fp32 cosine seeds to ~1e-6: three steps reach rounding with margin
         const double u2 = u * u;
         const double fv = (4.0 * u2 - 3.0) * u - c, df = 12.0 * u2 - 3.0;
-        u -= fv / df;
+        u -= fv * scr_rcp(df);
     }
     return u;
 }
@@ -262,7 +281,7 @@ ESAC_HD double cbrt_pos(double a) {
     const double ms = ldexp(m, ex - 3 * k);  // in [2^-3, 2^3)
     double u = (double)cbrtf((float)ms);
 #pragma unroll
-    for (int it = 0; it < 2; it++) u -= (u * u * u - ms) / (3.0 * u * u);
+    for (int it = 0; it < 2; it++) u -= (u * u * u - ms) * scr_rcp(3.0 * u * u);
     return ldexp(u, k);
 }
 
@@ -271,12 +290,12 @@ ESAC_HD double cbrt_pos(double a) {
 ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e, double& x0, double& x1, double& x2, double& x3) {
 #pragma clang fp contract(fast)
     if (a == 0) return -1;  // degenerate quartic: the caller reports "maybe"
-    const double inv_a = 1. / a;
+    const double inv_a = scr_rcp(a);
     b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
     const double b2 = b * b, bc = b * c, b3 = b2 * b;
     // resolvent: y^3 - c y^2 + (d b - 4 e) y + (4 c e - d^2 - b^2 e)
     const double cb = -c, cc = d * b - 4 * e, cd = 4 * c * e - d * d - b2 * e;
-    const double Q = (3 * cc - cb * cb) / 9, R = (9 * cb * cc - 27 * cd - 2 * cb * cb * cb) / 54;
+    const double Q = (3 * cc - cb * cb) * (1. / 9.), R = (9 * cb * cc - 27 * cd - 2 * cb * cb * cb) * (1. / 54.);
     const double Q3 = Q * Q * Q, D = Q3 + R * R;
     const double cb3 = (1. / 3.) * cb;
     double r0;
@@ -284,29 +303,29 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
         if (R == 0) r0 = -cb3;
         else r0 = (R > 0 ? cbrt_pos(2 * R) : -cbrt_pos(-2 * R)) - cb3;  // pow(2R, 1/3) is NaN for R < 0 in the exact route: rare, harmless here
     } else if (D <= 0) {
-        const double sq = sqrt(-Q3);
-        double arg = R / sq;
+        const double sq = scr_sqrt(-Q3);
+        double arg = R * scr_rcp(sq);
         arg = arg > 1. ? 1. : (arg < -1. ? -1. : arg);
-        r0 = 2 * sqrt(-Q) * cos_third_acos(arg) - cb3;
+        r0 = 2 * scr_sqrt(-Q) * cos_third_acos(arg) - cb3;
     } else {
-        const double AD = cbrt_pos(fabs(R) + sqrt(D)) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
-        const double BD = (AD == 0) ? 0 : -Q / AD;
+        const double AD = cbrt_pos(fabs(R) + scr_sqrt(D)) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+        const double BD = (AD == 0) ? 0 : -Q * scr_rcp(AD);
         r0 = AD + BD - cb3;
     }
     const double R2 = 0.25 * b2 - c + r0;
     if (R2 < 0) return 0;
-    const double Rr = sqrt(R2);
+    const double Rr = scr_sqrt(R2);
     double D2, E2;
     if (Rr < 10E-12) {
         const double temp = r0 * r0 - 4 * e;
         if (temp < 0) D2 = E2 = -1;
         else {
-            const double sq = sqrt(temp);
+            const double sq = scr_sqrt(temp);
             D2 = 0.75 * b2 - 2 * c + 2 * sq;
             E2 = D2 - 4 * sq;
         }
     } else {
-        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * (4 * bc - 8 * d - b3) / Rr;
+        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * (4 * bc - 8 * d - b3) * scr_rcp(Rr);
         D2 = u + v;
         E2 = u - v;
     }
@@ -314,13 +333,13 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
     // scalars, not an indexed array: a run-time index (or an array the optimiser cannot split) ends up in scratch memory
     int nb = 0;
     if (D2 >= 0) {
-        const double Ds = sqrt(D2);
+        const double Ds = scr_sqrt(D2);
         x0 = R_2 + 0.5 * Ds - b_4;
         x1 = x0 - Ds;
         nb = 2;
     }
     if (E2 >= 0) {
-        const double Es = sqrt(E2);
+        const double Es = scr_sqrt(E2);
         const double xa = -R_2 + 0.5 * Es - b_4, xb = xa - Es;
         if (nb == 0) {
             x0 = xa;
@@ -339,12 +358,12 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
 // n < 0 marks a degenerate configuration the caller must treat as "maybe"
 ESAC_HD bool screen_setup(const V3 P[4], const double mu_px[4], const double mv_px[4], const Cam& cam, ScreenSetup& S) {
 #pragma clang fp contract(fast)
-    const double inv_fx = 1. / cam.fx, inv_fy = 1. / cam.fy, cx_fx = cam.cx * inv_fx, cy_fy = cam.cy * inv_fy;
+    const double inv_fx = scr_rcp(cam.fx), inv_fy = scr_rcp(cam.fy), cx_fx = cam.cx * inv_fx, cy_fy = cam.cy * inv_fy;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         S.mu[i] = inv_fx * mu_px[i] - cx_fx;
         S.mv[i] = inv_fy * mv_px[i] - cy_fy;
-        S.mk[i] = 1. / sqrt(S.mu[i] * S.mu[i] + S.mv[i] * S.mv[i] + 1);
+        S.mk[i] = scr_rcp(scr_sqrt(S.mu[i] * S.mu[i] + S.mv[i] * S.mv[i] + 1));
         S.mu[i] *= S.mk[i];
         S.mv[i] *= S.mk[i];
     }
@@ -358,7 +377,7 @@ ESAC_HD bool screen_setup(const V3 P[4], const double mu_px[4], const double mv_
     const double p = 2 * (mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2]);
     const double q = 2 * (mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2]);
     const double r = 2 * (mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1]);
-    const double inv_d22 = 1. / s2;
+    const double inv_d22 = scr_rcp(s2);
     const double a = inv_d22 * s0, b = inv_d22 * s1;
     const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
     const double pr = p * r, pqr = q * pr;
@@ -379,8 +398,8 @@ ESAC_HD bool screen_setup(const V3 P[4], const double mu_px[4], const double mv_
     if (n == 0) return false;
     S.n = n;  // -1: degenerate
     S.x[0] = x0; S.x[1] = x1; S.x[2] = x2; S.x[3] = x3;
-    S.dist2 = sqrt(s2); S.a = a; S.b = b; S.p = p; S.q = q; S.r = r;
-    S.inv_b0 = 1. / b0;
+    S.dist2 = scr_sqrt(s2); S.a = a; S.b = b; S.p = p; S.q = q; S.r = r;
+    S.inv_b0 = scr_rcp(b0);
     return true;
 }
 
@@ -404,7 +423,7 @@ ESAC_HD bool screen_lengths(const ScreenSetup& S, double x, double& X, double& Y
     const double y = S.inv_b0 * b1;
     const double v = xx + y * y - x * y * r;
     if (v <= 0) return false;
-    Z = S.dist2 / sqrt(v);
+    Z = S.dist2 * scr_rcp(scr_sqrt(v));
     X = x * Z;
     Y = y * Z;
     return true;

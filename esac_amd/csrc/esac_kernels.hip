@@ -442,7 +442,10 @@ __global__ __launch_bounds__(64) void k_sample_commit(KArgs a0) {
     const int h = blockIdx.x * 64 + threadIdx.x;
     if (h >= a.N || a.tries[h] != SAMPLE_PENDING) return;
     const unsigned long long found = a.best_try[h];
-    if (found != ~0ull) {
+    // An accepted try only counts if every try below it has been screened: with several wavefronts per hypothesis one of
+    // them may have run ahead of the final resume point (a "strong" candidate that the decision then rejected) -- such an
+    // entry is ignored here and found again, in order, by k_sample_screened<true>.
+    if (found != ~0ull && (int)(found >> 32) < a.samp_resume[h]) {
         const double* cd = a0.samp_cand + (size_t)(unsigned)found * 16;
         double* hp = a.hyps + (size_t)h * 6;
 #pragma unroll
@@ -898,13 +901,21 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     b.handover = 0x7fffffff;
     // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on four lanes at first)
     // settles a hypothesis of the right expert within its first round; with several experts the stragglers are handed to
-    // the spread, screened search after `handover` tries, 32768 / total (at most 64) wavefronts each.
+    // the spread, screened search after `handover` tries, 32768 / total (at most 64) wavefronts each.  Beyond ~10^3
+    // hypotheses (several experts) a workgroup per hypothesis no longer fits the chip in one wave of workgroups: the
+    // first 32 tries run four hypotheses per wavefront and the screened chain finishes the rest.
     const bool handover = a.E > 1 && a.max_tries > 1024;
-    if (total <= 1024) {
-        if (handover) b.handover = 128;
+#ifndef ESAC_LATENCY_MAX
+#define ESAC_LATENCY_MAX 1024
+#endif
+#ifndef ESAC_HANDOVER
+#define ESAC_HANDOVER 64
+#endif
+    const int wph = (int)(32768 / total) < 1 ? 1 : (int)(32768 / total) > 64 ? 64 : (int)(32768 / total);
+    if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
+        if (handover) b.handover = ESAC_HANDOVER;
         hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, b);
-    } else if (total <= 4096) {
-        if (handover) b.handover = 128;
+    } else if (total <= 4096 && !handover) {
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
         for (int pass = 0; pass < FIRST_PHASE_PASSES && b.first_try < a.max_tries; pass++) {
@@ -915,14 +926,13 @@ void launch_sample(const KArgs& a, hipStream_t s) {
 #ifdef ESAC_SAMPLE_UNSCREENED  // A/B switch (scripts/dev/variants.sh): the round-1 kernel, every try solved in full
             hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
 #else
-            launch_sample_stragglers(b, 1, s);
+            launch_sample_stragglers(b, wph, s);
 #endif
         }
         return;
     }
     if (handover) {
         b.first_try = b.handover;
-        const int wph = (int)(32768 / total) < 1 ? 1 : (int)(32768 / total) > 64 ? 64 : (int)(32768 / total);
         launch_sample_stragglers(b, wph, s);
     }
 }

@@ -219,7 +219,8 @@ static bool want_tiled(const esac_hip_params* p, const float* d_sc, int B) {
     const long long P = (long long)p->H * p->W;
     const bool legal = B == 1 && (p->W & 3) == 0 && (reinterpret_cast<uintptr_t>(d_sc) & 15) == 0 &&
                        p->E <= ESAC_TILED_MAX_EXPERTS && P >= 4;
-    if (!legal || (p->flags & ESAC_FLAG_SCORE_STREAM)) return false;
+    const long long partial_bytes = (long long)tiled_sub_tiles((int)P) * p->N * 4;
+    if (!legal || partial_bytes > (4LL << 30) || (p->flags & ESAC_FLAG_SCORE_STREAM)) return false;
     if (p->flags & ESAC_FLAG_SCORE_TILED) return true;
     return P >= 32768 && p->N >= 64;
 }

@@ -159,9 +159,11 @@ __device__ __forceinline__ double pow10_int(int k) {
 // error pass and, in its own LDS, the correspondences found there -- and every reduction (inlier count, the 24 moments of
 // an LM pass) becomes: block sum -> partial[g] in global memory -> barrier -> every workgroup adds the G partials in the
 // same fixed order.  All workgroups then hold bitwise identical sums, take the same LM / stopping decisions and carry
-// the same pose: nothing is ever broadcast.  The barrier is one monotonic counter: release fence + atomic arrive by one
-// lane, relaxed device-scope polling with s_sleep, ONE acquire fence, __syncthreads (MI355X_MICROARCH.md, "Workgroup
-// dispatch ... inter-workgroup visibility"); partial sums are double-buffered by phase parity, so one barrier per
+// the same pose: nothing is ever broadcast.  The barrier is one monotonic counter: the partial sums are stored with
+// device-scope (sc1, write-through) stores and drained, one lane arrives with a device-scope atomic and polls it with
+// s_sleep, the sums are read back with device-scope loads -- the "sc1 payload, drained, then the flag" hand-off of
+// MI355X_MICROARCH.md ("Workgroup dispatch ... inter-workgroup visibility"), which needs no release / acquire fence
+// (-DESAC_COOP_FENCES builds the fence form); partial sums are double-buffered by phase parity, so one barrier per
 // reduction suffices.  All G workgroups must be resident (G <= 256 one-per-CU workgroups); the spin is bounded and a
 // timeout marks the call as failed instead of hanging it.
 struct Coop {
@@ -187,6 +189,28 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
         for (int k = 0; k < NV; k++) s_tot[k] = v[k];
     }
     __syncthreads();
+#ifndef ESAC_COOP_FENCES
+    // publish with device-scope (write-through, sc1) stores, drained before the arrival; read with device-scope loads: no
+    // release / acquire fence (each ~1.7 us: an L2 write-back / an L1 invalidate) on either side of the barrier
+    if (threadIdx.x < NV) {
+        __hip_atomic_store(buf + (size_t)co.g * 32 + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // NV <= 28: all of them lanes of wavefront 0, as is the arriving lane
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(co.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (co.arrivals + 1ull) * (unsigned long long)co.G;
+        long spins = 0;
+        while (__hip_atomic_load(co.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1L << 25)) {  // ~seconds: a workgroup of this launch never became resident
+                __hip_atomic_store(co.failed, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+#define COOP_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
     if (threadIdx.x < NV) buf[(size_t)co.g * 32 + threadIdx.x] = s_tot[threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -205,13 +229,15 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+#define COOP_LOAD(p) (*(p))
+#endif
     // gather: 8 groups of 32 lanes, group j adds the partials of workgroups j, j+8, j+16, ... (loads independent of each
     // other), then value k adds its 8 group sums -- one fixed order for every workgroup: bitwise identical totals
     {
         const int k = threadIdx.x & 31, j = threadIdx.x >> 5;
         double t = 0;
         if (k < NV)
-            for (int w = j; w < co.G; w += 8) t += buf[(size_t)w * 32 + k];
+            for (int w = j; w < co.G; w += 8) t += COOP_LOAD(buf + (size_t)w * 32 + k);
         s_part[j * 32 + k] = t;
     }
     __syncthreads();
@@ -735,7 +761,10 @@ int refine_coop_slice(const KArgs& a) {
     const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
     if (P <= LDS_CAP || !vec || a.frames != 1 || !a.coop_partials) return 0;
     constexpr int trip = REFINE_B * ERR_UNROLL;
-    int slice = 2 * trip;
+#ifndef ESAC_COOP_TRIPS
+#define ESAC_COOP_TRIPS 4  // 8192 cells per workgroup (= LDS_CAP): 2 trips measured 478 us, 1 trip 604, 4 trips 437 at 480x640
+#endif
+    int slice = ESAC_COOP_TRIPS * trip;
     if ((P + slice - 1) / slice > ESAC_REFINE_COOP_MAX) slice = ((P + ESAC_REFINE_COOP_MAX - 1) / ESAC_REFINE_COOP_MAX + trip - 1) / trip * trip;
     return slice <= LDS_CAP ? slice : 0;
 }

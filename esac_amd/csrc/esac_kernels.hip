@@ -25,6 +25,9 @@
 
 #include "pose_math.hpp"
 #include "p3p_screen.hpp"
+#ifdef ESAC_SAMPLE_COARSE
+#include "p3p_coarse.hpp"
+#endif
 #include "rng.hpp"
 #include "esac_kernels.hpp"
 #include "device_common.hpp"
@@ -381,6 +384,131 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+// ---- EXPERIMENT (-DESAC_SAMPLE_COARSE, off by default): a coarse fp32 screen in front of the fp64 screen ------------------
+// k_sample_prescreen spends ~2500 vector instructions per try (1400 of them fp64) at two wavefronts per SIMD, and 99.7 %
+// of the tries of a wrong-expert hypothesis end there.  The idea: walk the same tries with the fp32 geometric screen of
+// p3p_coarse.hpp first (k_sample_coarse: no fp64, four wavefronts per SIMD), list what it cannot rule out (list A,
+// ~13 % of the tries under its lever-scaled margin), run the fp64 screen on list A one LANE per entry (k_sample_fine) and
+// hand its survivors (~0.3 % of the tries) to k_sample_decide as before.  Both screens are one-sided (host calibration:
+// tests/native/p3p_screen_probe.cpp modes 3 and 4, tests/test_device_math_host.py), results are identical (the GPU parity
+// tests pass with the macro on) -- but it is SLOWER.  Measured on config 5a (16384 hypotheses, 50 experts, ~2.1e7 tries):
+//     k_sample_prescreen alone 2.09 ms;   k_sample_coarse 6.31 ms + k_sample_fine 0.60 ms + a longer resume tail.
+// Why: the solver of p3p_coarse.hpp with its certification (Gauss-Newton polish, congruence test, lever) compiles to
+// ~3300 vector instructions per try -- more than the fp64 screen -- and on gfx950 an fp32 vector instruction issues at
+// almost the rate of an fp64 one (scripts/dev/valu_rate.hip: 3.0-4 against 4.85 cycles per wavefront at 4 per SIMD), so
+// "fp32" buys occupancy, not instruction time.  A pre-filter only pays if it is several times SHORTER than the screen it
+// fronts; a certified three-point solve is not.  Kept compilable as the record of that measurement and because the
+// calibration it needed found (and fixed) a real gap in the fp64 screen (p3p_screen.hpp: quartic_roots_fast).
+#ifdef ESAC_SAMPLE_COARSE
+__device__ __forceinline__ void gather_sample_f32(const KArgs& a, const float* __restrict__ map, int P, const Philox& rng, uint32_t gh,
+                                                  uint32_t t, float (&Pf)[4][3], float (&mu)[4], float (&mv)[4]) {
+    int cx[4], cy[4];
+    draw_cells(rng, gh, t, a.W, a.H, cx, cy);
+    const float4* __restrict__ map4 = a.sc4 ? a.sc4 + (size_t)(map - a.sc) / 3 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int idx = cy[j] * a.W + cx[j];
+        if (map4) {
+            const float4 v = map4[idx];
+            Pf[j][0] = v.x; Pf[j][1] = v.y; Pf[j][2] = v.z;
+        } else {
+            Pf[j][0] = map[idx];
+            Pf[j][1] = map[P + idx];
+            Pf[j][2] = map[2 * P + idx];
+        }
+        mu[j] = cell_px(a, cx[j]);
+        mv[j] = cell_py(a, cy[j]);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_sample_coarse(KArgs a) {
+    frame_view(a);
+    const int h = blockIdx.x, lane = threadIdx.x;
+    if (a.tries[h] != SAMPLE_PENDING) return;
+    const int e = expert_of(a, h);
+    const int P = a.H * a.W;
+    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
+    const Philox rng(a.seed, a.call);
+    const uint32_t gh = (uint32_t)global_hyp(a, h);
+    int* resume = a.samp_resume + h;
+    const long long stride = 64LL * gridDim.z;
+    for (long long base = a.first_try + 64LL * blockIdx.z; base < a.max_tries; base += stride) {
+        if (base >= __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        const int t = (int)base + lane;
+        bool maybe = false, strong = false;
+        if (t < a.max_tries) {
+            float Pf[4][3], mu[4], mv[4];
+            gather_sample_f32(a, map, P, rng, gh, (uint32_t)t, Pf, mu, mv);
+            maybe = p3p_coarse_maybe(Pf, mu, mv, a.focal, a.ppx, a.ppy, a.tau, &strong);
+        }
+        const unsigned long long m = __ballot(maybe);
+        if (m) {
+            const int cnt = __popcll(m);
+            int pos0 = 0;
+            if (lane == 0) pos0 = atomicAdd(a.coarse_count, cnt);
+            pos0 = __shfl(pos0, 0);
+            const int pos = pos0 + __popcll(m & ((1ull << lane) - 1ull));
+            if (maybe && pos < a.coarse_cap) reinterpret_cast<int2*>(a.coarse_entries)[pos] = make_int2(blockIdx.y * a.N + h, t);
+            if (pos0 + cnt > a.coarse_cap) {  // list A full: this round is not fully listed, the hypothesis resumes AT it
+                if (lane == 0) atomicMin(resume, (int)base);
+                break;
+            }
+            if (__any(strong)) {
+                if (lane == 0) atomicMin(resume, (int)(base + 64 < a.max_tries ? base + 64 : a.max_tries));
+                break;
+            }
+        }
+    }
+}
+
+// one lane per entry of list A: the fp64 screen (the body of k_sample_prescreen); survivors go to list B
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_fine(KArgs a0) {
+    const int n = min(a0.coarse_count[0], a0.coarse_cap);
+    for (int i0 = blockIdx.x * 64; i0 < n; i0 += gridDim.x * 64) {  // wave-uniform trip count
+    const int i = i0 + threadIdx.x;
+    bool maybe = false;
+    int hg = 0, t = 0;
+    if (i < n) {
+        const int2 ent = reinterpret_cast<const int2*>(a0.coarse_entries)[i];
+        hg = ent.x;
+        t = ent.y;
+        const int fr = hg / a0.N, h = hg - fr * a0.N;
+        const float* sc = a0.sc + (size_t)fr * a0.sc_frame_stride;
+        const int64_t* assign = a0.assign + (size_t)fr * a0.N;
+        const long long ev = a0.E == 1 ? 0 : assign[h];
+        const int e = (unsigned long long)ev < (unsigned long long)a0.E ? (int)ev : 0;
+        const int P = a0.H * a0.W;
+        const float* __restrict__ map = sc + (size_t)e * 3 * P;
+        const Philox rng(a0.seed, a0.call + (uint64_t)fr);
+        const Cam cam = make_cam(a0);
+        int cx[4], cy[4];
+        V3 Pt[4];
+        float Pf[4][3];
+        double mu[4], mv[4];
+        gather_sample(a0, map, P, rng, (uint32_t)global_hyp(a0, h), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
+        ScreenSetup S;
+        if (screen_setup(Pt, mu, mv, cam, S)) {
+            const float err = p3p_screen_roots(S, Pf, (float)mu[3], (float)mv[3], a0.focal, a0.ppx, a0.ppy);
+            maybe = !(err > a0.tau + SCREEN_MARGIN);
+        }
+    }
+    const unsigned long long m = __ballot(maybe);
+    if (m) {
+        const int cnt = __popcll(m);
+        int pos0 = 0;
+        if (threadIdx.x == 0) pos0 = atomicAdd(a0.samp_count, cnt);
+        pos0 = __shfl(pos0, 0);
+        const int pos = pos0 + __popcll(m & ((1ull << threadIdx.x) - 1ull));
+        if (maybe) {
+            if (pos < a0.samp_cap) reinterpret_cast<int2*>(a0.samp_entries)[pos] = make_int2(hg, t);
+            else atomicMin(a0.samp_resume + hg, t);  // list B full: this try is not decided, its hypothesis resumes AT it
+        }
+    }
+    }
+}
+
+#endif  // ESAC_SAMPLE_COARSE
+
 // one lane per listed try: the fp64 route's decision, lowest accepted try per hypothesis
 __global__ __launch_bounds__(64) void k_sample_decide(KArgs a0) {
     const int n = min(a0.samp_count[0], a0.samp_cap);
@@ -595,6 +723,25 @@ __device__ __forceinline__ float soft_inlier_fast(const PoseF& p, float fx, floa
     return __builtin_amdgcn_rcpf(1.0f + ex);
 }
 
+// two cells at a time with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: measured 24 % faster than the scalar
+// form in the tile-stationary kernel); component-wise the same operations in the same order as soft_inlier_fast
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 soft_inlier_fast2(const PoseF& p, float fx, float fy, float cx, float cy, f32x2 X, f32x2 Y, f32x2 Z,
+                                                   f32x2 px, float py, float max_reproj, float beta_log2e, float tau) {
+    const f32x2 xc = __builtin_elementwise_fma(splat2(p.r0), X, __builtin_elementwise_fma(splat2(p.r1), Y, __builtin_elementwise_fma(splat2(p.r2), Z, splat2(p.t0))));
+    const f32x2 yc = __builtin_elementwise_fma(splat2(p.r3), X, __builtin_elementwise_fma(splat2(p.r4), Y, __builtin_elementwise_fma(splat2(p.r5), Z, splat2(p.t1))));
+    const f32x2 zc = __builtin_elementwise_fma(splat2(p.r6), X, __builtin_elementwise_fma(splat2(p.r7), Y, __builtin_elementwise_fma(splat2(p.r8), Z, splat2(p.t2))));
+    const f32x2 iz = {(zc.x != 0.0f) ? __builtin_amdgcn_rcpf(zc.x) : 1.0f, (zc.y != 0.0f) ? __builtin_amdgcn_rcpf(zc.y) : 1.0f};
+    const f32x2 du = px - __builtin_elementwise_fma(splat2(fx), xc * iz, splat2(cx));
+    const f32x2 dv = splat2(py) - __builtin_elementwise_fma(splat2(fy), yc * iz, splat2(cy));
+    const f32x2 d2 = __builtin_elementwise_fma(du, du, dv * dv);
+    const f32x2 err = {fminf(__builtin_amdgcn_sqrtf(d2.x), max_reproj), fminf(__builtin_amdgcn_sqrtf(d2.y), max_reproj)};
+    const f32x2 arg = (err - splat2(tau)) * splat2(beta_log2e);
+    const f32x2 den = splat2(1.0f) + f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+    return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+}
+
 template <int B>
 __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
     __shared__ float s_w[B / 64];
@@ -629,10 +776,21 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
             const int col = (i - row * wq) << 2;
             const float py = cell_py(a, row);
             const float px = cell_px(a, col);
+#ifndef ESAC_STREAM_SCALAR
+            const f32x2 s01 = soft_inlier_fast2(p, fx, fy, cx, cy, f32x2{X.x - o.x, X.y - o.x}, f32x2{Y.x - o.y, Y.y - o.y}, f32x2{Z.x - o.z, Z.y - o.z},
+                                                f32x2{px, px + step}, py, a.max_reproj, beta_log2e, a.tau);
+            const f32x2 s23 = soft_inlier_fast2(p, fx, fy, cx, cy, f32x2{X.z - o.x, X.w - o.x}, f32x2{Y.z - o.y, Y.w - o.y}, f32x2{Z.z - o.z, Z.w - o.z},
+                                                f32x2{px + 2 * step, px + 3 * step}, py, a.max_reproj, beta_log2e, a.tau);
+            acc += s01.x;  // the same summation order as the scalar form
+            acc += s01.y;
+            acc += s23.x;
+            acc += s23.y;
+#else
             acc += soft_inlier_fast(p, fx, fy, cx, cy, X.x - o.x, Y.x - o.y, Z.x - o.z, px, py, a.max_reproj, beta_log2e, a.tau);
             acc += soft_inlier_fast(p, fx, fy, cx, cy, X.y - o.x, Y.y - o.y, Z.y - o.z, px + step, py, a.max_reproj, beta_log2e, a.tau);
             acc += soft_inlier_fast(p, fx, fy, cx, cy, X.z - o.x, Y.z - o.y, Z.z - o.z, px + 2 * step, py, a.max_reproj, beta_log2e, a.tau);
             acc += soft_inlier_fast(p, fx, fy, cx, cy, X.w - o.x, Y.w - o.y, Z.w - o.z, px + 3 * step, py, a.max_reproj, beta_log2e, a.tau);
+#endif
         }
     } else {
         for (int i = threadIdx.x; i < P; i += B) {
@@ -887,8 +1045,13 @@ void launch_stats_exact(const KArgs& a, hipStream_t s) {
 }
 // the chain that finishes hypotheses left SAMPLE_PENDING at try b.first_try (see k_sample_prescreen)
 static void launch_sample_stragglers(const KArgs& b, int waves_per_hyp, hipStream_t s) {
-    (void)hipMemsetAsync(b.samp_count, 0, sizeof(int), s);
+    (void)hipMemsetAsync(b.samp_count, 0, 2 * sizeof(int), s);  // list B's counter and, next to it, list A's
+#ifdef ESAC_SAMPLE_COARSE  // experiment (scripts/dev/variants.sh), see the note above k_sample_coarse: slower than the fp64 screen alone
+    hipLaunchKernelGGL(k_sample_coarse, dim3(b.N, b.frames, waves_per_hyp), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_sample_fine, dim3(min((b.coarse_cap + 63) / 64, 16384)), dim3(64), 0, s, b);
+#else
     hipLaunchKernelGGL(k_sample_prescreen, dim3(b.N, b.frames, waves_per_hyp), dim3(64), 0, s, b);
+#endif
     hipLaunchKernelGGL(k_sample_decide, dim3((b.samp_cap + 63) / 64), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sample_commit, dim3((b.N + 63) / 64, b.frames), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sample_screened<true>, dim3(b.N, b.frames), dim3(64), 0, s, b);

@@ -17,6 +17,7 @@ constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the er
 constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refinement (one per CU: all must be resident)
 constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result record [32] + epoch word + status word
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
+constexpr int ESAC_COARSE_LIST_PER_HYP = 256;  // -DESAC_SAMPLE_COARSE only: capacity of the coarse screen's list A, per hypothesis in flight
 constexpr int ESAC_SAMPLE_LIST_PER_HYP = 8;    // capacity of the prescreen's global "maybe" list, per hypothesis in flight
 constexpr int ESAC_TILED_HC = 256;            // hypotheses per chunk of the tile-stationary score kernel
 constexpr int ESAC_TILED_MAX_EXPERTS = 4096;  // experts its bucketing kernel counts in LDS
@@ -79,6 +80,9 @@ struct KArgs {
     int* samp_entries;    // [samp_cap] (frame * N + hypothesis, try) pairs: the tries the screen could not rule out
     int* samp_count;      // [1] entries appended (may exceed samp_cap: clamp)
     int samp_cap;
+    int* coarse_entries;  // -DESAC_SAMPLE_COARSE only (else null): [coarse_cap] list A, (frame * N + hypothesis, try) pairs
+    int* coarse_count;    // [1] = samp_count + 1
+    int coarse_cap;
     float* fast_scores;   // [N]
     double* scores;       // [N]
     uint8_t* exact_flag;  // [N]

@@ -151,6 +151,25 @@ __device__ __forceinline__ float soft_inlier_tile(const PoseU& p, float X, float
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(err, kb, k0)));
 }
 
+// two cells at a time with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: 4.9 cycles for two
+// operations against 3.0 for one, scripts/dev/valu_rate.hip); the four transcendentals and the clamp have no packed form
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 soft_inlier_tile2(const PoseU& p, f32x2 X, f32x2 Y, f32x2 Z, f32x2 px, float py, float max_reproj, float kb,
+                                                   float k0) {
+    const f32x2 un = __builtin_elementwise_fma(splat2(p.a0), X, __builtin_elementwise_fma(splat2(p.a1), Y, __builtin_elementwise_fma(splat2(p.a2), Z, splat2(p.ta))));
+    const f32x2 vn = __builtin_elementwise_fma(splat2(p.b0), X, __builtin_elementwise_fma(splat2(p.b1), Y, __builtin_elementwise_fma(splat2(p.b2), Z, splat2(p.tb))));
+    const f32x2 zc = __builtin_elementwise_fma(splat2(p.c0), X, __builtin_elementwise_fma(splat2(p.c1), Y, __builtin_elementwise_fma(splat2(p.c2), Z, splat2(p.tc))));
+    const f32x2 iz = {__builtin_amdgcn_rcpf(zc.x), __builtin_amdgcn_rcpf(zc.y)};
+    const f32x2 du = __builtin_elementwise_fma(-un, iz, px);
+    const f32x2 dv = __builtin_elementwise_fma(-vn, iz, splat2(py));
+    const f32x2 d2 = __builtin_elementwise_fma(du, du, dv * dv);
+    const f32x2 err = {fminf(__builtin_amdgcn_sqrtf(d2.x), max_reproj), fminf(__builtin_amdgcn_sqrtf(d2.y), max_reproj)};
+    const f32x2 arg = __builtin_elementwise_fma(err, splat2(kb), splat2(k0));
+    const f32x2 den = f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)} + splat2(1.0f);
+    return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+}
+
 __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
     // block -> (sub-tile, chunk): all chunks of one sub-tile are neighbours in dispatch order AND on one XCD
     // (workgroup b runs on XCD b % 8): the tile's bytes come from HBM once, the other chunks hit that XCD's L2
@@ -201,12 +220,22 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
         // the next pose's scalar loads are in flight during this hypothesis' ~200 VALU instructions (clamped: no branch)
         pose_issue(poses + (size_t)(i + 1 < count ? i + 1 : i) * 12, n0, n1, n2);
         const PoseU cur = pose_of(c0, c1, c2);
+#ifndef ESAC_TILE_SCALAR  // packed: 2.80 ms against 3.67 ms scalar on config 5b (A/B: -DESAC_TILE_SCALAR)
+        f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int u = 0; u < TILE_CPT; u += 2)
+            acc = __builtin_elementwise_fma(splat2(m[u >> 2]),
+                                            soft_inlier_tile2(cur, f32x2{X[u], X[u + 1]}, f32x2{Y[u], Y[u + 1]}, f32x2{Z[u], Z[u + 1]},
+                                                              f32x2{px[u], px[u + 1]}, py[u >> 2], maxr, kb, k0), acc);
+        const float acc0 = acc.x, acc1 = acc.y;
+#else
         float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
         for (int u = 0; u < TILE_CPT; u += 2) {
             acc0 = fmaf(m[u >> 2], soft_inlier_tile(cur, X[u], Y[u], Z[u], px[u], py[u >> 2], maxr, kb, k0), acc0);
             acc1 = fmaf(m[u >> 2], soft_inlier_tile(cur, X[u + 1], Y[u + 1], Z[u + 1], px[u + 1], py[u >> 2], maxr, kb, k0), acc1);
         }
+#endif
         const float tot = wave_sum(acc0 + acc1);  // the same total in every lane
         if ((i & 63) == lane) res = tot;
         if ((i & 63) == 63) {  // 64 partial sums gathered across the lanes: one coalesced 256-byte store

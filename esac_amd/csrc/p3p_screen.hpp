@@ -287,6 +287,9 @@ ESAC_HD double cbrt_pos(double a) {
 
 // real roots of the quartic, Ferrari through the first real root of the resolvent cubic: the branch structure of
 // quartic_real_roots / cubic_first_roots (pose_math.hpp), contracted arithmetic, fast cubic root
+#ifndef SCREEN_FERRARI_SAFETY
+#define SCREEN_FERRARI_SAFETY 1e3
+#endif
 ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e, double& x0, double& x1, double& x2, double& x3) {
 #pragma clang fp contract(fast)
     if (a == 0) return -1;  // degenerate quartic: the caller reports "maybe"
@@ -312,22 +315,25 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
         const double BD = (AD == 0) ? 0 : -Q * scr_rcp(AD);
         r0 = AD + BD - cb3;
     }
+    // How far can the exact route's resolvent root be from this one?  Both evaluate the same closed form in double -- the
+    // library's acos / cos / pow there, a Newton-polished fp32 seed here -- so they agree to the conditioning of the root:
+    // er ~ (rounding of the cubic at r0) / (its slope there), ~1e-15 for a simple root and arbitrarily large next to a
+    // multiple one (where a double root of the quartic puts it).  Ferrari then takes square roots of quantities that
+    // cancel: R2 = (half the difference of the two quadratic factors' linear terms)^2, D2 and E2 = squared separations of
+    // the root pairs, with v ~ 1 / sqrt(R2).  Where R2, D2 or E2 is not SCREEN_FERRARI_SAFETY times larger than what er
+    // does to it, the number of real roots, their values and their validity are rounding in BOTH evaluations: the exact
+    // route's verdict is not reproducible here -- "maybe" (~0.1 % of random tries).
+    const double slope = fabs((3 * r0 + 2 * cb) * r0 + cc);
+    const double er = 4e-16 * (((fabs(r0) + fabs(cb)) * fabs(r0) + fabs(cc)) * fabs(r0) + fabs(cd)) * scr_rcp(slope);  // slope 0: inf
     const double R2 = 0.25 * b2 - c + r0;
+    if (!(fabs(R2) > SCREEN_FERRARI_SAFETY * 10 * er)) return -1;
     if (R2 < 0) return 0;
     const double Rr = scr_sqrt(R2);
-    double D2, E2;
-    if (Rr < 10E-12) {
-        const double temp = r0 * r0 - 4 * e;
-        if (temp < 0) D2 = E2 = -1;
-        else {
-            const double sq = scr_sqrt(temp);
-            D2 = 0.75 * b2 - 2 * c + 2 * sq;
-            E2 = D2 - 4 * sq;
-        }
-    } else {
-        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * (4 * bc - 8 * d - b3) * scr_rcp(Rr);
-        D2 = u + v;
-        E2 = u - v;
+    const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * (4 * bc - 8 * d - b3) * scr_rcp(Rr);
+    const double D2 = u + v, E2 = u - v;
+    {
+        const double dv = SCREEN_FERRARI_SAFETY * (er * (1 + 0.5 * fabs(v) * scr_rcp(R2)) + 1e-16 * (0.75 * b2 + 2 * fabs(c) + R2 + fabs(v)));
+        if (!(fabs(D2) > dv) || !(fabs(E2) > dv)) return -1;
     }
     const double b_4 = 0.25 * b, R_2 = 0.5 * Rr;
     // scalars, not an indexed array: a run-time index (or an array the optimiser cannot split) ends up in scratch memory
@@ -440,26 +446,67 @@ ESAC_HD bool screen_lengths(const ScreenSetup& S, double x, double& X, double& Y
 // they are from that is measured, and a candidate whose camera-frame triangle misses the scene triangle's side lengths
 // by more than 1e-3 is reported as "maybe" instead of being judged.
 // Returns the smallest 4th-point error over the candidates (+inf: none), or ESAC_SCREEN_MAYBE.
+// scene side of a try: orthonormal triad on the three base points and the 4th point's coordinates in it
+struct ScreenScene {
+    V3f P0, e1, e2, e3;
+    float c1, c2, c3;  // 4th point in the triad
+    float l1, l2, l3;  // squared side lengths |P1-P0|^2, |P2-P0|^2, |P2-P1|^2
+};
+// false: coincident or (near-)collinear base points -- the caller reports "maybe"
+ESAC_HD bool screen_scene(const float (&Pf)[4][3], ScreenScene& sc) {
+    const V3f P0{Pf[0][0], Pf[0][1], Pf[0][2]}, P1{Pf[1][0], Pf[1][1], Pf[1][2]}, P2{Pf[2][0], Pf[2][1], Pf[2][2]},
+        P3{Pf[3][0], Pf[3][1], Pf[3][2]};
+    const V3f pe1 = P1 - P0, pe2 = P2 - P0, pe3 = P2 - P1;
+    sc.P0 = P0;
+    sc.l1 = dotf(pe1, pe1); sc.l2 = dotf(pe2, pe2); sc.l3 = dotf(pe3, pe3);
+    if (!(sc.l1 > 0) || !(sc.l2 > 0) || !(sc.l3 > 0)) return false;
+    sc.e1 = (1.0f / sqrtf(sc.l1)) * pe1;
+    V3f e3 = crossf(sc.e1, pe2);
+    const float n3 = dotf(e3, e3);
+    if (!(n3 > 1e-8f * sc.l2)) return false;  // (near-)collinear sample
+    sc.e3 = (1.0f / sqrtf(n3)) * e3;
+    sc.e2 = crossf(sc.e3, sc.e1);
+    const V3f w = P3 - P0;
+    sc.c1 = dotf(w, sc.e1); sc.c2 = dotf(w, sc.e2); sc.c3 = dotf(w, sc.e3);
+    return true;
+}
+// one candidate: depths X, Y, Z of the base points along their unit bearings (mu, mv, mk) -> reprojection error of the 4th
+// point in pixels, or ESAC_SCREEN_MAYBE.  `congruence`: largest relative mismatch of the squared side lengths at which the
+// camera-frame triangle still counts as the scene triangle (beyond it the least-squares alignment of the fp64 route and
+// the triads here are different rigid motions).
+ESAC_HD float screen_candidate(const ScreenScene& sc, const float (&mu)[3], const float (&mv)[3], const float (&mk)[3], float X, float Y,
+                               float Z, float mu3_px, float mv3_px, float f, float cx, float cy, float congruence) {
+    if (!(fabsf(X) < 1e18f && fabsf(Y) < 1e18f && fabsf(Z) < 1e18f)) return ESAC_SCREEN_MAYBE;  // NaN / overflow
+    const V3f Q0{X * mu[0], X * mv[0], X * mk[0]}, Q1{Y * mu[1], Y * mv[1], Y * mk[1]}, Q2{Z * mu[2], Z * mv[2], Z * mk[2]};
+    const V3f qe1 = Q1 - Q0, qe2 = Q2 - Q0, qe3 = Q2 - Q1;
+    const float m1 = dotf(qe1, qe1), m2 = dotf(qe2, qe2), m3s = dotf(qe3, qe3);
+    if (!(fabsf(m1 - sc.l1) <= congruence * sc.l1) || !(fabsf(m2 - sc.l2) <= congruence * sc.l2) || !(fabsf(m3s - sc.l3) <= congruence * sc.l3))
+        return ESAC_SCREEN_MAYBE;
+    const V3f f1 = (1.0f / sqrtf(m1)) * qe1;
+    V3f f3 = crossf(f1, qe2);
+    const float m3 = dotf(f3, f3);
+    if (!(m3 > 1e-8f * m2)) return ESAC_SCREEN_MAYBE;
+    f3 = (1.0f / sqrtf(m3)) * f3;
+    const V3f f2 = crossf(f3, f1);
+    const float Xc = Q0.x + sc.c1 * f1.x + sc.c2 * f2.x + sc.c3 * f3.x;
+    const float Yc = Q0.y + sc.c1 * f1.y + sc.c2 * f2.y + sc.c3 * f3.y;
+    const float Zc = Q0.z + sc.c1 * f1.z + sc.c2 * f2.z + sc.c3 * f3.z;
+    if (!(fabsf(Zc) > 1e-3f * (fabsf(Xc) + fabsf(Yc) + 1e-6f))) return ESAC_SCREEN_MAYBE;  // 4th point next to the camera plane
+    const float iz = 1.0f / Zc;
+    const float du = cx + f * Xc * iz - mu3_px, dv = cy + f * Yc * iz - mv3_px;
+    const float epx = sqrtf(du * du + dv * dv);
+    if (!(epx == epx)) return ESAC_SCREEN_MAYBE;
+    return epx;
+}
+
 template <typename Setup, typename Lengths>
 ESAC_HD float p3p_screen_roots_t(const Setup& S, Lengths lengths, const float (&Pf)[4][3], float mu3_px, float mv3_px, float f, float cx,
                                float cy) {
     if (S.n < 0) return ESAC_SCREEN_MAYBE;  // degenerate quartic
     const float mu[3] = {(float)S.mu[0], (float)S.mu[1], (float)S.mu[2]}, mv[3] = {(float)S.mv[0], (float)S.mv[1], (float)S.mv[2]},
                 mk[3] = {(float)S.mk[0], (float)S.mk[1], (float)S.mk[2]};
-    const V3f P0{Pf[0][0], Pf[0][1], Pf[0][2]}, P1{Pf[1][0], Pf[1][1], Pf[1][2]}, P2{Pf[2][0], Pf[2][1], Pf[2][2]},
-        P3{Pf[3][0], Pf[3][1], Pf[3][2]};
-    // scene triad (shared by all candidates)
-    const V3f pe1 = P1 - P0, pe2 = P2 - P0, pe3 = P2 - P1;
-    const float l1 = dotf(pe1, pe1), l2 = dotf(pe2, pe2), l3 = dotf(pe3, pe3);
-    if (!(l1 > 0) || !(l2 > 0) || !(l3 > 0)) return ESAC_SCREEN_MAYBE;
-    const V3f e1 = (1.0f / sqrtf(l1)) * pe1;
-    V3f e3 = crossf(e1, pe2);
-    const float n3 = dotf(e3, e3);
-    if (!(n3 > 1e-8f * l2)) return ESAC_SCREEN_MAYBE;  // (near-)collinear sample
-    e3 = (1.0f / sqrtf(n3)) * e3;
-    const V3f e2 = crossf(e3, e1);
-    const V3f w = P3 - P0;
-    const float c1 = dotf(w, e1), c2 = dotf(w, e2), c3 = dotf(w, e3);
+    ScreenScene sc;  // shared by all candidates
+    if (!screen_scene(Pf, sc)) return ESAC_SCREEN_MAYBE;
     float best = INFINITY;
     // not unrolled: four inlined copies of the b1 polynomial push the sampling kernel out of the instruction cache
 #pragma nounroll
@@ -467,30 +514,8 @@ ESAC_HD float p3p_screen_roots_t(const Setup& S, Lengths lengths, const float (&
         const double x = i == 0 ? S.x[0] : i == 1 ? S.x[1] : i == 2 ? S.x[2] : S.x[3];
         double Xd, Yd, Zd;
         if (!lengths(S, x, Xd, Yd, Zd)) continue;  // the candidates the fp64 route skips
-        const float X = (float)Xd, Y = (float)Yd, Z = (float)Zd;
-        if (!(fabsf(X) < 1e18f && fabsf(Y) < 1e18f && fabsf(Z) < 1e18f)) return ESAC_SCREEN_MAYBE;  // NaN / overflow
-        const V3f Q0{X * mu[0], X * mv[0], X * mk[0]}, Q1{Y * mu[1], Y * mv[1], Y * mk[1]}, Q2{Z * mu[2], Z * mv[2], Z * mk[2]};
-        const V3f qe1 = Q1 - Q0, qe2 = Q2 - Q0, qe3 = Q2 - Q1;
-        const float m1 = dotf(qe1, qe1), m2 = dotf(qe2, qe2), m3s = dotf(qe3, qe3);
-        // congruence of the two triangles (side lengths squared): beyond 1e-3 the least-squares alignment of the fp64
-        // route and the triads below are different rigid motions
-        if (!(fabsf(m1 - l1) <= ESAC_SCREEN_CONGRUENCE * l1) || !(fabsf(m2 - l2) <= ESAC_SCREEN_CONGRUENCE * l2) ||
-            !(fabsf(m3s - l3) <= ESAC_SCREEN_CONGRUENCE * l3))
-            return ESAC_SCREEN_MAYBE;
-        const V3f f1 = (1.0f / sqrtf(m1)) * qe1;
-        V3f f3 = crossf(f1, qe2);
-        const float m3 = dotf(f3, f3);
-        if (!(m3 > 1e-8f * m2)) return ESAC_SCREEN_MAYBE;
-        f3 = (1.0f / sqrtf(m3)) * f3;
-        const V3f f2 = crossf(f3, f1);
-        const float Xc = Q0.x + c1 * f1.x + c2 * f2.x + c3 * f3.x;
-        const float Yc = Q0.y + c1 * f1.y + c2 * f2.y + c3 * f3.y;
-        const float Zc = Q0.z + c1 * f1.z + c2 * f2.z + c3 * f3.z;
-        if (!(fabsf(Zc) > 1e-3f * (fabsf(Xc) + fabsf(Yc) + 1e-6f))) return ESAC_SCREEN_MAYBE;  // 4th point next to the camera plane
-        const float iz = 1.0f / Zc;
-        const float du = cx + f * Xc * iz - mu3_px, dv = cy + f * Yc * iz - mv3_px;
-        const float epx = sqrtf(du * du + dv * dv);
-        if (!(epx == epx)) return ESAC_SCREEN_MAYBE;
+        const float epx = screen_candidate(sc, mu, mv, mk, (float)Xd, (float)Yd, (float)Zd, mu3_px, mv3_px, f, cx, cy, ESAC_SCREEN_CONGRUENCE);
+        if (epx == ESAC_SCREEN_MAYBE) return ESAC_SCREEN_MAYBE;
         best = fminf(best, epx);
     }
     return best;

@@ -378,26 +378,31 @@ def main():
                         traffic = float(sum(fb) + sum(wb))
                     rp_ms = srow["rocprofv3_avg_us"] * 1e-3 if srow.get("rocprofv3_avg_us") else None
             cache_resident = 12.0 * H * W * E <= 4 * 2**20
+            quoted_ms = max(score_ms, rp_ms) if rp_ms else score_ms
+            achieved_q = alg_bytes / (quoted_ms * 1e-3) / 1e9
             out["roofline"] = {
                 "kernel": "score stage (%s)" % ("k_bucket + k_score_tiled + k_score_tiled_reduce" if H * W >= 32768 and n_total >= 64 and W % 4 == 0
                                                 else "k_score_fast"),
                 "bound": "hbm" if not cache_resident else "hbm (nominal: the maps are L2-resident at this grid, the launch is latency/VALU-bound)",
-                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                # the live HIP-event figure and the committed rocprofv3 average of the same kernel differ by a dispatch / drain
+                # share (back-to-back launches hide part of it): `frac` is quoted on the LONGER of the two durations
+                "achieved": achieved_q, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_q / HBM_PEAK_GBPS,
+                "achieved_live": achieved, "frac_live": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": prof["file"] if prof and traffic is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": score_ms,
                 "kernel_ms_source": "HIP events on the launch stream around %d back-to-back launches of the stage, mean over the %d cycled frames "
                                     "(includes ~1.5 us of dependent-kernel boundary per launch)" % (reps, n_frames),
                 "rocprofv3_kernel_ms": rp_ms,
                 "frac_at_rocprofv3_duration": alg_bytes / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if rp_ms else None,
-                "frac_of_l2_peak": achieved / L2_PEAK_GBPS,
-                "cache_served": achieved > HBM_PEAK_GBPS,
-                # what actually limits the kernel: fp32 VALU issue (21 instructions per cell, 4 of them transcendental)
-                "valu": {"bound": "fp32 vector", "achieved": n_total * float(H * W) * SCORE_FLOPS_PER_CELL / (score_ms * 1e-3) / 1e12,
+                "frac_of_l2_peak": achieved_q / L2_PEAK_GBPS,
+                "cache_served": achieved_q > HBM_PEAK_GBPS,
+                # what actually limits the kernel: fp32 VALU issue (per cell ~13 vector instructions, packed two cells wide, + 4 transcendentals)
+                "valu": {"bound": "fp32 vector", "achieved": n_total * float(H * W) * SCORE_FLOPS_PER_CELL / (quoted_ms * 1e-3) / 1e12,
                          "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": n_total * float(H * W) * SCORE_FLOPS_PER_CELL / (score_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
+                         "frac": n_total * float(H * W) * SCORE_FLOPS_PER_CELL / (quoted_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                          "flops_per_cell": SCORE_FLOPS_PER_CELL,
                          "frac_of_issue_bound_rocprofv3": (srow.get("rocprofv3") or [{}])[0].get("frac_of_issue_bound") if prof else None},
-                "hbm_physical_frac": (traffic / (score_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                "hbm_physical_frac": (traffic / (quoted_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
                 "note": "algorithmic bytes = every hypothesis reads x,y,z of its expert's map once (12*H*W, SURVEY 8d); `traffic` is what reached "
                         "the fabric.  A fraction above 1 (`cache_served`) means the re-reads never leave L2 / the registers of the tile-"
                         "stationary kernel -- by design; the limiter is then VALU issue, see `valu` and DESIGN.md section 5",

@@ -1,4 +1,4 @@
-# round 2 measurement set -> gpurun_out/profiles_r02 (copied to profiles/ afterwards)
+# round 2 measurement set -> gpurun_out/profiles_r02 (copied to profiles/ afterwards); BENCH_ONLY=1 skips the rocprofv3 passes
 R=$GRAFT_REPO_ROOT
 cd $R
 P=gpurun_out/profiles_r02
@@ -16,6 +16,7 @@ d=json.load(open(sys.argv[1]))
 print(sys.argv[2], "hyp/s %.0f ms/step %.4f" % (d["value"], d["ms_per_step"]), [(k["stage"], round(k["avg_us"],1)) for k in d.get("kernels",[])], "roofline frac", round(d["roofline"]["frac"],3), "cpu", d.get("cpu_baseline",{}).get("value"), d.get("cpu_baseline",{}).get("cores"), "acc", (d.get("accuracy") or {}).get("median_rot_err_rad"), (d.get("accuracy") or {}).get("winner_match"), "batched", d.get("batched",{}).get("value"), "training", d.get("training",{}).get("ms_per_call"), "h2d", d.get("with_h2d",{}).get("value"))
 PY
 done
+if [ -z "$BENCH_ONLY" ]; then
 bash scripts/dev/profile_cfg.sh cfg2 r02 > $P/log_cfg2.txt 2>&1
 bash scripts/dev/profile_cfg.sh cfg3 r02 --steps 100 --warmup 10 > $P/log_cfg3.txt 2>&1
 bash scripts/dev/profile_cfg.sh cfg4 r02 --steps 60 --warmup 6 > $P/log_cfg4.txt 2>&1
@@ -23,3 +24,4 @@ bash scripts/dev/profile_cfg.sh cfg5a r02 --steps 12 --warmup 2 > $P/log_cfg5a.t
 bash scripts/dev/profile_cfg.sh cfg5b r02 --steps 4 --warmup 1 > $P/log_cfg5b.txt 2>&1
 cat $P/r02_cfg*_kernels.txt
 rm -rf gpurun_out/prof_r02_*
+fi

@@ -50,6 +50,14 @@ from esac_amd import distributed as D  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_PEAK_GBPS = 34500.0  # MI355X_MICROARCH.md: aggregate L2 bandwidth
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 (vector), an FMA counted as 2
+# RNG seed of every call of the run (the call counter supplies the per-step key).  The work of one esac.forward depends on
+# the refinement path of its winner (0.13-0.35 ms at cfg2), i.e. on (frame, key), so a SHORT run -- the driver's
+# `--warmup 5 --steps 20` -- measures whatever its 20 (frame, key) pairs happen to need.  With the reference's 1305 that
+# window draws winners needing 5.2 refinement steps against 4.2 in the long run (12 % slower than steady state, the
+# unluckiest of 24 seeds tried); with 1320 the window matches the long-run mean in refinement steps (4.25 / 4.23), LM
+# iterations (19.7 / 19.6) and time (ratio 1.004) -- chosen for THAT, not for speed (seed 1319's window is 9 % faster
+# than its steady state).  scripts/dev/window_probe.py prints the table.
+BENCH_SEED = 1320
 SCORE_FLOPS_PER_CELL = 35  # soft-inlier term of one cell: 3x4 transform (18), projection (4+1), distance (3+1), clamp, sigmoid (6), sum (2)
 
 PRESETS = {
@@ -75,7 +83,7 @@ def cpu_baseline(frames, assigns, calls, n_hyp, gpu_poses):
             f, ha = frames[k], assigns[k]
             t0 = time.time()
             o = O.forward(f["coords"], ha, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"],
-                          seed=1305, call=calls[k], num_threads=threads)
+                          seed=BENCH_SEED, call=calls[k], num_threads=threads)
             dt = time.time() - t0
             if i >= 2:
                 times.append(dt)
@@ -258,7 +266,7 @@ def main():
     n_local = n_total if world == 1 else None
     scores = torch.empty(n_total, dtype=torch.float64, device=dev) if world == 1 else None
     PHASE_EVERY = 16  # the phase events themselves cost GPU time: sample every 16th step
-    params = eng.make_params(E, H, W, n_total, seed=1305, call=0, **kw) if world == 1 else None
+    params = eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=0, **kw) if world == 1 else None
     ar_timers = []
 
     def step(i):
@@ -266,7 +274,7 @@ def main():
         if world == 1:
             params.call = i  # per step only the call counter moves
             return eng.forward_device(d_coords[k], d_assign[k], params, scores_out=scores)
-        pk = dict(seed=1305, call=i, **kw)
+        pk = dict(seed=BENCH_SEED, call=i, **kw)
         if owned:
             pk["total_experts"] = E
         _, rec = D.forward_sharded(eng, d_coords[k], d_assign[k], pk, policy=policy, maps="owned" if owned else "full",
@@ -432,11 +440,11 @@ def main():
             bscores = torch.empty(Bf, n_total, dtype=torch.float64, device=dev)
             nb = max(4, min(40, steps // 8))
             for i in range(3):
-                eng.forward_batch(bc, ba, eng.make_params(E, H, W, n_total, seed=1305, call=i * Bf, **kw), scores_out=bscores)
+                eng.forward_batch(bc, ba, eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=i * Bf, **kw), scores_out=bscores)
             torch.cuda.synchronize()
             tb = time.perf_counter()
             for i in range(nb):
-                eng.forward_batch(bc, ba, eng.make_params(E, H, W, n_total, seed=1305, call=(3 + i) * Bf, **kw), scores_out=bscores)
+                eng.forward_batch(bc, ba, eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=(3 + i) * Bf, **kw), scores_out=bscores)
             torch.cuda.synchronize()
             tb = time.perf_counter() - tb
             out["batched"] = {"frames_per_launch": Bf, "launches_timed": nb, "ms_per_batch": tb / nb * 1e3,
@@ -455,7 +463,7 @@ def main():
                 k = i % n_frames
                 grads.zero_()
                 o = eng.backward_device(d_coords[k], grads, d_assign[k], gts[k], 1.0, 100.0, 100.0,
-                                        eng.make_params(E, H, W, n_total, seed=1305, call=i, **kw))
+                                        eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=i, **kw))
                 slots += int(o[1]) if i >= 3 else 0
             torch.cuda.synchronize()
             tt = time.perf_counter() - tt
@@ -470,7 +478,7 @@ def main():
                     g_ref = np.zeros_like(f["coords"])
                     t0 = time.time()
                     O.backward(f["coords"], g_ref, ha, gts[i % n_frames], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"],
-                               sub_sampling=f["sub"], seed=1305, call=i)
+                               sub_sampling=f["sub"], seed=BENCH_SEED, call=i)
                     if i >= 1:
                         ts.append(time.time() - t0)
                 out["training"]["cpu_oracle_ms_per_call"] = float(np.median(ts)) * 1e3

@@ -240,10 +240,12 @@ def test_stage_timing_entry_point(engine):
     st = engine.time_stages(sc, hat, p, reps=8)
     assert set(st) == {"sample", "score", "select_rescore", "refine"} and all(v > 0 for v in st.values())
     np.testing.assert_array_equal(engine.read(api.BUF_RESULT)[:31], res[:31])
-    t0 = time.perf_counter()
-    for _ in range(20):
+    calls = []
+    for _ in range(21):
+        t0 = time.perf_counter()
         engine.forward_device(sc, hat, p)
-    call_ms = (time.perf_counter() - t0) / 20 * 1e3
+        calls.append((time.perf_counter() - t0) * 1e3)
+    call_ms = float(np.median(calls))  # the median: one host-side stall among the calls must not decide a timing check
     assert 0.5 * call_ms < sum(st.values()) < 1.2 * call_ms, (st, call_ms)
     assert st["refine"] > st["sample"] > st["score"]  # the single frame's profile: one-CU refinement dominates
 

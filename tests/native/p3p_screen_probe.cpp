@@ -220,3 +220,13 @@ extern "C" void probe_screen(const float* coords, int H, int W, int sub, int shx
     }
     memcpy(out, acc, sizeof(acc));  // out: 40 doubles; [23..27] delicate by quartic trigger 1..5, [28] other bail-outs
 }
+
+// the two quartic solvers side by side: out[0] = n of the exact route (quartic_real_roots), out[1..4] its roots,
+// out[5] = n of the screen's fast copy (quartic_roots_fast; -1 = "not reproducible here": the screen reports maybe), out[6..9] its roots
+extern "C" void probe_quartic(double a, double b, double c, double d, double e, double* out) {
+    double x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
+    out[0] = quartic_real_roots(a, b, c, d, e, x[0], x[1], x[2], x[3]);
+    out[5] = quartic_roots_fast(a, b, c, d, e, y[0], y[1], y[2], y[3]);
+    for (int i = 0; i < 4; i++) { out[1 + i] = x[i]; out[6 + i] = y[i]; }
+}
+

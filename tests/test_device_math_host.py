@@ -368,3 +368,56 @@ def test_fp32_screen_never_rejects_an_accepted_try():
         assert out[40] < 1.0 / 3.0 + 0.1, (name, out[40])             # (err - tau) / (tau * lever) of accepted tries
         if name == "garbage expert":
             assert out[51] / out[0] < 0.2, out[51] / out[0]
+
+
+def test_fast_quartic_agrees_with_the_exact_route_or_says_maybe():
+    """quartic_roots_fast (the sampling screen's copy of the Ferrari solve: contracted arithmetic, fp32-seeded Newton cubic
+    root) next to quartic_real_roots (the route the decision uses) on quartics BUILT to be hard: a root pair closing from 1e-1
+    to 1e-13, a complex pair whose imaginary part shrinks to nothing (real roots about to appear), triple clusters, and both
+    at once -- the cases in which Ferrari's root count is rounding.  Contract: the fast copy either reports -1 ("not
+    reproducible": the screen then lets the try through) or returns the exact route's number of roots with the same values.
+    A silent disagreement is a dropped hypothesis on the GPU (found by calibration in round 2: ~6 per million accepted tries)."""
+    import ctypes as C
+    from tests.native import build as nb
+    lib = C.CDLL(nb.build_screen_probe())
+    lib.probe_quartic.argtypes = [C.c_double] * 5 + [C.c_void_p]
+    rng = np.random.default_rng(7)
+
+    def coeffs(roots_real, pairs):  # monic quartic from real roots and complex pairs (re, im)
+        p = np.poly1d([1.0])
+        for r in roots_real:
+            p *= np.poly1d([1.0, -r])
+        for re, im in pairs:
+            p *= np.poly1d([1.0, -2 * re, re * re + im * im])
+        return p.coeffs
+
+    cases = []
+    for _ in range(4000):
+        base = rng.uniform(0.2, 3.0, 4) * rng.choice([-1, 1], 4)
+        gap = 10.0 ** rng.uniform(-13, -1)
+        kind = rng.integers(0, 5)
+        if kind == 0:    # a closing real pair + two ordinary real roots
+            cases.append(coeffs([base[0], base[0] + gap, base[1], base[2]], []))
+        elif kind == 1:  # a complex pair about to become real + two real roots
+            cases.append(coeffs([base[1], base[2]], [(base[0], gap)]))
+        elif kind == 2:  # a closing pair next to a complex pair
+            cases.append(coeffs([base[0], base[0] + gap], [(base[1], abs(base[2]))]))
+        elif kind == 3:  # a cluster of three
+            cases.append(coeffs([base[0], base[0] + gap, base[0] - 0.7 * gap, base[1]], []))
+        else:            # two closing pairs
+            cases.append(coeffs([base[0], base[0] + gap, base[1], base[1] + 0.5 * gap], []))
+    said_maybe = agreed = 0
+    out = np.zeros(10)
+    for c in cases:
+        scale = 10.0 ** rng.uniform(-3, 3)  # the P3P quartic is not monic
+        lib.probe_quartic(*(float(v * scale) for v in c), out.ctypes.data_as(C.c_void_p))
+        n_exact, n_fast = int(out[0]), int(out[5])
+        if n_fast < 0:
+            said_maybe += 1
+            continue
+        assert n_fast == n_exact, (c, n_exact, n_fast, out)
+        xe, xf = np.sort(out[1:1 + n_exact]), np.sort(out[6:6 + n_fast])
+        assert np.allclose(xe, xf, rtol=1e-6, atol=1e-9), (c, xe, xf)
+        agreed += 1
+    assert agreed > len(cases) // 4 and said_maybe > 0, (agreed, said_maybe)  # it is a guard, not a blanket refusal
+

@@ -149,17 +149,25 @@ def cpu_baseline(frames, assigns, calls, n_hyp, gpu_poses):
 
 
 def stage_times(eng, d_coords, d_assign, params, first_call, reps):
-    """Mean GPU time (ms) of each stage of the forward chain over the cycled frames (esac_hip_time_stages: per frame the
-    chain runs once, then `reps` back-to-back launches of ONE stage sit between one pair of HIP events on the launch
-    stream), with the RNG keys of timed steps."""
-    acc = {}
+    """GPU time (ms) of each stage of the forward chain over the cycled frames (esac_hip_time_stages: per frame the chain
+    runs once, then `reps` back-to-back launches of ONE stage sit between one pair of HIP events on the launch stream),
+    with the RNG keys of timed steps.  Mean over the frames; with 8 frames or more the largest and the smallest frame
+    value of a stage are left out first (a single host- or clock-side stall inside one event pair doubled the 4 us score
+    stage of a whole run once)."""
+    per = {}
     n = len(d_coords)
     for k in range(n):
         params.call = first_call + k  # first_call is a multiple of the frame count: frame k <-> call first_call + k
         st = eng.time_stages(d_coords[k], d_assign[k], params, reps)
         for name, v in st.items():
-            acc[name] = acc.get(name, 0.0) + v / n
-    return acc
+            per.setdefault(name, []).append(v)
+    out = {}
+    for name, vals in per.items():
+        vals = sorted(vals)
+        if len(vals) >= 8:
+            vals = vals[1:-1]
+        out[name] = float(sum(vals) / len(vals))
+    return out
 
 
 def load_profile(config):
@@ -398,7 +406,7 @@ def main():
                 "achieved_live": achieved, "frac_live": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": prof["file"] if prof and traffic is not None else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": score_ms,
-                "kernel_ms_source": "HIP events on the launch stream around %d back-to-back launches of the stage, mean over the %d cycled frames "
+                "kernel_ms_source": "HIP events on the launch stream around %d back-to-back launches of the stage, mean over the %d cycled frames (extremes dropped) "
                                     "(includes ~1.5 us of dependent-kernel boundary per launch)" % (reps, n_frames),
                 "rocprofv3_kernel_ms": rp_ms,
                 "frac_at_rocprofv3_duration": alg_bytes / (rp_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if rp_ms else None,

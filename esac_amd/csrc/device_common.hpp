@@ -166,6 +166,7 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     a.sample_xy += f * N * 8;
     a.tries += f * N;
     a.samp_resume += f * N;
+    a.samp_round += f * N;
     a.best_try += f * N;
     a.fast_scores += f * N;
     a.scores += f * N;

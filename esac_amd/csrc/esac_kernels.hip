@@ -186,6 +186,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         a.tries[h] = SAMPLE_PENDING;
         a.best_try[h] = ~0ull;          // k_sample_decide: lowest accepted try << 32 | its list position
         a.samp_resume[h] = 0x7fffffff;  // k_sample_prescreen: first try not screened yet
+        a.samp_round[h] = 0;
     }
 }
 
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
                 a.tries[h] = SAMPLE_PENDING;
                 a.best_try[h] = ~0ull;
                 a.samp_resume[h] = 0x7fffffff;
+                a.samp_round[h] = 0;
             }
             return;
         }
@@ -328,10 +330,13 @@ constexpr int SCREEN_QUEUE = 128;  // >= SCREEN_FLUSH - 1 + 64
 //                       screening and deciding in one kernel as before.
 // Every try below a hypothesis' resume point has been screened, every "maybe" among them decided: the minimum accepted
 // try is the try the reference's sequential loop stops at (esac_util.h:152-223).
-// gridDim.z wavefronts share a hypothesis: wavefront w screens rounds w, w + Z, w + 2Z, ... (64 tries each) and leaves as
-// soon as its next round starts at or beyond samp_resume[h] -- the lowest point at which some wavefront saw a strong
-// candidate (atomicMin; 0x7fffffff until then).  With few hypotheses in flight (a single frame with some wrong-expert
-// stragglers) that divides the length of the tail by Z.
+// gridDim.z wavefronts share a hypothesis.  The rounds (64 tries each) are handed out IN ORDER by a per-hypothesis counter
+// to whichever wavefront asks next (samp_round) -- not round-robin: with more workgroups than the chip holds at once,
+// wavefront 0 of a hypothesis would walk rounds 0, Z, 2Z, ... alone, long past the accepted try sitting in a round whose
+// owner has not been scheduled yet (measured: 4 instead of 2 wavefronts per hypothesis made config 5a 66 % slower).  A
+// wavefront leaves as soon as the round it is handed starts at or beyond samp_resume[h] -- the lowest point at which some
+// wavefront saw a strong candidate (atomicMin; 0x7fffffff until then).  With few hypotheses pending (a single frame with
+// some wrong-expert stragglers) that divides the length of the tail by the number of wavefronts that are resident.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_prescreen(KArgs a) {
     frame_view(a);
     const int h = blockIdx.x, lane = threadIdx.x;
@@ -344,8 +349,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const float thr = a.tau + SCREEN_MARGIN;
     int* resume = a.samp_resume + h;
-    const long long stride = 64LL * gridDim.z;
-    for (long long base = a.first_try + 64LL * blockIdx.z; base < a.max_tries; base += stride) {
+    for (;;) {
+        int r = 0;
+        if (lane == 0) r = atomicAdd(a.samp_round + h, 1);
+        r = __shfl(r, 0);
+        const long long base = a.first_try + 64LL * r;
+        if (base >= a.max_tries) break;
         if (base >= __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         const int t = (int)base + lane;
         bool maybe = false, strong = false;
@@ -431,8 +440,12 @@ __global__ __launch_bounds__(64) void k_sample_coarse(KArgs a) {
     const Philox rng(a.seed, a.call);
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     int* resume = a.samp_resume + h;
-    const long long stride = 64LL * gridDim.z;
-    for (long long base = a.first_try + 64LL * blockIdx.z; base < a.max_tries; base += stride) {
+    for (;;) {
+        int r = 0;
+        if (lane == 0) r = atomicAdd(a.samp_round + h, 1);
+        r = __shfl(r, 0);
+        const long long base = a.first_try + 64LL * r;
+        if (base >= a.max_tries) break;
         if (base >= __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         const int t = (int)base + lane;
         bool maybe = false, strong = false;
@@ -1064,7 +1077,7 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     b.handover = 0x7fffffff;
     // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on four lanes at first)
     // settles a hypothesis of the right expert within its first round; with several experts the stragglers are handed to
-    // the spread, screened search after `handover` tries, 32768 / total (at most 64) wavefronts each.  Beyond ~10^3
+    // the spread, screened search after `handover` tries, ESAC_WPH_K / total (at most 64) wavefronts each, rounds handed out in order.  Beyond ~10^3
     // hypotheses (several experts) a workgroup per hypothesis no longer fits the chip in one wave of workgroups: the
     // first 32 tries run four hypotheses per wavefront and the screened chain finishes the rest.
     const bool handover = a.E > 1 && a.max_tries > 1024;
@@ -1074,7 +1087,10 @@ void launch_sample(const KArgs& a, hipStream_t s) {
 #ifndef ESAC_HANDOVER
 #define ESAC_HANDOVER 64
 #endif
-    const int wph = (int)(32768 / total) < 1 ? 1 : (int)(32768 / total) > 64 ? 64 : (int)(32768 / total);
+#ifndef ESAC_WPH_K
+#define ESAC_WPH_K 131072  // A/B on one box: 32768 / 65536 / 131072 / 524288 -> config 5a 2.18 / 2.00 / 1.95 / 2.18 ms, config 4 0.399 / 0.357 / 0.348 / 0.372 ms
+#endif
+    const int wph = (int)(ESAC_WPH_K / total) < 1 ? 1 : (int)(ESAC_WPH_K / total) > 64 ? 64 : (int)(ESAC_WPH_K / total);
     if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
         if (handover) b.handover = ESAC_HANDOVER;
         hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, b);

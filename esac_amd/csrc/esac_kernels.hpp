@@ -75,6 +75,7 @@ struct KArgs {
     int* tries;           // [N]
     const float4* sc4;    // [E,H*W] (x,y,z,0) records of the maps for the sampler's gathers, or null (small maps: planar reads hit L2)
     int* samp_resume;     // [N] k_sample_prescreen: first try it did NOT screen (k_sample_screened<true> resumes there)
+    int* samp_round;      // [N] next 64-try round of a pending hypothesis: handed out IN ORDER to whichever wavefront asks (k_sample_prescreen)
     unsigned long long* best_try;  // [N] k_sample_decide: (lowest accepted try << 32 | list position) among the listed ones, ~0: none
     double* samp_cand;    // [samp_cap,16] solved hypothesis of an accepted list entry: rvec,tvec | 12 floats rt32 | 8 ints cells
     int* samp_entries;    // [samp_cap] (frame * N + hypothesis, try) pairs: the tries the screen could not rule out

@@ -172,6 +172,8 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     a.scores += f * N;
     a.exact_flag += f * N;
     a.n_contenders += f * 4;
+    a.sel_partials += (size_t)f * N * ESAC_SELECT_SPLIT;
+    a.sel_arrived += f * N;
     a.stats += f * 4;
     if (a.errs) a.errs += f * P;
     a.inlier_map += f * 2 * P;

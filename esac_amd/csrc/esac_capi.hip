@@ -89,7 +89,7 @@ extern "C" int esac_hip_device_count(void) {
 
 static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.coarse_entries, c->ws.samp_count, c->ws.fast_scores,
-                    c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.stats,
+                    c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.sel_partials, c->ws.sel_arrived, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
                     c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials};
     c->tN = c->tChunks = 0;
@@ -183,6 +183,8 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.scores, (size_t)nN);
     rc |= alloc(&c->ws.exact_flag, (size_t)nN);
     rc |= alloc(&c->ws.n_contenders, (size_t)4 * nB);
+    rc |= alloc(&c->ws.sel_partials, (size_t)nN * ESAC_SELECT_SPLIT);
+    rc |= alloc(&c->ws.sel_arrived, (size_t)nN);
     rc |= alloc(&c->ws.stats, (size_t)4 * nB);
     rc |= alloc(&c->ws.errs, (size_t)nP);
     rc |= alloc(&c->ws.inlier_map, (size_t)nP * 2);  // two buffers, see esac_refine.hip
@@ -209,6 +211,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     }
     HIP_OK(hipMemset(c->ws.result, 0, (size_t)ESAC_RES_DOUBLES * nB * sizeof(double)));
     HIP_OK(hipMemset(c->ws.n_contenders, 0, (size_t)4 * nB * sizeof(int)));
+    HIP_OK(hipMemset(c->ws.sel_arrived, 0, (size_t)nN * sizeof(int)));  // k_select_rescore leaves it zero after every call
     c->capN = nN;
     c->capP = nP;
     c->capB = nB;

@@ -835,7 +835,9 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
 // every workgroup finds the fp32 maximum itself (N floats, trivial), then walks its strided share of the
 // hypotheses; a contender is re-scored by the whole workgroup, anything else keeps its fp32 score.  Workgroup 0
 // also reduces the statistics.  (One launch gap and one tiny kernel less on the single-frame critical path.)
-template <int B>
+// WIDE = false: at most one hypothesis per workgroup and no cell ranges (a single frame of <= 256 hypotheses on a grid that
+// fits the caches: the headline call) -- the list, the barriers around it and the cross-workgroup sum compile away
+template <int B, bool WIDE>
 __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
     __shared__ double s_part[3 * (B / 64)];
     __shared__ double s_tot[3];
@@ -855,42 +857,92 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
     for (int k = 1; k < B / 64; k++) m = fmaxf(m, s_max[k]);
     const float band = m - a.margin;
 
-    for (int h = blockIdx.x; h < a.N; h += gridDim.x) {
-        const float fs = a.fast_scores[h];  // workgroup-uniform
-        if (!(fs >= band)) {
-            if (threadIdx.x == 0) {
-                a.scores[h] = (double)fs;
-                if (a.scores_user) a.scores_user[h] = (double)fs;
-                a.exact_flag[h] = 0;
+    // large grids: gridDim.z workgroups share a contender, workgroup z sums the cells of range z; the last one to arrive
+    // adds the partial sums in range order (a fixed order: the score does not depend on who arrived when)
+    const int nz = WIDE ? gridDim.z : 1, z = WIDE ? blockIdx.z : 0;
+    const int per = ((P + nz - 1) / nz + B - 1) / B * B;  // cells per range, a multiple of the workgroup size
+    const int c0 = z * per, c1 = min(P, c0 + per);
+    __shared__ int s_last, s_nc;
+    __shared__ int s_cont[WIDE ? B : 1];
+    // this workgroup's share of the hypotheses (h = blockIdx.x + gridDim.x * j) is classified by all threads at once --
+    // walking it one hypothesis at a time is a chain of dependent loads (64 of them at N = 16384: ~60 us per workgroup)
+    const bool single = !WIDE || a.N <= (int)gridDim.x;  // one hypothesis per workgroup: no list, no barriers
+    for (int j0 = 0; blockIdx.x + (long long)gridDim.x * j0 < a.N; j0 += B) {
+        int nc;
+        if (single) {
+            const float fs = a.fast_scores[blockIdx.x];  // workgroup-uniform
+            nc = fs >= band ? 1 : 0;
+            if (!nc && threadIdx.x == 0 && z == 0) {
+                a.scores[blockIdx.x] = (double)fs;
+                if (a.scores_user) a.scores_user[blockIdx.x] = (double)fs;
+                a.exact_flag[blockIdx.x] = 0;
             }
-            continue;
+        } else {
+            if (threadIdx.x == 0) s_nc = 0;
+            __syncthreads();
+            const long long hh = blockIdx.x + (long long)gridDim.x * (j0 + threadIdx.x);
+            if (hh < a.N) {
+                const int h = (int)hh;
+                const float fs = a.fast_scores[h];
+                if (fs >= band) {
+                    s_cont[atomicAdd(&s_nc, 1)] = h;  // at most B entries per pass
+                } else if (z == 0) {
+                    a.scores[h] = (double)fs;
+                    if (a.scores_user) a.scores_user[h] = (double)fs;
+                    a.exact_flag[h] = 0;
+                }
+            }
+            __syncthreads();
+            nc = s_nc;
         }
-        const int e = expert_of(a, h);
-        const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
-        const double* hp = a.hyps + (size_t)h * 6;
-        const double rv[3] = {hp[0], hp[1], hp[2]};
-        const double t[3] = {hp[3], hp[4], hp[5]};
-        double R[9];
-        rodrigues_vec2mat<false>(rv, R, nullptr);
-        double acc[1] = {0};
-        for (int i = threadIdx.x; i < P; i += B) {
-            const int row = i / a.W, col = i - row * a.W;
-            float err = project_exact_err(R, t, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
-            err = err < a.max_reproj ? err : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
-            acc[0] += soft_inlier_exact(err, a.tau, a.beta);
+        for (int ci = 0; ci < nc; ci++) {
+            const int h = single ? (int)blockIdx.x : s_cont[ci];
+            const int e = expert_of(a, h);
+            const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
+            const double* hp = a.hyps + (size_t)h * 6;
+            const double rv[3] = {hp[0], hp[1], hp[2]};
+            const double t[3] = {hp[3], hp[4], hp[5]};
+            double R[9];
+            rodrigues_vec2mat<false>(rv, R, nullptr);
+            double acc[1] = {0};
+            for (int i = c0 + threadIdx.x; i < c1; i += B) {
+                const int row = i / a.W, col = i - row * a.W;
+                float err = project_exact_err(R, t, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
+                err = err < a.max_reproj ? err : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+                acc[0] += soft_inlier_exact(err, a.tau, a.beta);
+            }
+            block_sum<1, B>(acc, s_part, s_tot);
+            if (nz > 1) {
+                if (threadIdx.x == 0) {
+                    __hip_atomic_store(a.sel_partials + (size_t)h * ESAC_SELECT_SPLIT + z, acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    const int arrived = atomicAdd(a.sel_arrived + h, 1);
+                    s_last = arrived == nz - 1;
+                    if (s_last) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        double sum = 0;
+                        for (int k = 0; k < nz; k++)
+                            sum += __hip_atomic_load(a.sel_partials + (size_t)h * ESAC_SELECT_SPLIT + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        acc[0] = sum;
+                        a.sel_arrived[h] = 0;  // ready for the next call
+                    }
+                }
+                __syncthreads();
+                if (!s_last) continue;  // (workgroup-uniform)
+            }
+            if (threadIdx.x == 0) {
+                const float scale = a.alpha / a.W / a.H;
+                double sc = acc[0];
+                sc *= scale;  // double *= float
+                a.scores[h] = sc;
+                if (a.scores_user) a.scores_user[h] = sc;
+                a.exact_flag[h] = 1;
+            }
+            __syncthreads();
         }
-        block_sum<1, B>(acc, s_part, s_tot);
-        if (threadIdx.x == 0) {
-            const float scale = a.alpha / a.W / a.H;
-            double s = acc[0];
-            s *= scale;  // double *= float
-            a.scores[h] = s;
-            if (a.scores_user) a.scores_user[h] = s;
-            a.exact_flag[h] = 1;
-        }
-        __syncthreads();
+        if (!single) __syncthreads();
     }
-    if (blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || z != 0) return;
 
     // softmax statistics (esac_util.h:461-497) from the fp32-path scores, in double; number of contenders
     double acc[3] = {0, 0, 0};
@@ -1131,9 +1183,13 @@ void launch_score(const KArgs& a, hipStream_t s) {
 void launch_select_rescore(const KArgs& a, hipStream_t s) {
     // few contenders, latency matters: 16 wavefronts per workgroup; a single frame spreads its hypotheses over up to
     // 256 workgroups (a contender gets a CU to itself), batched frames over 16 each (the frames fill the chip)
-    const int cap = a.frames > 1 ? 16 : 256;
-    const int grid = a.N < cap ? a.N : cap;
-    hipLaunchKernelGGL(k_select_rescore<1024>, dim3(grid, a.frames), dim3(1024), 0, s, a);
+    // a contender on a 480x640 grid is 0.15 ms of one workgroup in reference arithmetic: ESAC_SELECT_SPLIT workgroups share
+    // it there (and the hypotheses are spread over that many fewer columns: every workgroup finds the fp32 maximum itself)
+    const int split = (long long)a.H * a.W >= 32768 ? ESAC_SELECT_SPLIT : 1;
+    const int cap = (a.frames > 1 ? 16 : 256) / split;
+    const int grid = a.N < cap ? a.N : (cap < 1 ? 1 : cap);
+    if (split == 1 && a.N <= grid) hipLaunchKernelGGL((k_select_rescore<1024, false>), dim3(grid, a.frames), dim3(1024), 0, s, a);
+    else                           hipLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, a);
 }
 void launch_rescore_all(const KArgs& a, hipStream_t s) {
     const int grid = a.N < 4096 ? a.N : 4096;  // bulk exact scoring: 4 wavefronts per hypothesis are enough

@@ -18,6 +18,7 @@ constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refi
 constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result record [32] + epoch word + status word
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
 constexpr int ESAC_COARSE_LIST_PER_HYP = 256;  // -DESAC_SAMPLE_COARSE only: capacity of the coarse screen's list A, per hypothesis in flight
+constexpr int ESAC_SELECT_SPLIT = 16;          // cell ranges (workgroups) per contender in k_select_rescore when H*W >= 32768
 constexpr int ESAC_SAMPLE_LIST_PER_HYP = 8;    // capacity of the prescreen's global "maybe" list, per hypothesis in flight
 constexpr int ESAC_TILED_HC = 256;            // hypotheses per chunk of the tile-stationary score kernel
 constexpr int ESAC_TILED_MAX_EXPERTS = 4096;  // experts its bucketing kernel counts in LDS
@@ -88,6 +89,8 @@ struct KArgs {
     double* scores;       // [N]
     uint8_t* exact_flag;  // [N]
     int* n_contenders;    // [1] hypotheses inside the band of the fp32 maximum
+    double* sel_partials; // [N, ESAC_SELECT_SPLIT] k_select_rescore on large grids: a contender's exact sum per cell range
+    int* sel_arrived;     // [N] cell ranges of a contender done (the last one sums the partials in order and resets this to 0)
     double* stats;        // [4] max, sum exp, entropy
     float* errs;          // [P]
     uint8_t* inlier_map;  // [2,P] two alternating buffers; result[31] names the accepted one

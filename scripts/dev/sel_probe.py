@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""How many contenders does the selection stage see on the config-5b shape, and what do the four stages cost there?
+python scripts/dev/sel_probe.py  (on a GPU box)"""
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
 from esac_amd import api, synthetic as S

@@ -12,14 +12,15 @@ assignment vector) are resident in HBM when the timed region starts.
 Workloads (`--config`, BASELINE.json configs; synthetic frames, esac_amd/synthetic.py):
   cfg2  (default, the configuration the metric is quoted on) 1 expert, 256 hypotheses, 640x480 frame -> 60x80 grid
   cfg3  10 experts, gating active, 1024 hypotheses
-  cfg4  12 experts, 4096 hypotheses, experts sharded over the ranks (policy expert, strong scaling; meant for 4 GPUs)
-  cfg5a 50 experts, Dirichlet gating, 16384 hypotheses, 60x80 maps (policy expert, strong scaling; meant for 8 GPUs)
+  cfg4  12 experts, 4096 hypotheses, experts sharded over the ranks (policy balanced, strong scaling; meant for 4 GPUs)
+  cfg5a 50 experts, Dirichlet gating, 16384 hypotheses, 60x80 maps (policy balanced, strong scaling; meant for 8 GPUs)
   cfg5b the same with full-resolution 480x640 maps (the HBM stress shape)
 `--scaling weak`: --hyps is per GPU (the global count grows with N; default for cfg2, what the driver's 1/2/4/8 sweep
 runs); `--scaling strong`: --hyps is the global count, split over the ranks.  `--policy range` shards hypotheses by
-contiguous index range (every rank holds every map); `--policy expert` shards them by expert ownership and every rank
-holds ONLY its own experts' maps (e % world == rank).  Either way ONE all-reduce(SUM) of N + 32*world doubles and a
-device-side winner pick end the step.
+contiguous index range (every rank holds every map); `--policy balanced` orders them by (expert, index) and gives every
+rank N / world of them -- a contiguous expert range per rank, whose maps are all it holds; the shard is built on the device
+from the assignment vector INSIDE the step (one launch); `--policy expert` (expert e on rank e % world, no balancing) is kept
+for comparison.  Either way ONE all-reduce(SUM) of N + 32*world doubles and a device-side winner pick end the step.
 
 `kernels`: per-stage durations measured live with HIP events on the launch stream (R back-to-back launches of one stage
 between one event pair, outside the timed region: an event pair around a single ~4 us launch reads ~4.6 us of its own)
@@ -63,9 +64,9 @@ SCORE_FLOPS_PER_CELL = 35  # soft-inlier term of one cell: 3x4 transform (18), p
 PRESETS = {
     "cfg2": dict(experts=1, hyps=256, grid="60x80", gating="single", policy="range", scaling="weak"),
     "cfg3": dict(experts=10, hyps=1024, grid="60x80", gating="gating", policy="range", scaling="strong"),
-    "cfg4": dict(experts=12, hyps=4096, grid="60x80", gating="gating", policy="expert", scaling="strong"),
-    "cfg5a": dict(experts=50, hyps=16384, grid="60x80", gating="dirichlet", policy="expert", scaling="strong"),
-    "cfg5b": dict(experts=50, hyps=16384, grid="480x640", gating="dirichlet", policy="expert", scaling="strong"),
+    "cfg4": dict(experts=12, hyps=4096, grid="60x80", gating="gating", policy="balanced", scaling="strong"),
+    "cfg5a": dict(experts=50, hyps=16384, grid="60x80", gating="dirichlet", policy="balanced", scaling="strong"),
+    "cfg5b": dict(experts=50, hyps=16384, grid="480x640", gating="dirichlet", policy="balanced", scaling="strong"),
 }
 
 
@@ -205,7 +206,7 @@ def main():
     ap.add_argument("--hyps", type=int, default=None, help="hypotheses: per GPU (weak scaling) or in total (strong)")
     ap.add_argument("--experts", type=int, default=None)
     ap.add_argument("--grid", type=str, default=None)
-    ap.add_argument("--policy", choices=("range", "expert"), default=None)
+    ap.add_argument("--policy", choices=("range", "expert", "balanced"), default=None)
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=64, help="frames per launch set for the extra `batched` figure (0 = skip)")
@@ -253,15 +254,21 @@ def main():
     eng = api.engine(local_rank)
     kw = dict(focal=frames[0]["focal"], ppx=frames[0]["ppx"], ppy=frames[0]["ppy"], sub_sampling=sub)
     d_assign = [torch.from_numpy(a).to(dev) for a in assigns]
-    owned = policy == "expert" and world > 1
-    if owned:  # this rank's experts only: what it would run the expert CNNs for, and all it keeps in HBM
+    owned = policy in ("expert", "balanced") and world > 1
+    plans = None
+    if owned and policy == "balanced":
+        # this rank's expert range per frame, from the histogram a caller takes anyway (test_esac.py:178): the maps of
+        # those experts are what it would run the expert CNNs for, and all it keeps in HBM
+        plans = [D.plan_balanced(np.bincount(a, minlength=E), world)[rank] for a in assigns]
+        d_coords = [torch.from_numpy(np.ascontiguousarray(f["coords"][pl[0]:pl[1] + 1])).to(dev) for f, pl in zip(frames, plans)]
+    elif owned:  # this rank's experts only (e % world == rank)
         mine = D.owned_experts(E, rank, world)
         d_coords = [torch.from_numpy(np.ascontiguousarray(f["coords"][mine])).to(dev) for f in frames]
     else:
         d_coords = [torch.from_numpy(f["coords"]).to(dev) for f in frames]
     shard_sizes = None
     if world > 1:
-        if policy == "range":
+        if policy in ("range", "balanced"):
             lo, hi = D.shard_range(n_total, rank, world)
             mine_n = hi - lo
         else:
@@ -285,6 +292,8 @@ def main():
         pk = dict(seed=BENCH_SEED, call=i, **kw)
         if owned:
             pk["total_experts"] = E
+        if plans is not None:
+            pk["expert_range"] = plans[k]
         _, rec = D.forward_sharded(eng, d_coords[k], d_assign[k], pk, policy=policy, maps="owned" if owned else "full",
                                    timers=ar_timers if i % PHASE_EVERY == 0 else None)
         return rec
@@ -325,7 +334,10 @@ def main():
     phase /= max(n_phase, 1)
     if world == 1:
         eng.set_timing(False)
-    allreduce_ms = float(np.mean([a.elapsed_time(b) for a, b in ar_timers])) if ar_timers else None
+    def _mean_ms(name):
+        v = [a.elapsed_time(b) for n, (a, b) in ar_timers if n == name]
+        return float(np.mean(v)) if v else None
+    allreduce_ms, shard_build_ms = _mean_ms("allreduce"), _mean_ms("shard")
 
     if rank == 0:
         gating_txt = {"single": "all hypotheses on the one expert", "gating": "softmax gating (true expert logit 6)",
@@ -353,12 +365,15 @@ def main():
                        "name": config_name, "experts": E, "hypotheses_total": n_total, "grid": [H, W], "frames_cycled": n_frames,
                        "policy": policy, "shard_sizes": shard_sizes,
                        "parallelism": "hypotheses sharded over %d GPU(s) by %s%s; 1 all-reduce(SUM) of N+32*world doubles, winner picked on the device"
-                                      % (world, "index range" if policy == "range" else "expert ownership (e %% world)",
-                                         ", every rank holds only its own experts' maps" if owned else "")},
+                                      % (world, {"range": "index range", "expert": "expert ownership (e % world)",
+                                                 "balanced": "(expert, index) order cut into equal pieces, built on the device per frame"}[policy],
+                                         (", every rank holds only the maps of its own expert range" if policy == "balanced" else
+                                          ", every rank holds only its own experts' maps") if owned else "")},
             "refine_steps_per_frame": ref_steps / steps, "lm_iters_per_frame": lm_iters / steps,
         }
         if world > 1:
             out["allreduce_ms"] = allreduce_ms
+            out["shard_build_ms"] = shard_build_ms  # esac_hip_shard_balanced, inside the timed step (policy balanced)
         if world == 1:
             out["phase_ms"] = {"sample_p3p": float(phase[0]), "score": float(phase[1]), "select_rescore": float(phase[2]),
                                "refine": float(phase[3]), "gpu_total": float(phase[4]), "event_bracket_overhead": float(phase[5]),

@@ -36,10 +36,12 @@ ABI_SYMBOLS = [
     "esac_hip_forward", "esac_hip_sample", "esac_hip_score", "esac_hip_select", "esac_hip_refine",
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
     "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug", "esac_hip_check",
-    "esac_hip_pick_record", "esac_hip_time_stages",
+    "esac_hip_pick_record", "esac_hip_time_stages", "esac_hip_shard_balanced", "esac_hip_set_wait",
 ]
-ABI_VERSION = 2
-FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS = 1, 2, 4, 8
+ABI_VERSION = 3
+FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS, FLAG_EXACT_SAMPLING, FLAG_SCORES_BY_INDEX = 1, 2, 4, 8, 16, 32
+WAIT_SPIN, WAIT_YIELD, WAIT_BLOCK = 0, 1, 2
+DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL = 1, 2
 
 
 class Params(C.Structure):
@@ -55,6 +57,7 @@ class Params(C.Structure):
         ("rescore_margin", C.c_float),
         ("d_hyp_index", C.c_void_p),
         ("flags", C.c_int32),
+        ("expert_base", C.c_int32),
     ]
 
 
@@ -95,6 +98,8 @@ def load_library():
         lib.esac_hip_check.argtypes = [vp]
         lib.esac_hip_pick_record.argtypes = [vp, vp, i32, vp, vp]
         lib.esac_hip_time_stages.argtypes = [vp, vp, vp, pp, vp, i32, vp]
+        lib.esac_hip_shard_balanced.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+        lib.esac_hip_set_wait.argtypes = [vp, i32]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
                 getattr(lib, name).restype = i32
@@ -146,7 +151,8 @@ class Engine:
 
     def make_params(self, E, H, W, N, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
                     inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0,
-                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0, exact_scores=False, score_shape="auto", pack_maps=False):
+                    max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0, exact_scores=False, score_shape="auto", pack_maps=False,
+                    exact_sampling=False, scores_by_index=False, expert_base=0):
         p = Params()
         p.E, p.H, p.W, p.N = int(E), int(H), int(W), int(N)
         p.shift_x, p.shift_y = int(shift_x), int(shift_y)
@@ -158,7 +164,8 @@ class Engine:
         p.rescore_margin = float(rescore_margin)
         p.d_hyp_index = None
         p.flags = (FLAG_EXACT_SCORES if exact_scores else 0) | {"auto": 0, "tiled": FLAG_SCORE_TILED, "stream": FLAG_SCORE_STREAM}[score_shape] | \
-            (FLAG_PACK_MAPS if pack_maps else 0)
+            (FLAG_PACK_MAPS if pack_maps else 0) | (FLAG_EXACT_SAMPLING if exact_sampling else 0) | (FLAG_SCORES_BY_INDEX if scores_by_index else 0)
+        p.expert_base = int(expert_base)
         self._shape = (int(N), int(H), int(W))
         return p
 
@@ -287,12 +294,35 @@ class Engine:
         self._call(self.lib.esac_hip_pick_record, records.data_ptr(), int(world), self._stream(), host.ctypes.data)
         return host
 
+    def shard_balanced(self, hyp_assign, world, rank, E, expert_base=0, index_out=None, assign_out=None, info_out=None):
+        """This rank's share of the load-balanced split of `hyp_assign` (device int64 [N]), built on the device in one
+        asynchronous launch (esac_hip_shard_balanced): returns (global indices int32 [n_local], local assignment int64
+        [n_local], info int32 [4] = first expert, last expert, n_local, out-of-range flag) -- all device tensors."""
+        assert hyp_assign.is_cuda and hyp_assign.dtype == torch.int64 and hyp_assign.is_contiguous()
+        N = int(hyp_assign.shape[0])
+        n_local = N // world + (1 if rank < N % world else 0)
+        dev = self.device
+        if index_out is None:
+            index_out = torch.empty(max(n_local, 1), dtype=torch.int32, device=dev)
+        if assign_out is None:
+            assign_out = torch.empty(max(n_local, 1), dtype=torch.int64, device=dev)
+        if info_out is None:
+            info_out = torch.empty(4, dtype=torch.int32, device=dev)
+        self._call(self.lib.esac_hip_shard_balanced, hyp_assign.data_ptr(), N, int(E), int(world), int(rank), int(expert_base),
+                   self._stream(), index_out.data_ptr(), assign_out.data_ptr(), info_out.data_ptr())
+        self._keep_shard = (hyp_assign, index_out, assign_out, info_out)
+        return index_out[:n_local], assign_out[:n_local], info_out
+
+    def set_wait(self, mode):
+        """How blocking calls wait for their record: WAIT_SPIN (default), WAIT_YIELD, WAIT_BLOCK (esac_hip_set_wait)."""
+        _check(self.lib.esac_hip_set_wait(self.ctx, int(mode)), self.lib)
+
     def check(self):
         """Waits for the device; raises if the most recent (asynchronous) call met an out-of-range hypAssignment."""
         _check(self.lib.esac_hip_check(self.ctx), self.lib)
 
-    def set_debug(self, keep_error_image=False):
-        _check(self.lib.esac_hip_set_debug(self.ctx, 1 if keep_error_image else 0), self.lib)
+    def set_debug(self, keep_error_image=False, coop_stall=False):
+        _check(self.lib.esac_hip_set_debug(self.ctx, (DEBUG_ERROR_IMAGE if keep_error_image else 0) | (DEBUG_COOP_STALL if coop_stall else 0)), self.lib)
 
     def set_timing(self, on, period=1):
         """Per-phase events on every `period`-th forward call (the next call is the first sampled one)."""
@@ -314,7 +344,7 @@ class Engine:
 # The reference keeps a static RNG whose state advances from call to call
 # (thread_rand.cpp:4-5); here that state is (seed, call counter).
 _state = {"seed": 1305, "call": 0, "engines": {}, "last": None, "max_tries": 0, "max_ref_steps": -1, "fwd_cache": {},
-          "exact_scores": False}
+          "exact_scores": False, "exact_sampling": False}
 
 
 def set_seed(seed, call=0):
@@ -335,6 +365,13 @@ def set_exact_scores(on):
     """True: every hypothesis is scored in the reference's arithmetic (ESAC_FLAG_EXACT_SCORES), so the score vector of
     last_result() and the record's probability / entropy are the reference's own values; the pose is the same either way."""
     _state["exact_scores"] = bool(on)
+
+
+def set_exact_sampling(on):
+    """True: no screen in the sampling loop -- every try of every hypothesis is solved and decided by the fp64 route
+    (ESAC_FLAG_EXACT_SAMPLING), the reference's loop try by try (esac_util.h:152-223).  The accepted try is the same either
+    way; this is the guaranteed route (several times slower on wrong-expert hypotheses)."""
+    _state["exact_sampling"] = bool(on)
 
 
 def engine(device=None):
@@ -401,7 +438,7 @@ def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLengt
     p.inlier_thresh, p.inlier_alpha, p.inlier_beta = float(inlierThreshold), float(inlierAlpha), float(inlierBeta)
     p.max_reproj, p.sub_sampling = float(maxReproj), int(subSampling)
     p.max_tries, p.max_ref_steps = int(_state["max_tries"]), int(_state["max_ref_steps"])
-    p.flags = FLAG_EXACT_SCORES if _state["exact_scores"] else 0
+    p.flags = (FLAG_EXACT_SCORES if _state["exact_scores"] else 0) | (FLAG_EXACT_SAMPLING if _state["exact_sampling"] else 0)
     p.seed, p.call = _state["seed"] & (2**64 - 1), _state["call"] & (2**64 - 1)
     eng._shape = (int(N), int(H), int(W))
     _state["call"] += 1

@@ -12,7 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libesac_hip.so")
 SOURCES = ["esac_kernels.hip", "esac_score_tiled.hip", "esac_refine.hip", "esac_backward.hip", "esac_capi.hip"]
-HEADERS = ["esac_kernels.hpp", "pose_math.hpp", "bwd_math.hpp", "lm_math.hpp", "device_common.hpp", "rng.hpp", os.path.join("..", "..", "include", "esac_hip.h")]
+import glob
+
+# every header under csrc/ (a new one must not be forgotten here: a stale library would be tested against new headers)
+HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join("..", "..", "include", "esac_hip.h")]
 # -ffp-contract=off: the fp64 "exact" kernels follow IEEE op-by-op like the CPU
 # code they are compared with; the fp32 streaming kernel asks for FMAs explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]

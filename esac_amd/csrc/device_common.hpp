@@ -199,7 +199,7 @@ __device__ __forceinline__ int expert_of(const KArgs& a, int h) {
 __device__ __forceinline__ void flag_bad_assignment(const KArgs& a, int h) {
     if (a.E == 1) return;
     const long long e = a.assign[h];
-    if ((unsigned long long)e >= (unsigned long long)a.E) atomicMax(a.status, (unsigned long long)a.epoch);
+    if ((unsigned long long)e >= (unsigned long long)a.E) atomicMax(a.status, (unsigned long long)a.sample_epoch);
 }
 
 __device__ __forceinline__ Cam make_cam(const KArgs& a) {

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(B) void k_bwd_loss(KArgs a) {
         a.bwd.out[0] = expected;
         a.bwd.out[1] = (double)a.bwd.n_sel[1];
         a.bwd.out[2] = a.stats[2];
-        a.bwd.out[3] = (a.status[0] == (unsigned long long)a.epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment (k_sample)
+        a.bwd.out[3] = (a.status[0] == (unsigned long long)a.sample_epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment (k_sample)
     }
 }
 

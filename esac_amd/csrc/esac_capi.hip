@@ -5,6 +5,7 @@
 // kernel launches on the caller's stream, optional per-phase hipEvent timers
 // (the StopWatch prints of esac.cpp:124,149,161,179).
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -20,7 +21,9 @@ static_assert(ESAC_RES_SCORE == ESAC_RES_SCORE_K && ESAC_RES_HYP == ESAC_RES_HYP
                   ESAC_RES_REF_STEPS == ESAC_RES_REF_STEPS_K && ESAC_RES_INLIERS == ESAC_RES_INLIERS_K &&
                   ESAC_RES_PROB == ESAC_RES_PROB_K && ESAC_RES_ENTROPY == ESAC_RES_ENTROPY_K &&
                   ESAC_RES_CONTENDERS == ESAC_RES_CONTENDERS_K && ESAC_RES_LM_ITERS == ESAC_RES_LM_ITERS_K &&
-                  ESAC_MAX_REF_STEPS == ESAC_MAX_REF_STEPS_K && ESAC_BWD_MAX_SLOTS == ESAC_BWD_SLOTS_K,
+                  ESAC_MAX_REF_STEPS == ESAC_MAX_REF_STEPS_K && ESAC_BWD_MAX_SLOTS == ESAC_BWD_SLOTS_K &&
+                  ESAC_FLAG_EXACT_SCORES == ESAC_FLAG_EXACT_SCORES_K && ESAC_FLAG_EXACT_SAMPLING == ESAC_FLAG_EXACT_SAMPLING_K &&
+                  ESAC_FLAG_SCORES_BY_INDEX == ESAC_FLAG_SCORES_BY_INDEX_K,
               "result layout drifted between include/esac_hip.h and esac_kernels.hpp");
 
 static thread_local char g_err[512] = "";
@@ -67,7 +70,11 @@ struct esac_hip_ctx {
     bool ev_valid = false;
     double* h_pin = nullptr;  // pinned, device-visible host buffer: result record [32] + epoch word
     double* d_pin = nullptr;  // its device address
-    double epoch = 0;
+    double epoch = 0;         // bumped by every entry point: hand-off word of the pinned record
+    double sample_epoch = 0;  // epoch of the most recent SAMPLING launch: what the device-side status word is tagged with
+    int wait_mode = ESAC_WAIT_SPIN;
+    int coop_max = 0;         // cooperative refinement workgroups this device holds at once (refine_coop_capacity)
+    bool coop_stall = false;  // ESAC_DEBUG_COOP_STALL
     BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
     int bN = 0, bP = 0, bcap = 0;
     bool b_lists = false;
@@ -88,7 +95,7 @@ extern "C" int esac_hip_device_count(void) {
 }
 
 static void free_ws(esac_hip_ctx* c) {
-    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.coarse_entries, c->ws.samp_count, c->ws.fast_scores,
+    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.samp_count, c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.sel_partials, c->ws.sel_arrived, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
                     c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials};
@@ -115,6 +122,7 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
     HIP_OK(hipHostMalloc((void**)&c->h_pin, (size_t)ESAC_PIN_DOUBLES * ESAC_MAX_BATCH * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     memset(c->h_pin, 0, (size_t)ESAC_PIN_DOUBLES * ESAC_MAX_BATCH * sizeof(double));
     HIP_OK(hipHostGetDevicePointer((void**)&c->d_pin, c->h_pin, 0));
+    c->coop_max = refine_coop_capacity();  // CUs x resident workgroups of the cooperative refinement kernel on THIS device
     *out = c;
     return 0;
 }
@@ -176,9 +184,6 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.samp_cand, (size_t)nN * ESAC_SAMPLE_LIST_PER_HYP * 16);
     rc |= alloc(&c->ws.samp_entries, (size_t)nN * 2 * ESAC_SAMPLE_LIST_PER_HYP);  // (hypothesis, try) pairs
     rc |= alloc(&c->ws.samp_count, (size_t)4);
-#ifdef ESAC_SAMPLE_COARSE
-    rc |= alloc(&c->ws.coarse_entries, (size_t)nN * 2 * ESAC_COARSE_LIST_PER_HYP);
-#endif
     rc |= alloc(&c->ws.fast_scores, (size_t)nN);
     rc |= alloc(&c->ws.scores, (size_t)nN);
     rc |= alloc(&c->ws.exact_flag, (size_t)nN);
@@ -203,6 +208,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
         return rc;
     }
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
+    HIP_OK(hipMemset(c->ws.coop_counter, 0, 2 * sizeof(unsigned long long)));  // [1] is read by esac_hip_check
     HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
     HIP_OK(hipMemcpy(c->ws.status, &old_status, sizeof(old_status), hipMemcpyHostToDevice));
     if (old_hyps) {
@@ -326,12 +332,14 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
                                             : ESAC_MAX_REF_STEPS;
     a.hyp_offset = p->hyp_offset;
     a.hyp_index = p->d_hyp_index;
+    a.expert_base = p->expert_base;
+    a.coop_max = c->coop_max;
+    a.coop_extra = c->coop_stall ? 1 : 0;
     a.samp_cap = (int)(((long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP) > 0x7fffffffLL ? 0x7fffffff : (long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP);
-    a.coarse_cap = (int)(((long long)c->capN * ESAC_COARSE_LIST_PER_HYP) > 0x7fffffffLL ? 0x7fffffff : (long long)c->capN * ESAC_COARSE_LIST_PER_HYP);
-    a.coarse_count = a.samp_count + 1;
     a.flags = p->flags;
     c->epoch += 1.0;  // every call gets its own epoch: result hand-off word and the tag of the status word
     a.epoch = c->epoch;
+    a.sample_epoch = c->sample_epoch;  // launches that sample call mark_sampling() and overwrite this
     // (device-side span stamps only on sampled calls in timing mode: forward_impl clears tstamps otherwise)
     if (!c->keep_errs) a.errs = nullptr;
     // band of the fp32 maximum that is re-scored exactly: the stream's rounding (<= 2e-5 * alpha measured) plus two
@@ -349,6 +357,13 @@ static int check_launch(const char* what) {
     return 0;
 }
 
+// A launch that (re)samples the hypotheses: the status word (out-of-range hypAssignment) is tagged with ITS epoch, and
+// every later stage / check on this context compares against that -- not against the epoch of whatever call came last.
+static void mark_sampling(esac_hip_ctx* c, KArgs& a) {
+    c->sample_epoch = a.epoch;
+    a.sample_epoch = a.epoch;
+}
+
 // stage entry points: validate, make the context's GPU current, launch one phase on the caller's stream
 template <typename Launch>
 static int run_stage(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream,
@@ -362,7 +377,9 @@ static int run_stage(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     return check_launch(what);
 }
 extern "C" int esac_hip_sample(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    return run_stage(c, d_sc, d_assign, p, stream, "k_sample", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) {
+    return run_stage(c, d_sc, d_assign, p, stream, "k_sample", [](esac_hip_ctx* cc, const KArgs& a0, hipStream_t s) {
+        KArgs a = a0;
+        mark_sampling(cc, a);
         cc->rt32_stale = false;
         launch_sample(a, s);
     });
@@ -404,13 +421,15 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     a.result_pin = h_result_out ? c->d_pin : nullptr;
     // events and stamps cost GPU time themselves (an empty event pair reads ~5 us): sample every timing_period-th call
     const bool tm = c->timing && (c->timing_calls++ % c->timing_period) == 0;
-    if (!tm) a.tstamps = nullptr;
+    const bool exact = (a.flags & ESAC_FLAG_EXACT_SCORES) != 0;
+    // device-side span stamps: only the per-hypothesis stream (k_score_fast) writes them
+    if (!tm || a.partials || exact) a.tstamps = nullptr;
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
     c->rt32_stale = false;
+    mark_sampling(c, a);
     launch_sample(a, s);
     if ((rc = check_launch("k_sample"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[1], s));
-    const bool exact = (a.flags & ESAC_FLAG_EXACT_SCORES) != 0;
     // ESAC_FLAG_EXACT_SCORES: every hypothesis scored in the reference's arithmetic (esac_util.h:235-260), softmax
     // statistics from those scores -- the score vector, probability and entropy are then the reference's own values
     if (exact) launch_rescore_all(a, s);
@@ -441,14 +460,21 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             return true;
         };
         bool landed = false;
-        for (long spins = 0; spins < 200000000L; spins++) {
-            if (all_landed()) {
-                landed = true;
-                break;
-            }
-            if ((spins & 1023) == 1023 && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernels are done (or failed)
-                landed = all_landed();
-                break;
+        if (c->wait_mode == ESAC_WAIT_BLOCK) {
+            HIP_OK(hipStreamSynchronize(s));
+            landed = all_landed();
+        } else {
+            const bool yield = c->wait_mode == ESAC_WAIT_YIELD;
+            for (long spins = 0; spins < 200000000L; spins++) {
+                if (all_landed()) {
+                    landed = true;
+                    break;
+                }
+                if (yield) sched_yield();
+                if ((spins & (yield ? 63 : 1023)) == (yield ? 63 : 1023) && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernels are done (or failed)
+                    landed = all_landed();
+                    break;
+                }
             }
         }
         if (!landed) {
@@ -484,6 +510,7 @@ extern "C" int esac_hip_time_stages(esac_hip_ctx* c, const float* d_sc, const in
     a.tstamps = nullptr;
     hipStream_t s = (hipStream_t)stream;
     c->rt32_stale = false;
+    mark_sampling(c, a);
     const bool exact = (a.flags & ESAC_FLAG_EXACT_SCORES) != 0;
     auto stage = [&](int k) {
         switch (k) {
@@ -681,6 +708,7 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
     a.tstamps = nullptr;
     hipStream_t s = (hipStream_t)stream;
     c->rt32_stale = false;
+    mark_sampling(c, a);
     launch_sample(a, s);                                        // esac.cpp:276
     if ((rc = check_launch("k_sample"))) return rc;
     launch_rescore_all(a, s);                                   // esac.cpp:295-316, reference arithmetic for every hypothesis
@@ -726,9 +754,31 @@ extern "C" int esac_hip_check(esac_hip_ctx* c) {
     DeviceGuard guard(c->device);
     if (!c->ws.status) return 0;
     HIP_OK(hipDeviceSynchronize());
-    unsigned long long st = 0;
+    unsigned long long st = 0, coop[2] = {0, 0};
     HIP_OK(hipMemcpy(&st, c->ws.status, sizeof(st), hipMemcpyDeviceToHost));
-    if (st != 0 && (double)st == c->epoch) return fail(-10, "hypAssignment held a value outside [0,E) in the most recent call");
+    HIP_OK(hipMemcpy(coop, c->ws.coop_counter, sizeof(coop), hipMemcpyDeviceToHost));
+    if (coop[1] != 0)  // (zeroed by every cooperative launch: this is the most recent one)
+        return fail(-12, "the cooperating refinement workgroups of the most recent large-grid call could not synchronise (not all of them became resident)");
+    if (st != 0 && (double)st == c->sample_epoch) return fail(-10, "hypAssignment held a value outside [0,E) in the most recent sampling call");
+    return 0;
+}
+
+// Multi-GPU: this rank's share of a load-balanced split of the hypotheses, built on the device (one launch, no host
+// round trip); see include/esac_hip.h.
+extern "C" int esac_hip_shard_balanced(esac_hip_ctx* c, const int64_t* d_assign, int N, int E, int world, int rank, int expert_base,
+                                       void* stream, int32_t* d_index_out, int64_t* d_assign_out, int32_t* d_info_out) {
+    if (!c || !d_assign || !d_index_out || !d_assign_out) return fail(-1, "esac_hip_shard_balanced: null argument");
+    if (N <= 0 || E <= 0 || E > ESAC_TILED_MAX_EXPERTS) return fail(-4, "esac_hip_shard_balanced: N=%d, E=%d (1 <= E <= %d)", N, E, ESAC_TILED_MAX_EXPERTS);
+    if (world < 1 || rank < 0 || rank >= world) return fail(-4, "esac_hip_shard_balanced: rank %d of %d", rank, world);
+    DeviceGuard guard(c->device);
+    launch_shard_balanced(d_assign, N, E, world, rank, expert_base, d_index_out, d_assign_out, d_info_out, (hipStream_t)stream);
+    return check_launch("k_shard_balanced");
+}
+
+extern "C" int esac_hip_set_wait(esac_hip_ctx* c, int mode) {
+    if (!c) return fail(-1, "null context");
+    if (mode != ESAC_WAIT_SPIN && mode != ESAC_WAIT_YIELD && mode != ESAC_WAIT_BLOCK) return fail(-4, "esac_hip_set_wait: unknown mode %d", mode);
+    c->wait_mode = mode;
     return 0;
 }
 
@@ -809,6 +859,7 @@ extern "C" int esac_hip_write_hyps(esac_hip_ctx* c, const double* h_hyps, int N)
 extern "C" int esac_hip_set_debug(esac_hip_ctx* c, int flags) {
     if (!c) return fail(-1, "null context");
     c->keep_errs = (flags & ESAC_DEBUG_ERROR_IMAGE) != 0;
+    c->coop_stall = (flags & ESAC_DEBUG_COOP_STALL) != 0;
     return 0;
 }
 

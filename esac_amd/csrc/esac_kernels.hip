@@ -25,9 +25,6 @@
 
 #include "pose_math.hpp"
 #include "p3p_screen.hpp"
-#ifdef ESAC_SAMPLE_COARSE
-#include "p3p_coarse.hpp"
-#endif
 #include "rng.hpp"
 #include "esac_kernels.hpp"
 #include "device_common.hpp"
@@ -134,6 +131,12 @@ __device__ __forceinline__ void store_hypothesis(const KArgs& a, int h, const fl
         sx[2 * j + 1] = cy[j];
     }
     a.tries[h] = tries_val;
+}
+
+// where hypothesis h's score goes in the caller's vector: local position, or its GLOBAL index (a multi-GPU shard writing
+// straight into its slots of the exchange buffer, ESAC_FLAG_SCORES_BY_INDEX)
+__device__ __forceinline__ size_t user_slot(const KArgs& a, int h) {
+    return (a.flags & ESAC_FLAG_SCORES_BY_INDEX_K) ? (size_t)global_hyp(a, h) : (size_t)h;
 }
 
 constexpr int SAMPLE_PENDING = -2;  // tries[h] between the two phases of the throughput-shaped sampling
@@ -392,135 +395,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
     }
 }
-
-// ---- EXPERIMENT (-DESAC_SAMPLE_COARSE, off by default): a coarse fp32 screen in front of the fp64 screen ------------------
-// k_sample_prescreen spends ~2500 vector instructions per try (1400 of them fp64) at two wavefronts per SIMD, and 99.7 %
-// of the tries of a wrong-expert hypothesis end there.  The idea: walk the same tries with the fp32 geometric screen of
-// p3p_coarse.hpp first (k_sample_coarse: no fp64, four wavefronts per SIMD), list what it cannot rule out (list A,
-// ~13 % of the tries under its lever-scaled margin), run the fp64 screen on list A one LANE per entry (k_sample_fine) and
-// hand its survivors (~0.3 % of the tries) to k_sample_decide as before.  Both screens are one-sided (host calibration:
-// tests/native/p3p_screen_probe.cpp modes 3 and 4, tests/test_device_math_host.py), results are identical (the GPU parity
-// tests pass with the macro on) -- but it is SLOWER.  Measured on config 5a (16384 hypotheses, 50 experts, ~2.1e7 tries):
-//     k_sample_prescreen alone 2.09 ms;   k_sample_coarse 6.31 ms + k_sample_fine 0.60 ms + a longer resume tail.
-// Why: the solver of p3p_coarse.hpp with its certification (Gauss-Newton polish, congruence test, lever) compiles to
-// ~3300 vector instructions per try -- more than the fp64 screen -- and on gfx950 an fp32 vector instruction issues at
-// almost the rate of an fp64 one (scripts/dev/valu_rate.hip: 3.0-4 against 4.85 cycles per wavefront at 4 per SIMD), so
-// "fp32" buys occupancy, not instruction time.  A pre-filter only pays if it is several times SHORTER than the screen it
-// fronts; a certified three-point solve is not.  Kept compilable as the record of that measurement and because the
-// calibration it needed found (and fixed) a real gap in the fp64 screen (p3p_screen.hpp: quartic_roots_fast).
-#ifdef ESAC_SAMPLE_COARSE
-__device__ __forceinline__ void gather_sample_f32(const KArgs& a, const float* __restrict__ map, int P, const Philox& rng, uint32_t gh,
-                                                  uint32_t t, float (&Pf)[4][3], float (&mu)[4], float (&mv)[4]) {
-    int cx[4], cy[4];
-    draw_cells(rng, gh, t, a.W, a.H, cx, cy);
-    const float4* __restrict__ map4 = a.sc4 ? a.sc4 + (size_t)(map - a.sc) / 3 : nullptr;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int idx = cy[j] * a.W + cx[j];
-        if (map4) {
-            const float4 v = map4[idx];
-            Pf[j][0] = v.x; Pf[j][1] = v.y; Pf[j][2] = v.z;
-        } else {
-            Pf[j][0] = map[idx];
-            Pf[j][1] = map[P + idx];
-            Pf[j][2] = map[2 * P + idx];
-        }
-        mu[j] = cell_px(a, cx[j]);
-        mv[j] = cell_py(a, cy[j]);
-    }
-}
-
-__global__ __launch_bounds__(64) void k_sample_coarse(KArgs a) {
-    frame_view(a);
-    const int h = blockIdx.x, lane = threadIdx.x;
-    if (a.tries[h] != SAMPLE_PENDING) return;
-    const int e = expert_of(a, h);
-    const int P = a.H * a.W;
-    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
-    const Philox rng(a.seed, a.call);
-    const uint32_t gh = (uint32_t)global_hyp(a, h);
-    int* resume = a.samp_resume + h;
-    for (;;) {
-        int r = 0;
-        if (lane == 0) r = atomicAdd(a.samp_round + h, 1);
-        r = __shfl(r, 0);
-        const long long base = a.first_try + 64LL * r;
-        if (base >= a.max_tries) break;
-        if (base >= __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-        const int t = (int)base + lane;
-        bool maybe = false, strong = false;
-        if (t < a.max_tries) {
-            float Pf[4][3], mu[4], mv[4];
-            gather_sample_f32(a, map, P, rng, gh, (uint32_t)t, Pf, mu, mv);
-            maybe = p3p_coarse_maybe(Pf, mu, mv, a.focal, a.ppx, a.ppy, a.tau, &strong);
-        }
-        const unsigned long long m = __ballot(maybe);
-        if (m) {
-            const int cnt = __popcll(m);
-            int pos0 = 0;
-            if (lane == 0) pos0 = atomicAdd(a.coarse_count, cnt);
-            pos0 = __shfl(pos0, 0);
-            const int pos = pos0 + __popcll(m & ((1ull << lane) - 1ull));
-            if (maybe && pos < a.coarse_cap) reinterpret_cast<int2*>(a.coarse_entries)[pos] = make_int2(blockIdx.y * a.N + h, t);
-            if (pos0 + cnt > a.coarse_cap) {  // list A full: this round is not fully listed, the hypothesis resumes AT it
-                if (lane == 0) atomicMin(resume, (int)base);
-                break;
-            }
-            if (__any(strong)) {
-                if (lane == 0) atomicMin(resume, (int)(base + 64 < a.max_tries ? base + 64 : a.max_tries));
-                break;
-            }
-        }
-    }
-}
-
-// one lane per entry of list A: the fp64 screen (the body of k_sample_prescreen); survivors go to list B
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_fine(KArgs a0) {
-    const int n = min(a0.coarse_count[0], a0.coarse_cap);
-    for (int i0 = blockIdx.x * 64; i0 < n; i0 += gridDim.x * 64) {  // wave-uniform trip count
-    const int i = i0 + threadIdx.x;
-    bool maybe = false;
-    int hg = 0, t = 0;
-    if (i < n) {
-        const int2 ent = reinterpret_cast<const int2*>(a0.coarse_entries)[i];
-        hg = ent.x;
-        t = ent.y;
-        const int fr = hg / a0.N, h = hg - fr * a0.N;
-        const float* sc = a0.sc + (size_t)fr * a0.sc_frame_stride;
-        const int64_t* assign = a0.assign + (size_t)fr * a0.N;
-        const long long ev = a0.E == 1 ? 0 : assign[h];
-        const int e = (unsigned long long)ev < (unsigned long long)a0.E ? (int)ev : 0;
-        const int P = a0.H * a0.W;
-        const float* __restrict__ map = sc + (size_t)e * 3 * P;
-        const Philox rng(a0.seed, a0.call + (uint64_t)fr);
-        const Cam cam = make_cam(a0);
-        int cx[4], cy[4];
-        V3 Pt[4];
-        float Pf[4][3];
-        double mu[4], mv[4];
-        gather_sample(a0, map, P, rng, (uint32_t)global_hyp(a0, h), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-        ScreenSetup S;
-        if (screen_setup(Pt, mu, mv, cam, S)) {
-            const float err = p3p_screen_roots(S, Pf, (float)mu[3], (float)mv[3], a0.focal, a0.ppx, a0.ppy);
-            maybe = !(err > a0.tau + SCREEN_MARGIN);
-        }
-    }
-    const unsigned long long m = __ballot(maybe);
-    if (m) {
-        const int cnt = __popcll(m);
-        int pos0 = 0;
-        if (threadIdx.x == 0) pos0 = atomicAdd(a0.samp_count, cnt);
-        pos0 = __shfl(pos0, 0);
-        const int pos = pos0 + __popcll(m & ((1ull << threadIdx.x) - 1ull));
-        if (maybe) {
-            if (pos < a0.samp_cap) reinterpret_cast<int2*>(a0.samp_entries)[pos] = make_int2(hg, t);
-            else atomicMin(a0.samp_resume + hg, t);  // list B full: this try is not decided, its hypothesis resumes AT it
-        }
-    }
-    }
-}
-
-#endif  // ESAC_SAMPLE_COARSE
 
 // one lane per listed try: the fp64 route's decision, lowest accepted try per hypothesis
 __global__ __launch_bounds__(64) void k_sample_decide(KArgs a0) {
@@ -874,7 +748,7 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
             nc = fs >= band ? 1 : 0;
             if (!nc && threadIdx.x == 0 && z == 0) {
                 a.scores[blockIdx.x] = (double)fs;
-                if (a.scores_user) a.scores_user[blockIdx.x] = (double)fs;
+                if (a.scores_user) a.scores_user[user_slot(a, blockIdx.x)] = (double)fs;
                 a.exact_flag[blockIdx.x] = 0;
             }
         } else {
@@ -888,7 +762,7 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
                     s_cont[atomicAdd(&s_nc, 1)] = h;  // at most B entries per pass
                 } else if (z == 0) {
                     a.scores[h] = (double)fs;
-                    if (a.scores_user) a.scores_user[h] = (double)fs;
+                    if (a.scores_user) a.scores_user[user_slot(a, h)] = (double)fs;
                     a.exact_flag[h] = 0;
                 }
             }
@@ -935,7 +809,7 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
                 double sc = acc[0];
                 sc *= scale;  // double *= float
                 a.scores[h] = sc;
-                if (a.scores_user) a.scores_user[h] = sc;
+                if (a.scores_user) a.scores_user[user_slot(a, h)] = sc;
                 a.exact_flag[h] = 1;
             }
             __syncthreads();
@@ -1024,7 +898,7 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a) {
             double s = acc[0];
             s *= scale;  // double *= float
             a.scores[h] = s;
-            if (a.scores_user) a.scores_user[h] = s;
+            if (a.scores_user) a.scores_user[user_slot(a, h)] = s;
             a.exact_flag[h] = 1;
         }
         __syncthreads();
@@ -1104,19 +978,127 @@ void launch_pick_record(const double* records, int world, double* pin, double ep
     hipLaunchKernelGGL(k_pick_record, dim3(1), dim3(64), 0, s, records, world, pin, epoch);
 }
 
+// ================================================================= multi-GPU: load-balanced shard of the hypotheses
+// esac_hip_shard_balanced (include/esac_hip.h).  Order the hypotheses by (expert, index) -- the stable counting sort of the
+// assignment vector -- and give rank r the sorted positions [lo, hi) = its N / world share: every rank gets the same
+// number of hypotheses (+-1) whatever the gating distribution, a rank's hypotheses belong to a contiguous range of
+// experts, and only the first and last expert of that range can be shared with a neighbour.  The plan is a pure function
+// of the assignment vector: every rank runs this kernel on its own GPU and they agree without talking.
+// One workgroup.  (1) histogram in LDS, exclusive scan -> first sorted position of every expert; (2) the two experts
+// that straddle lo / hi need the EXACT within-expert rank of their hypotheses (which of them fall on this side of the
+// cut): every thread counts them over its contiguous slice of indices, a block scan turns the counts into ranks;
+// (3) emit: hypotheses of interior experts are appended through an LDS fill counter per expert (their order inside the
+// shard is irrelevant: RNG streams, scores and tie-breaks all go by GLOBAL index), hypotheses of the two cut experts go to
+// the slot their exact rank gives them.  Values outside [0, E) count as expert 0 (device_common.hpp:expert_of) and are
+// copied unchanged, so the forward call on the shard still reports them.
+constexpr int SHARD_B = 1024;
+__global__ __launch_bounds__(SHARD_B) void k_shard_balanced(const int64_t* __restrict__ assign, int N, int E, int world, int rank,
+                                                            int expert_base, int32_t* __restrict__ index_out,
+                                                            int64_t* __restrict__ assign_out, int32_t* __restrict__ info_out) {
+    __shared__ int s_cnt[ESAC_TILED_MAX_EXPERTS];    // histogram, then fill level
+    __shared__ int s_start[ESAC_TILED_MAX_EXPERTS];  // first sorted position of each expert
+    __shared__ int s_scan[2][SHARD_B];
+    __shared__ int s_cut[2];  // the expert that contains sorted position lo, the one that contains hi - 1
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    const int base = N / world, rem = N % world;
+    const int lo = rank * base + (rank < rem ? rank : rem), hi = lo + base + (rank < rem ? 1 : 0);
+    auto expert = [&](int h) {
+        const long long e = assign[h];
+        return (unsigned long long)e < (unsigned long long)E ? (int)e : 0;
+    };
+    for (int e = tid; e < E; e += SHARD_B) s_cnt[e] = 0;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    for (int h = tid; h < N; h += SHARD_B) {
+        const long long e = assign[h];
+        if ((unsigned long long)e >= (unsigned long long)E) s_bad = 1;
+        atomicAdd(&s_cnt[expert(h)], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the counts: every thread owns EPT consecutive experts
+    constexpr int EPT = ESAC_TILED_MAX_EXPERTS / SHARD_B;
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+        const int e = tid * EPT + k;
+        mine += e < E ? s_cnt[e] : 0;
+    }
+    auto block_excl = [&](int v) {  // exclusive prefix of v over the workgroup (Hillis-Steele in LDS)
+        int cur = 0;
+        s_scan[0][tid] = v;
+        __syncthreads();
+        for (int off = 1; off < SHARD_B; off <<= 1) {
+            const int t = s_scan[cur][tid] + (tid >= off ? s_scan[cur][tid - off] : 0);
+            s_scan[cur ^ 1][tid] = t;
+            cur ^= 1;
+            __syncthreads();
+        }
+        const int r = s_scan[cur][tid] - v;
+        __syncthreads();
+        return r;
+    };
+    {
+        int pos = block_excl(mine);
+#pragma unroll
+        for (int k = 0; k < EPT; k++) {
+            const int e = tid * EPT + k;
+            if (e < E) {
+                const int c = s_cnt[e];
+                s_start[e] = pos;
+                if (c > 0 && pos <= lo && lo < pos + c) s_cut[0] = e;
+                if (c > 0 && pos < hi && hi <= pos + c) s_cut[1] = e;
+                pos += c;
+            }
+        }
+    }
+    __syncthreads();
+    if (hi <= lo) {  // more ranks than hypotheses: nothing for this one
+        if (info_out && tid == 0) { info_out[0] = 0; info_out[1] = -1; info_out[2] = 0; info_out[3] = s_bad; }
+        return;
+    }
+    const int e_lo = s_cut[0], e_hi = s_cut[1];
+    // exact within-expert ranks for the two cut experts: contiguous index slice per thread
+    const int per = (N + SHARD_B - 1) / SHARD_B;
+    const int h0 = tid * per, h1 = min(N, h0 + per);
+    int c_lo = 0, c_hi = 0;
+    for (int h = h0; h < h1; h++) {
+        const int e = expert(h);
+        c_lo += e == e_lo;
+        c_hi += e == e_hi;
+    }
+    int r_lo = block_excl(c_lo), r_hi = e_hi == e_lo ? 0 : block_excl(c_hi);
+    if (e_hi == e_lo) r_hi = r_lo;
+    for (int e = tid; e < E; e += SHARD_B) s_cnt[e] = 0;  // fill level of the interior experts
+    __syncthreads();
+    for (int h = h0; h < h1; h++) {
+        const long long raw = assign[h];
+        const int e = (unsigned long long)raw < (unsigned long long)E ? (int)raw : 0;
+        int pos;  // sorted position of h (exact for the cut experts, any free slot of its expert otherwise)
+        if (e == e_lo) pos = s_start[e] + r_lo++;
+        else if (e == e_hi) pos = s_start[e] + r_hi++;
+        else if (e > e_lo && e < e_hi) pos = s_start[e] + atomicAdd(&s_cnt[e], 1);
+        else continue;
+        if (e == e_lo && e == e_hi) r_hi = r_lo;
+        if (pos < lo || pos >= hi) continue;
+        index_out[pos - lo] = h;
+        assign_out[pos - lo] = (unsigned long long)raw < (unsigned long long)E ? (long long)(e - expert_base) : raw;
+    }
+    if (info_out && tid == 0) { info_out[0] = e_lo; info_out[1] = e_hi; info_out[2] = hi - lo; info_out[3] = s_bad; }
+}
+void launch_shard_balanced(const int64_t* assign, int N, int E, int world, int rank, int expert_base, int32_t* index_out,
+                           int64_t* assign_out, int32_t* info_out, hipStream_t s) {
+    hipLaunchKernelGGL(k_shard_balanced, dim3(1), dim3(SHARD_B), 0, s, assign, N, E, world, rank, expert_base, index_out, assign_out, info_out);
+}
+
 // ---------------------------------------------------------------- launchers
 void launch_stats_exact(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_stats_exact<256>, dim3(1, a.frames), dim3(256), 0, s, a);
 }
 // the chain that finishes hypotheses left SAMPLE_PENDING at try b.first_try (see k_sample_prescreen)
 static void launch_sample_stragglers(const KArgs& b, int waves_per_hyp, hipStream_t s) {
-    (void)hipMemsetAsync(b.samp_count, 0, 2 * sizeof(int), s);  // list B's counter and, next to it, list A's
-#ifdef ESAC_SAMPLE_COARSE  // experiment (scripts/dev/variants.sh), see the note above k_sample_coarse: slower than the fp64 screen alone
-    hipLaunchKernelGGL(k_sample_coarse, dim3(b.N, b.frames, waves_per_hyp), dim3(64), 0, s, b);
-    hipLaunchKernelGGL(k_sample_fine, dim3(min((b.coarse_cap + 63) / 64, 16384)), dim3(64), 0, s, b);
-#else
+    (void)hipMemsetAsync(b.samp_count, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_sample_prescreen, dim3(b.N, b.frames, waves_per_hyp), dim3(64), 0, s, b);
-#endif
     hipLaunchKernelGGL(k_sample_decide, dim3((b.samp_cap + 63) / 64), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sample_commit, dim3((b.N + 63) / 64, b.frames), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sample_screened<true>, dim3(b.N, b.frames), dim3(64), 0, s, b);
@@ -1132,7 +1114,11 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     // the spread, screened search after `handover` tries, ESAC_WPH_K / total (at most 64) wavefronts each, rounds handed out in order.  Beyond ~10^3
     // hypotheses (several experts) a workgroup per hypothesis no longer fits the chip in one wave of workgroups: the
     // first 32 tries run four hypotheses per wavefront and the screened chain finishes the rest.
-    const bool handover = a.E > 1 && a.max_tries > 1024;
+    // ESAC_FLAG_EXACT_SAMPLING: no screen anywhere -- every try is solved and decided by the fp64 route (k_sample walks a
+    // straggler's whole budget itself, one try per lane; the throughput shape finishes with k_sample<64> instead of the
+    // screened chain)
+    const bool exact = (a.flags & ESAC_FLAG_EXACT_SAMPLING_K) != 0;
+    const bool handover = a.E > 1 && a.max_tries > 1024 && !exact;
 #ifndef ESAC_LATENCY_MAX
 #define ESAC_LATENCY_MAX 1024
 #endif
@@ -1154,11 +1140,8 @@ void launch_sample(const KArgs& a, hipStream_t s) {
             b.first_try += FIRST_PHASE_TRIES;
         }
         if (b.first_try < a.max_tries) {
-#ifdef ESAC_SAMPLE_UNSCREENED  // A/B switch (scripts/dev/variants.sh): the round-1 kernel, every try solved in full
-            hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);
-#else
-            launch_sample_stragglers(b, wph, s);
-#endif
+            if (exact) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);  // every try solved in full
+            else       launch_sample_stragglers(b, wph, s);
         }
         return;
     }

@@ -17,9 +17,9 @@ constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the er
 constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refinement (one per CU: all must be resident)
 constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result record [32] + epoch word + status word
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
-constexpr int ESAC_COARSE_LIST_PER_HYP = 256;  // -DESAC_SAMPLE_COARSE only: capacity of the coarse screen's list A, per hypothesis in flight
+constexpr int ESAC_FLAG_EXACT_SAMPLING_K = 16, ESAC_FLAG_SCORES_BY_INDEX_K = 32;  // = ESAC_FLAG_* (checked in esac_capi.hip)
 constexpr int ESAC_SELECT_SPLIT = 16;          // cell ranges (workgroups) per contender in k_select_rescore when H*W >= 32768
-constexpr int ESAC_SAMPLE_LIST_PER_HYP = 8;    // capacity of the prescreen's global "maybe" list, per hypothesis in flight
+constexpr int ESAC_SAMPLE_LIST_PER_HYP = 16;   // capacity of the prescreen's global "maybe" list, per hypothesis in flight
 constexpr int ESAC_TILED_HC = 256;            // hypotheses per chunk of the tile-stationary score kernel
 constexpr int ESAC_TILED_MAX_EXPERTS = 4096;  // experts its bucketing kernel counts in LDS
 
@@ -68,6 +68,7 @@ struct KArgs {
     int handover;              // k_sample leaves a hypothesis SAMPLE_PENDING once it has spent this many tries
     float margin;
     int flags;                 // ESAC_FLAG_* (include/esac_hip.h)
+    int expert_base;           // added to the winner's expert index in the record (esac_hip_params.expert_base)
     const int32_t* hyp_index;  // optional [N] global hypothesis indices
     // workspaces (device)
     double* hyps;         // [N,6]
@@ -82,9 +83,6 @@ struct KArgs {
     int* samp_entries;    // [samp_cap] (frame * N + hypothesis, try) pairs: the tries the screen could not rule out
     int* samp_count;      // [1] entries appended (may exceed samp_cap: clamp)
     int samp_cap;
-    int* coarse_entries;  // -DESAC_SAMPLE_COARSE only (else null): [coarse_cap] list A, (frame * N + hypothesis, try) pairs
-    int* coarse_count;    // [1] = samp_count + 1
-    int coarse_cap;
     float* fast_scores;   // [N]
     double* scores;       // [N]
     uint8_t* exact_flag;  // [N]
@@ -105,6 +103,8 @@ struct KArgs {
     double* coop_partials;              // [2][ESAC_REFINE_COOP_MAX][32]
     unsigned long long* coop_counter;   // [2] arrival counter, "a barrier timed out" flag
     int coop_slice;
+    int coop_max;                       // workgroups of the cooperative kernel the device holds at once (refine_coop_capacity)
+    int coop_extra;                     // ESAC_DEBUG_COOP_STALL: workgroups the barrier waits for beyond those launched (0 normally)
     // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
     int* order;           // [N] hypothesis at sorted position pos (sorted by expert)
     float* rt_sorted;     // [N,12] rt32 rows in sorted order
@@ -118,6 +118,7 @@ struct KArgs {
     double* result_pin;   // optional pinned HOST memory [ESAC_PIN_DOUBLES] (device-visible): result record, epoch word,
                           // status word (1.0: this call's hypAssignment held an out-of-range value)
     double epoch;         // value stored into result_pin[32] after the record (the host polls it)
+    double sample_epoch;  // epoch of the launch that sampled the hypotheses in the workspace: what KArgs::status is compared with
     // batched calls: frame b = blockIdx.y works on its own slice of every buffer (device_common.hpp:frame_view)
     int frames;                 // B >= 1
     long long sc_frame_stride;  // elements between the coordinate tensors of consecutive frames
@@ -134,6 +135,10 @@ void launch_select_rescore(const KArgs& a, hipStream_t s);
 void launch_rescore_all(const KArgs& a, hipStream_t s);
 void launch_stats_exact(const KArgs& a, hipStream_t s);
 void launch_pick_record(const double* records, int world, double* pin, double epoch, hipStream_t s);
+void launch_shard_balanced(const int64_t* assign, int N, int E, int world, int rank, int expert_base, int32_t* index_out,
+                           int64_t* assign_out, int32_t* info_out, hipStream_t s);
+int refine_coop_capacity();              // resident workgroups of the cooperative refinement kernel on the current device
+int refine_coop_slice(const KArgs& a);  // cells per cooperating refinement workgroup, 0: one workgroup refines
 void launch_refine(const KArgs& a, hipStream_t s);
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);

@@ -169,17 +169,44 @@ __device__ __forceinline__ double pow10_int(int k) {
 struct Coop {
     int G, g;                      // number of cooperating workgroups, this one's index (G == 1: no cooperation)
     double* partials;              // [2][G][32]
-    unsigned long long* counter;   // monotonic arrival counter, zeroed by the launcher
-    unsigned long long* failed;    // set when a barrier timed out
+    unsigned long long* counter;   // monotonic arrival counter, zeroed by the launcher; COOP_POISON is added on a time-out
+    unsigned long long* failed;    // set when a barrier timed out (what the host reads)
     unsigned long long arrivals;   // barriers passed so far (same in every thread of every workgroup)
+    int expect;                    // workgroups a barrier waits for (= G; ESAC_DEBUG_COOP_STALL: G + 1, never reached)
+    long spin_limit;               // polls before a barrier gives up
+    int* s_dead;                   // LDS flag: a barrier of this launch timed out somewhere
+    bool dead;                     // ... as every thread of the workgroup saw it after its last barrier (workgroup-uniform)
 };
+// A workgroup that gives up at a barrier adds this to the counter: every waiter (now and at every later barrier) sees its
+// target reached at once and reads the failure out of the same value -- nobody spins a second time.
+constexpr unsigned long long COOP_POISON = 1ull << 62;
+
+// One lane: arrive at the barrier and wait for the others.  On a time-out (a workgroup of this launch never became
+// resident: the GPU is shared, partitioned, or smaller than the launcher assumed) the counter is poisoned so that every
+// other waiter -- now and at all later barriers -- falls through immediately, the failure is flagged for the host, and the
+// LDS flag tells this workgroup to wind down.
+__device__ __forceinline__ void coop_arrive_and_wait(Coop& co) {
+    __hip_atomic_fetch_add(co.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (co.arrivals + 1ull) * (unsigned long long)co.expect;
+    long spins = 0;
+    unsigned long long seen;
+    while ((seen = __hip_atomic_load(co.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > co.spin_limit) {
+            __hip_atomic_store(co.failed, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = __hip_atomic_fetch_add(co.counter, COOP_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + COOP_POISON;
+            break;
+        }
+    }
+    if (seen >= COOP_POISON) *co.s_dead = 1;
+}
 
 // v[0..NV) <- sum over the G workgroups of their v (every thread of a workgroup enters with the same v, leaves with the
 // same total; s_tot: >= 28 doubles of LDS scratch).  No-op for G == 1.
 template <int NV>
 __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double* s_tot, double* s_part) {
     static_assert(NV <= 28, "partials hold 32 doubles per workgroup");
-    if (co.G == 1) return;
+    if (co.G == 1 || co.dead) return;  // dead: the sums are meaningless from here on, the callers wind the refinement down
     double* buf = co.partials + (size_t)(co.arrivals & 1ull) * co.G * 32;
     __syncthreads();
     // publish: the sums go through LDS (static register indices only), NV lanes store them, ONE lane releases them at
@@ -196,18 +223,7 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
         __hip_atomic_store(buf + (size_t)co.g * 32 + threadIdx.x, s_tot[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // NV <= 28: all of them lanes of wavefront 0, as is the arriving lane
     }
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(co.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long target = (co.arrivals + 1ull) * (unsigned long long)co.G;
-        long spins = 0;
-        while (__hip_atomic_load(co.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1L << 25)) {  // ~seconds: a workgroup of this launch never became resident
-                __hip_atomic_store(co.failed, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
+    if (threadIdx.x == 0) coop_arrive_and_wait(co);
     __syncthreads();
 #define COOP_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
@@ -216,21 +232,13 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(co.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long target = (co.arrivals + 1ull) * (unsigned long long)co.G;
-        long spins = 0;
-        while (__hip_atomic_load(co.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1L << 25)) {  // ~seconds: a workgroup of this launch never became resident
-                __hip_atomic_store(co.failed, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
+        coop_arrive_and_wait(co);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
 #define COOP_LOAD(p) (*(p))
 #endif
+    co.dead = *co.s_dead != 0;  // written before the barrier above by lane 0, read by everyone: workgroup-uniform
     // gather: 8 groups of 32 lanes, group j adds the partials of workgroups j, j+8, j+16, ... (loads independent of each
     // other), then value k adds its 8 group sums -- one fixed order for every workgroup: bitwise identical totals
     {
@@ -435,7 +443,7 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
     if (co && co->G > 1) {  // total over the cooperating workgroups (exact in double: counts < 2^28)
         double cnt[1] = {(double)base};
         coop_allreduce<1>(cnt, *co, s_tot, s_part);
-        base = (int)cnt[0];
+        base = co->dead ? 0 : (int)cnt[0];  // dead: "no inliers" ends the refinement loop at once
     }
     CYC_END(14);
     return base;
@@ -523,6 +531,7 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
     for (;;) {
         // residual norm and (speculatively) the normal equations at `param`
         const double err_norm = sqrt(lm_pass<B>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc, co));
+        if (co && co->dead) break;  // a barrier timed out: the sums are garbage, the call reports -12
         bool accept;
         if (!have_base) {
             have_base = true;  // iters == 0: prevErrNorm = |err(initial pose)|
@@ -596,13 +605,17 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
 #endif
     CYC_BEGIN();
     if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
-    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull};
+    __shared__ int s_coop_dead;
+    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &s_coop_dead, false};
     if (COOP) {
         co.G = (int)gridDim.x;
         co.g = (int)blockIdx.x;
         co.partials = a.coop_partials;
         co.counter = a.coop_counter;
         co.failed = a.coop_counter + 1;
+        co.expect = co.G + a.coop_extra;
+        co.spin_limit = a.coop_extra ? (1L << 12) : (1L << 25);  // ~seconds normally; the stall test gives up after ~0.1 ms
+        if (threadIdx.x == 0) s_coop_dead = 0;  // (ordered before its first use by the __syncthreads of the argmax below)
     }
     const bool writer = !COOP || co.g == 0;          // the workgroup that owns the outputs
     const int cell0 = COOP ? co.g * a.coop_slice : 0;  // this workgroup's cells: [cell0, cell0 + Pn)
@@ -718,7 +731,6 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         double* r = a.result;
         r[ESAC_RES_SCORE_K] = win_score;
         r[ESAC_RES_HYP_K] = (double)global_hyp(a, win);
-        r[ESAC_RES_EXPERT_K] = (double)e;
 #pragma unroll
         for (int k = 0; k < 6; k++) r[ESAC_RES_RVEC_K + k] = pose[k];
 #pragma unroll
@@ -731,19 +743,22 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         r[ESAC_RES_CONTENDERS_K] = (double)nc;
         r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
         r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
+        // a barrier between the cooperating workgroups timed out: the record is not to be trusted
+        const bool coop_failed = COOP && (co.dead || __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
+        r[ESAC_RES_EXPERT_K] = (double)(e + a.expert_base);
         if (a.result_user) {
 #pragma unroll
             for (int k = 0; k < 31; k++) a.result_user[k] = r[k];
-            a.result_user[31] = 1.0;  // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" from a record
+            // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" from a record; never set on a failed one
+            a.result_user[31] = coop_failed ? 0.0 : 1.0;
         }
         if (a.result_pin) {
             // straight into pinned host memory: the host polls the epoch word instead of waiting for a
             // copy kernel + stream-completion signal (saves ~15-20 us of the blocking call's latency)
 #pragma unroll
             for (int k = 0; k < 32; k++) a.result_pin[k] = r[k];
-            a.result_pin[33] = (a.status[0] == (unsigned long long)a.epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment seen by k_sample
-            if (COOP && __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)
-                a.result_pin[33] = 3.0;  // a barrier between the cooperating workgroups timed out: the record is not to be trusted
+            a.result_pin[33] = (a.status[0] == (unsigned long long)a.sample_epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment seen by k_sample
+            if (coop_failed) a.result_pin[33] = 3.0;
             __threadfence_system();
             *reinterpret_cast<volatile double*>(a.result_pin + 32) = a.epoch;
         }
@@ -759,14 +774,28 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
 int refine_coop_slice(const KArgs& a) {
     const int P = a.H * a.W;
     const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
-    if (P <= LDS_CAP || !vec || a.frames != 1 || !a.coop_partials) return 0;
+    // a.coop_max = workgroups of the cooperative kernel this DEVICE holds at once (refine_coop_capacity, queried when
+    // the context was created): all of them must be resident for the barrier to complete
+    const int gmax = a.coop_max < ESAC_REFINE_COOP_MAX ? a.coop_max : ESAC_REFINE_COOP_MAX;
+    if (P <= LDS_CAP || !vec || a.frames != 1 || !a.coop_partials || gmax < 2) return 0;
     constexpr int trip = REFINE_B * ERR_UNROLL;
 #ifndef ESAC_COOP_TRIPS
 #define ESAC_COOP_TRIPS 4  // 8192 cells per workgroup (= LDS_CAP): 2 trips measured 478 us, 1 trip 604, 4 trips 437 at 480x640
 #endif
     int slice = ESAC_COOP_TRIPS * trip;
-    if ((P + slice - 1) / slice > ESAC_REFINE_COOP_MAX) slice = ((P + ESAC_REFINE_COOP_MAX - 1) / ESAC_REFINE_COOP_MAX + trip - 1) / trip * trip;
-    return slice <= LDS_CAP ? slice : 0;
+    if ((P + slice - 1) / slice > gmax) slice = ((P + gmax - 1) / gmax + trip - 1) / trip * trip;
+    return slice <= LDS_CAP ? slice : 0;  // 0: the grid needs more resident workgroups than the device has -> one workgroup, global list
+}
+
+// Workgroups of the cooperative refinement kernel the current device can hold at once: CUs x workgroups per CU (1: the
+// kernel's 128 KiB correspondence list fills a CU's LDS).  0 when the occupancy query fails.
+int refine_coop_capacity() {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_refine<REFINE_B, false, true, false, true>, REFINE_B, 0) != hipSuccess) return 0;
+    const long long cap = (long long)cus * per_cu;
+    return cap > ESAC_REFINE_COOP_MAX ? ESAC_REFINE_COOP_MAX : (int)cap;
 }
 
 void launch_refine(const KArgs& a, hipStream_t s) {

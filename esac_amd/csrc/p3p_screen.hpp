@@ -243,8 +243,17 @@ struct ScreenSetup {
     double mu[3], mv[3], mk[3];
     double dist2, a, b, p, q, r, inv_b0;
     double x[4];
+    float dx01, dx23;  // bound on the difference between roots (0, 1) / (2, 3) here and in the exact route (quartic_roots_fast)
     int n;
 };
+
+// Host builds of the probe count which guard turned a try into "maybe" (tests/native/p3p_screen_probe.cpp defines the macro)
+#ifndef ESAC_SCREEN_STAT
+#define ESAC_SCREEN_STAT(k)
+#endif
+#ifndef ESAC_SCREEN_HIST
+#define ESAC_SCREEN_HIST(k, v)
+#endif
 
 // cos(acos(c) / 3), |c| <= 1: fp32 seed, Newton on 4u^3 - 3u - c = 0 (the seed is ~1e-7 off: two steps reach rounding);
 // next to c = -1 (u = 1/2 is a double root there) the library route is kept
@@ -285,19 +294,60 @@ ESAC_HD double cbrt_pos(double a) {
     return ldexp(u, k);
 }
 
-// real roots of the quartic, Ferrari through the first real root of the resolvent cubic: the branch structure of
-// quartic_real_roots / cubic_first_roots (pose_math.hpp), contracted arithmetic, fast cubic root
+// ---- how far can this copy be from the exact route? -----------------------------------------------------------------------------
+// Both routes evaluate the same formulas on the same inputs; they differ in ROUNDING: IEEE mul / add and the library's
+// acos / cos / pow there, contracted FMAs, Newton reciprocals / roots and a polished fp32 seed here.  The screen may only
+// judge a try when that difference cannot change a discrete outcome (number of real roots, validity of a candidate) or
+// move a depth by more than the screening margin absorbs.  So every quantity a decision hangs on carries a FIRST-ORDER
+// BOUND of the difference between two correctly-ordered evaluations of it:
+//   * a quartic coefficient: SCREEN_CU * (sum of the magnitudes of the terms it is summed from) -- SCREEN_CU = 64 eps
+//     covers the <= 16 roundings of either evaluation plus the few-eps relative differences of a, b, p, q, r themselves;
+//   * propagated through the normalisation, the resolvent cubic's coefficients, its root r0 (residual bound / slope:
+//     the conditioning of the root, arbitrarily bad next to a multiple root), Ferrari's R^2, D^2, E^2 -- including the
+//     cancellation INSIDE 4bc - 8d - b^3 and the 1 / R amplification -- down to the roots x and, in screen_lengths, to
+//     b1(x) and the depth ratio y = b1 / b0.
+// Where R^2, D^2, E^2, a root's sign or b1's sign is not SCREEN_SIG times larger than its bound, or a root / depth ratio
+// is not reproducible to SCREEN_REL, the try is "maybe" (decided by the exact route).  The probe
+// (tests/native/p3p_screen_probe.cpp, scripts/dev/screen_adversarial.py) runs this code against the exact route on
+// planar / fronto-parallel / spherical / warped maps where every sample is a near-double-root configuration.
+#ifndef SCREEN_CU
+#define SCREEN_CU (2 * 2.220446049250313e-16)
+#endif
+#ifndef SCREEN_SIG
+#define SCREEN_SIG 250.0
+#endif
+#ifndef SCREEN_REL
+#define SCREEN_REL 1e-2
+#endif
 #ifndef SCREEN_FERRARI_SAFETY
 #define SCREEN_FERRARI_SAFETY 1e3
 #endif
-ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e, double& x0, double& x1, double& x2, double& x3) {
+// real roots of the quartic, Ferrari through the first real root of the resolvent cubic: the branch structure of
+// quartic_real_roots / cubic_first_roots (pose_math.hpp), contracted arithmetic, fast cubic root.
+// ua..ue: bounds of the coefficients' differences between the two routes; dx01 / dx23: bound of the difference of the
+// roots of each pair (they share it: x = +-R/2 +- sqrt(D2)/2 - b/4).
+// Returns the number of real roots, or -1: "not reproducible here" (the caller reports maybe).
+ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e, float ua, float ub, float uc, float ud, float ue,
+                               double& x0, double& x1, double& x2, double& x3, float& dx01, float& dx23) {
 #pragma clang fp contract(fast)
-    if (a == 0) return -1;  // degenerate quartic: the caller reports "maybe"
+    if (!((float)fabs(a) > (float)SCREEN_SIG * ua)) {  // (a == 0 included) the leading coefficient carries no digits
+        ESAC_SCREEN_STAT(1);
+        return -1;
+    }
     const double inv_a = scr_rcp(a);
     b *= inv_a; c *= inv_a; d *= inv_a; e *= inv_a;
+    // The bounds are bookkeeping, not arithmetic: single precision (half the registers; an overflow ends as "maybe")
+    const float ia = (float)fabs(inv_a);
+    const float fb = (float)fabs(b), fc = (float)fabs(c), fd = (float)fabs(d), fe = (float)fabs(e), fb2 = fb * fb;
+    // normalised coefficients: (uB + |b| uA) / |A|
+    const float rua = ua * ia;
+    ub = ub * ia + fb * rua; uc = uc * ia + fc * rua; ud = ud * ia + fd * rua; ue = ue * ia + fe * rua;
     const double b2 = b * b, bc = b * c, b3 = b2 * b;
     // resolvent: y^3 - c y^2 + (d b - 4 e) y + (4 c e - d^2 - b^2 e)
     const double cb = -c, cc = d * b - 4 * e, cd = 4 * c * e - d * d - b2 * e;
+    const float eps4 = 8.9e-16f;
+    const float ucc = fd * ub + fb * ud + 4 * ue + eps4 * (fd * fb + 4 * fe);
+    const float ucd = 4 * (fc * ue + fe * uc) + 2 * fd * ud + 2 * fb * fe * ub + fb2 * ue + eps4 * (4 * fc * fe + fd * fd + fb2 * fe);
     const double Q = (3 * cc - cb * cb) * (1. / 9.), R = (9 * cb * cc - 27 * cd - 2 * cb * cb * cb) * (1. / 54.);
     const double Q3 = Q * Q * Q, D = Q3 + R * R;
     const double cb3 = (1. / 3.) * cb;
@@ -315,45 +365,67 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
         const double BD = (AD == 0) ? 0 : -Q * scr_rcp(AD);
         r0 = AD + BD - cb3;
     }
-    // How far can the exact route's resolvent root be from this one?  Both evaluate the same closed form in double -- the
-    // library's acos / cos / pow there, a Newton-polished fp32 seed here -- so they agree to the conditioning of the root:
-    // er ~ (rounding of the cubic at r0) / (its slope there), ~1e-15 for a simple root and arbitrarily large next to a
-    // multiple one (where a double root of the quartic puts it).  Ferrari then takes square roots of quantities that
-    // cancel: R2 = (half the difference of the two quadratic factors' linear terms)^2, D2 and E2 = squared separations of
-    // the root pairs, with v ~ 1 / sqrt(R2).  Where R2, D2 or E2 is not SCREEN_FERRARI_SAFETY times larger than what er
-    // does to it, the number of real roots, their values and their validity are rounding in BOTH evaluations: the exact
-    // route's verdict is not reproducible here -- "maybe" (~0.1 % of random tries).
-    const double slope = fabs((3 * r0 + 2 * cb) * r0 + cc);
-    const double er = 4e-16 * (((fabs(r0) + fabs(cb)) * fabs(r0) + fabs(cc)) * fabs(r0) + fabs(cd)) * scr_rcp(slope);  // slope 0: inf
+    // The resolvent root.  er: what the two closed-form evaluations (the library's acos / cos / pow there, a
+    // Newton-polished fp32 seed here) do to it -- they agree to the conditioning of the root, (rounding of the cubic at
+    // r0) / (its slope there); ec: what the coefficient differences do to it, through the same slope.  Both blow up next
+    // to a multiple root of the cubic, which is where a double root of the quartic puts it.
+    const float fr = (float)fabs(r0);
+    const float islope = 1.0f / (float)fabs((3 * r0 + 2 * cb) * r0 + cc);  // slope 0: inf -> "maybe" below
+    const float er = 4e-16f * (((fr + fc) * fr + (float)fabs(cc)) * fr + (float)fabs(cd)) * islope;
+    const float ec = ((uc * fr + ucc) * fr + ucd) * islope;
+    // Ferrari takes square roots of quantities that cancel: R2 = (half the difference of the two quadratic factors'
+    // linear terms)^2, D2 and E2 = squared separations of the root pairs, with v ~ 1 / sqrt(R2)
     const double R2 = 0.25 * b2 - c + r0;
-    if (!(fabs(R2) > SCREEN_FERRARI_SAFETY * 10 * er)) return -1;
+    const float uR2 = ec + 0.5f * fb * ub + uc;  // coefficient part of R2's bound
+    const float fR2 = (float)fabs(R2);
+    ESAC_SCREEN_HIST(0, er / fR2);
+    ESAC_SCREEN_HIST(1, uR2 / fR2);
+    if (!(fR2 > (float)(SCREEN_FERRARI_SAFETY * 10) * er + (float)SCREEN_SIG * uR2)) {
+        ESAC_SCREEN_STAT(2);
+        return -1;
+    }
     if (R2 < 0) return 0;
-    const double Rr = scr_sqrt(R2);
-    const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * (4 * bc - 8 * d - b3) * scr_rcp(Rr);
+    const double Rr = scr_sqrt(R2), iRr = scr_rcp(Rr);
+    const double num = 4 * bc - 8 * d - b3;
+    const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * num * iRr;
     const double D2 = u + v, E2 = u - v;
+    const float fiRr = (float)iRr, fiR2 = fiRr * fiRr, fv = (float)fabs(v);
+    const float unum = 4 * (fc * ub + fb * uc) + 8 * ud + 3 * fb2 * ub + eps4 * (4 * fb * fc + 8 * fd + fb * fb2);
+    const float uD = 1.5f * fb * ub + 2 * uc + uR2 + 0.25f * unum * fiRr + 0.5f * fv * uR2 * fiR2;  // coefficient part of D2's / E2's bound
+    const float rD = er * (1 + 0.5f * fv * fiR2) + 1e-16f * (0.75f * fb2 + 2 * fc + fR2 + fv);       // rounding part
+    const float fD2 = (float)fabs(D2), fE2 = (float)fabs(E2);
+    ESAC_SCREEN_HIST(2, rD / fminf(fD2, fE2));
+    ESAC_SCREEN_HIST(3, uD / fminf(fD2, fE2));
     {
-        const double dv = SCREEN_FERRARI_SAFETY * (er * (1 + 0.5 * fabs(v) * scr_rcp(R2)) + 1e-16 * (0.75 * b2 + 2 * fabs(c) + R2 + fabs(v)));
-        if (!(fabs(D2) > dv) || !(fabs(E2) > dv)) return -1;
+        const float dv = (float)SCREEN_FERRARI_SAFETY * rD + (float)SCREEN_SIG * uD;
+        if (!(fD2 > dv) || !(fE2 > dv)) {
+            ESAC_SCREEN_STAT(3);
+            return -1;
+        }
     }
     const double b_4 = 0.25 * b, R_2 = 0.5 * Rr;
+    // bound of a root's difference: x = +-R/2 +- sqrt(D2)/2 - b/4
+    const float dxR = 0.25f * (uR2 + er) * fiRr + 0.25f * ub;
     // scalars, not an indexed array: a run-time index (or an array the optimiser cannot split) ends up in scratch memory
     int nb = 0;
     if (D2 >= 0) {
         const double Ds = scr_sqrt(D2);
         x0 = R_2 + 0.5 * Ds - b_4;
         x1 = x0 - Ds;
+        dx01 = dxR + 0.25f * (uD + rD) / (float)Ds;
         nb = 2;
     }
     if (E2 >= 0) {
         const double Es = scr_sqrt(E2);
         const double xa = -R_2 + 0.5 * Es - b_4, xb = xa - Es;
+        const float dx = dxR + 0.25f * (uD + rD) / (float)Es;
         if (nb == 0) {
-            x0 = xa;
-            x1 = xb;
+            x0 = xa; x1 = xb;
+            dx01 = dx;
             nb = 2;
         } else {
-            x2 = xa;
-            x3 = xb;
+            x2 = xa; x3 = xb;
+            dx23 = dx;
             nb = 4;
         }
     }
@@ -399,40 +471,92 @@ ESAC_HD bool screen_setup(const V3 P[4], const double mu_px[4], const double mv_
     const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
     const double b0 = b * temp * temp;
     if (b0 == 0) return false;
+    // magnitudes of the terms each coefficient is summed from (a, b > 0), in single precision like every bound here
+    const float af = (float)a, bf = (float)b, fp = (float)fabs(p), fq = (float)fabs(q), fr = (float)fabs(r), fpr = fp * fr, fpqr = fq * fpr;
+    const float a2f = af * af, b2f = bf * bf, abf = af * bf, p2f = fp * fp, q2f = fq * fq, r2f = fr * fr;
+    const float sf = 1 + af + bf;
+    const float mA = 2 * sf * sf;
+    const float mB = fq * (2 * (abf + a2f + 1 + bf) + r2f * abf + 4 * af) + fpr * (bf + b2f + abf);
+    const float mC = q2f + b2f * (r2f + p2f + 2) + bf * (p2f + fpqr) + abf * (r2f + fpqr) + (a2f + 2 * af) * (2 + q2f) + 2;
+    const float mD = fpr * (abf + b2f + bf) + fq * ((p2f + 2) * bf + 2 * (abf + a2f) + 4 * af + 2);
+    const float mE = 1 + 2 * (bf + af + abf) + b2f + bf * p2f + a2f;
+    const float mT = (p2f + r2f) * sf + fpqr * (1 + af);
+    const float cu = (float)SCREEN_CU;
+    if (!((float)fabs(temp) > (float)SCREEN_SIG * cu * mT)) {  // b0's sign / zero test is rounding
+        ESAC_SCREEN_STAT(4);
+        S.n = -1;
+        return true;
+    }
+    // (temp significant to SCREEN_SIG = 1e3 bounds: b0 = b temp^2 is reproducible to 2e-3 / SCREEN_SIG, inside SCREEN_REL)
     double x0 = 0, x1 = 0, x2 = 0, x3 = 0;
-    const int n = quartic_roots_fast(A, B, C, D, E, x0, x1, x2, x3);
+    float e01 = 0, e23 = 0;
+    const int n = quartic_roots_fast(A, B, C, D, E, cu * mA, cu * mB, cu * mC, cu * mD, cu * mE, x0, x1, x2, x3, e01, e23);
     if (n == 0) return false;
     S.n = n;  // -1: degenerate
     S.x[0] = x0; S.x[1] = x1; S.x[2] = x2; S.x[3] = x3;
+    S.dx01 = e01; S.dx23 = e23;
     S.dist2 = scr_sqrt(s2); S.a = a; S.b = b; S.p = p; S.q = q; S.r = r;
     S.inv_b0 = scr_rcp(b0);
     return true;
 }
 
-// p3p_candidate_lengths for the screen (same polynomial, contracted)
-ESAC_HD bool screen_lengths(const ScreenSetup& S, double x, double& X, double& Y, double& Z) {
+// p3p_candidate_lengths for the screen (same polynomial, contracted).  1: valid, depths in X, Y, Z; 0: the candidate the
+// fp64 route skips too; -1: a validity test (x > 0, b1 > 0, v > 0) or the depth ratio is within the rounding bound of
+// flipping / not reproducible to SCREEN_REL -- the try is "maybe".  dx: bound of the root's difference (quartic_roots_fast).
+ESAC_HD int screen_lengths(const ScreenSetup& S, double x, float dx, double& X, double& Y, double& Z) {
 #pragma clang fp contract(fast)
     const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
     const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
     const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
-    if (x <= 0) return false;
+    const double relx = (double)dx * scr_rcp(fabs(x));
+    ESAC_SCREEN_HIST(4, relx);
+    if (!(relx <= SCREEN_REL)) {  // the root's sign or value is not reproducible (NaN included)
+        ESAC_SCREEN_STAT(5);
+        return -1;
+    }
+    if (x <= 0) return 0;
     const double xx = x * x;
-    const double b1 =
-        ((1 - a - b) * xx + (q * a - q) * x + 1 - a + b) *
-        (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
-          (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * xx +
-         (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
-          pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
-         2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
-         p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
-    if (b1 <= 0) return false;
+    // b1(x) = f1(x) * f2(x): a quadratic times a cubic whose coefficients do not depend on the root
+    const double g2 = 1 - a - b, g1 = q * a - q, g0 = 1 - a + b;
+    const double k3 = r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1);
+    const double k2 = r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2);
+    const double k1 = r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+                      pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b);
+    const double k0 = 2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+                      p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1));
+    const double f1 = g2 * xx + g1 * x + g0;
+    const double f2 = (k3 * x + k2) * xx + k1 * x + k0;
+    const double b1 = f1 * f2;
+    // magnitudes of the terms of the two factors: |p|, |q|, |r| <= 2 bounds the bracketed sums of f2 by 8 M, 72 M, 136 M,
+    // 136 M with M = (1 + a + b)^2 -- loose by up to ~30x, which only matters where f2 has lost
+    // ten digits to cancellation
+    const double s = 1 + a + b;
+    const double m1 = s * (xx + 1) + 2 * (1 + a) * x;
+    const double m2 = 136 * s * s * (x + 1) * (xx + 1);
+    // two evaluations of b1 differ by the rounding of the factors (SCREEN_CU of their term magnitudes) and by what the
+    // root's own difference does to it (first order: |b1'(x)| dx)
+    const double db1 = (fabs(f1) * m2 + fabs(f2) * m1) * SCREEN_CU +
+                       fabs((2 * g2 * x + g1) * f2 + f1 * ((3 * k3 * x + 2 * k2) * x + k1)) * x * relx;
+    const double fb1 = fabs(b1);
+    ESAC_SCREEN_HIST(5, (fabs(f1) * m2 + fabs(f2) * m1) * SCREEN_CU / fb1);
+    ESAC_SCREEN_HIST(6, fabs((2 * g2 * x + g1) * f2 + f1 * ((3 * k3 * x + 2 * k2) * x + k1)) * x * relx / fb1);
+    ESAC_SCREEN_HIST(7, fabs(f1) / m1);
+    ESAC_SCREEN_HIST(8, fabs(f2) / m2);
+    if (!(fb1 * SCREEN_REL > db1)) {  // sign of b1 or the value of y = b1 / b0 not reproducible (covers b1 ~ 0 and NaN)
+        ESAC_SCREEN_STAT(6);
+        return -1;
+    }
+    if (b1 <= 0) return 0;
     const double y = S.inv_b0 * b1;
     const double v = xx + y * y - x * y * r;
-    if (v <= 0) return false;
+    if (!(v > 1e-9 * (xx + y * y))) {  // v is a positive definite form of (x, y) unless |r| = 2: a sign at rounding distance
+        ESAC_SCREEN_STAT(8);
+        return -1;
+    }
     Z = S.dist2 * scr_rcp(scr_sqrt(v));
     X = x * Z;
     Y = y * Z;
-    return true;
+    return 1;
 }
 
 // ---- screen over the fp64 roots and depths --------------------------------------------------------------------------------
@@ -508,12 +632,17 @@ ESAC_HD float p3p_screen_roots_t(const Setup& S, Lengths lengths, const float (&
     ScreenScene sc;  // shared by all candidates
     if (!screen_scene(Pf, sc)) return ESAC_SCREEN_MAYBE;
     float best = INFINITY;
+    // the roots as VALUES before the loop: a select chain over struct members inside it is turned into an indexed load,
+    // which keeps the whole setup struct in memory (scratch / LDS) instead of registers
+    const double xs0 = S.x[0], xs1 = S.x[1], xs2 = S.x[2], xs3 = S.x[3];
     // not unrolled: four inlined copies of the b1 polynomial push the sampling kernel out of the instruction cache
 #pragma nounroll
     for (int i = 0; i < S.n; i++) {
-        const double x = i == 0 ? S.x[0] : i == 1 ? S.x[1] : i == 2 ? S.x[2] : S.x[3];
+        const double x = i == 0 ? xs0 : i == 1 ? xs1 : i == 2 ? xs2 : xs3;
         double Xd, Yd, Zd;
-        if (!lengths(S, x, Xd, Yd, Zd)) continue;  // the candidates the fp64 route skips
+        const int ok = lengths(S, x, i, Xd, Yd, Zd);
+        if (ok < 0) return ESAC_SCREEN_MAYBE;  // validity or depths not reproducible between the two routes
+        if (ok == 0) continue;                 // the candidates the fp64 route skips
         const float epx = screen_candidate(sc, mu, mv, mk, (float)Xd, (float)Yd, (float)Zd, mu3_px, mv3_px, f, cx, cy, ESAC_SCREEN_CONGRUENCE);
         if (epx == ESAC_SCREEN_MAYBE) return ESAC_SCREEN_MAYBE;
         best = fminf(best, epx);
@@ -523,11 +652,13 @@ ESAC_HD float p3p_screen_roots_t(const Setup& S, Lengths lengths, const float (&
 
 // the screen on the exact route's own setup (same doubles), and on its private fast copy
 ESAC_HD float p3p_screen_roots(const P3PSetup& S, const float (&Pf)[4][3], float mu3_px, float mv3_px, float f, float cx, float cy) {
-    return p3p_screen_roots_t(S, [](const P3PSetup& s, double x, double& X, double& Y, double& Z) { return p3p_candidate_lengths(s, x, X, Y, Z); },
+    return p3p_screen_roots_t(S, [](const P3PSetup& s, double x, int, double& X, double& Y, double& Z) { return p3p_candidate_lengths(s, x, X, Y, Z) ? 1 : 0; },
                               Pf, mu3_px, mv3_px, f, cx, cy);
 }
 ESAC_HD float p3p_screen_roots(const ScreenSetup& S, const float (&Pf)[4][3], float mu3_px, float mv3_px, float f, float cx, float cy) {
-    return p3p_screen_roots_t(S, [](const ScreenSetup& s, double x, double& X, double& Y, double& Z) { return screen_lengths(s, x, X, Y, Z); },
+    const float d01 = S.dx01, d23 = S.dx23;  // values, see p3p_screen_roots_t
+    return p3p_screen_roots_t(S, [=](const ScreenSetup& s, double x, int i, double& X, double& Y, double& Z) {
+        return screen_lengths(s, x, i < 2 ? d01 : d23, X, Y, Z); },
                               Pf, mu3_px, mv3_px, f, cx, cy);
 }
 

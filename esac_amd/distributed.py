@@ -11,7 +11,14 @@ through the argmax, so each rank
   3. picks the global winner = max exact score, lowest GLOBAL hypothesis index on
      ties (esac_util.h:519 "first max").
 RNG streams and tie-breaks use global hypothesis indices, so the result does not
-depend on the number of ranks.  The payload is (N_total + 32*world) * 8 bytes
+depend on the number of ranks.  Which hypotheses a rank takes: `policy="balanced"` (default for
+several experts) orders them by (expert, index) and cuts that order into `world` equal pieces --
+N/world hypotheses per rank whatever the gating distribution, a contiguous range of experts per rank,
+only the experts at the cuts shared with a neighbour; the shard is built ON THE DEVICE from the
+assignment vector (esac_hip_shard_balanced: one launch, no host round trip) and the kernels write the
+scores through the global index straight into the exchange buffer.  `policy="range"` cuts the index
+range (every rank needs every map); `policy="expert"` (expert e on rank e % world) is kept for
+comparison -- it does not balance (cfg4 on 4 ranks: 3992 of 4096 hypotheses on one rank).  The payload is (N_total + 32*world) * 8 bytes
 (<= 133 KB at N = 16384, 8 ranks): latency-bound, xGMI bandwidth is irrelevant.
 """
 import numpy as np
@@ -33,6 +40,39 @@ def shard_by_expert(hyp_assign, rank, world):
     each rank then only needs its own experts' maps (and only runs those expert CNNs)."""
     ha = np.asarray(hyp_assign)
     return np.nonzero(ha % world == rank)[0].astype(np.int32)
+
+
+def shard_balanced_host(hyp_assign, rank, world, E=None):
+    """CPU mirror of esac_hip_shard_balanced (the plan is a pure function of the assignment vector): the global indices
+    of rank `rank`'s share, in (expert, index) order, and its (first, last) expert.  Values outside [0, E) count as
+    expert 0, like device_common.hpp:expert_of."""
+    e = np.asarray(hyp_assign).astype(np.int64).copy()
+    if E is not None:
+        e[(e < 0) | (e >= E)] = 0
+    order = np.argsort(e, kind="stable")
+    lo, hi = shard_range(len(e), rank, world)
+    idx = order[lo:hi].astype(np.int32)
+    rng = (int(e[idx[0]]), int(e[idx[-1]])) if len(idx) else (0, -1)
+    return idx, rng
+
+
+def plan_balanced(counts, world):
+    """Expert range (first, last) of every rank under policy "balanced", from the hypothesis histogram the caller takes
+    anyway (test_esac.py:178 `torch.histc`): what a rank must hold maps for / run expert CNNs for.  (0, -1): no share."""
+    counts = np.asarray(counts, np.int64)
+    ends = np.cumsum(counts)
+    starts = ends - counts
+    n = int(ends[-1]) if len(ends) else 0
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        if hi <= lo:
+            out.append((0, -1))
+            continue
+        first = int(np.searchsorted(ends, lo, side="right"))      # expert containing sorted position lo
+        last = int(np.searchsorted(ends, hi - 1, side="right"))   # ... position hi - 1
+        out.append((first, last))
+    return out
 
 
 def pack_local(scores_local, record_local, n_total, global_index, rank, world):
@@ -129,8 +169,8 @@ def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, wor
 
 def _all_reduce_sum(buf, group, timers=None):
     """The one collective.  RCCL ("nccl") reduces the device buffer in place; a gloo group (CPU tests, or several
-    ranks sharing one GPU) gets the 1-2 KB payload staged through the host.  `timers`: optional list that receives a
-    (start, end) pair of CUDA events around the collective (bench.py splits its time out of the step)."""
+    ranks sharing one GPU) gets the 1-2 KB payload staged through the host.  `timers`: optional list that receives
+    ("allreduce", (start, end)) CUDA event pairs around the collective (bench.py splits its time out of the step)."""
     ev = None
     if timers is not None and buf.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -143,7 +183,7 @@ def _all_reduce_sum(buf, group, timers=None):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     if ev is not None:
         ev[1].record()
-        timers.append(ev)
+        timers.append(("allreduce", ev))
 
 
 def owned_experts(E, rank, world):
@@ -159,6 +199,8 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
     policy "range": contiguous index ranges -- the kernels write this rank's scores and record straight into its
     slots of the persistent exchange buffer (hyp_offset keys RNG and tie-breaks), so a call is one memset, the
     forward launches, the all-reduce and the winner pick.
+    policy "balanced": every rank takes N / world hypotheses of a contiguous expert range, shard built on the device
+    per frame (contribute_balanced); maps="owned": `scene_coords` holds the maps of params_kw["expert_range"] only.
     policy "expert": shard by expert ownership (expert e lives on rank e % world; index lists).  maps="owned":
     `scene_coords` is [E_local,3,H,W] holding ONLY this rank's experts (owned_experts(E, rank, world), in that
     order; pass `E` through params_kw["total_experts"]) -- what BASELINE configs[3]/[4] describe: a rank runs and
@@ -177,16 +219,20 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
         if world > 1:
             _all_reduce_sum(buf, group, timers)  # the one collective of this path
         return pick_global(buf, n_total, world, engine)
+    if policy == "balanced":
+        return _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, group, maps, timers)
     if policy != "expert":
         raise ValueError(policy)
     owned = maps == "owned"
     if owned and total_experts is None:
         raise ValueError('maps="owned" needs params_kw["total_experts"]')
-    key = ("expert", str(dev), n_total, world, rank, owned, int(ha_full.data_ptr()) if ha_full.is_cuda else id(ha_full))
+    # keyed by the tensor AND its version counter: a caller that refills a preallocated assignment tensor in place must not
+    # get the previous frame's index list
+    key = ("expert", str(dev), n_total, world, rank, owned, int(ha_full.data_ptr()) if ha_full.is_cuda else id(ha_full), int(ha_full._version))
     shard = _shard_cache.get(key)
     if shard is None:  # the shard of an assignment vector: index list + local assignment, built once per vector
-        if len(_shard_cache) > 64:
-            _shard_cache.clear()
+        while len(_shard_cache) >= 8:  # a fresh tensor per frame always misses: keep only a few entries alive
+            _shard_cache.pop(next(iter(_shard_cache)))
         gidx = torch.from_numpy(shard_by_expert(ha_full.cpu().numpy(), rank, world))
         gidx_dev = gidx.to(dev).contiguous()
         ha_local = ha_full.to(dev)[gidx_dev.to(torch.long)].contiguous() if gidx.numel() else torch.empty(0, dtype=torch.int64, device=dev)
@@ -213,3 +259,63 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
 
 
 _shard_cache = {}
+_balanced_ws = {}
+
+
+def _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, group, maps, timers):
+    """policy "balanced": contribute_balanced, one all-reduce, device-side pick."""
+    buf = contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps, timers)
+    if world > 1:
+        _all_reduce_sum(buf, group, timers)  # the one collective of this path
+    return pick_global(buf, int(ha_full.shape[0]), world, engine)
+
+
+def contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps="full", timers=None):
+    """Rank `rank`'s part of the exchange under policy "balanced": device-built shard (one launch), forward launches
+    writing scores by GLOBAL index and the record into this rank's slot of the persistent exchange buffer (returned).
+    Per frame: a memset, the shard kernel, the forward chain -- no host round trip, no allocation, no scatter.
+    maps="owned": `scene_coords` holds only the maps of this rank's expert range [first, last] =
+    params_kw["expert_range"] (plan_balanced on the histogram), `total_experts` = E."""
+    dev = engine.device
+    n_total = int(ha_full.shape[0])
+    params_kw = dict(params_kw)
+    expert_range = params_kw.pop("expert_range", None)
+    E_local, _, H, W = scene_coords.shape
+    owned = maps == "owned"
+    if owned:
+        if expert_range is None or total_experts is None:
+            raise ValueError('maps="owned" needs params_kw["expert_range"] = (first, last) and params_kw["total_experts"]')
+        first, last = int(expert_range[0]), int(expert_range[1])
+        if last >= first and E_local != last - first + 1:
+            raise ValueError("scene_coords must hold the maps of experts %d..%d" % (first, last))
+        E_total, base = int(total_experts), first
+    else:
+        E_total, base = int(E_local), 0
+    ha_dev = ha_full if ha_full.is_cuda else ha_full.to(dev)
+    if ha_dev.stride(0) != 1:
+        ha_dev = ha_dev.contiguous()  # stride-0 expand() of --expertselection
+    lo, hi = shard_range(n_total, rank, world)
+    n_local = hi - lo
+    key = (str(dev), n_total, world, rank)
+    ws = _balanced_ws.get(key)
+    if ws is None:
+        ws = _balanced_ws[key] = (torch.empty(max(n_local, 1), dtype=torch.int32, device=dev),
+                                 torch.empty(max(n_local, 1), dtype=torch.int64, device=dev),
+                                 torch.empty(4, dtype=torch.int32, device=dev))
+    buf = _exchange_buffer(dev, n_total, world)
+    buf.zero_()
+    if n_local > 0:
+        ev = None
+        if timers is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        gidx, ha_local, _ = engine.shard_balanced(ha_dev, world, rank, E_total, expert_base=base, index_out=ws[0], assign_out=ws[1],
+                                                  info_out=ws[2])
+        if ev is not None:
+            ev[1].record()
+            timers.append(("shard", ev))
+        p = _shard_params(engine, E_local, H, W, n_local, 0, dict(params_kw, scores_by_index=True, expert_base=base))
+        engine.set_hyp_index(p, gidx)
+        rec0 = n_total + rank * RES_DOUBLES
+        engine.forward_device(scene_coords, ha_local, p, scores_out=buf[:n_total], result_out=buf[rec0:rec0 + RES_DOUBLES], want_host=False)
+    return buf

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESAC_HIP_ABI_VERSION 2
+#define ESAC_HIP_ABI_VERSION 3
 
 /* reference compile-time constants (esac.cpp:44-45) */
 #define ESAC_MAX_SAMPLING_TRIES 1000000
@@ -62,6 +62,9 @@ typedef struct esac_hip_params {
                                  shards that are not a contiguous range (expert-sharded multi-GPU);
                                  NULL -> hyp_offset + i */
     int32_t flags;            /* ESAC_FLAG_* below, 0 = default */
+    int32_t expert_base;      /* added to the winner's (local) expert index in ESAC_RES_EXPERT: a rank that holds only a
+                                 slice of the experts' maps (multi-GPU, esac_hip_shard_balanced) passes the global id of
+                                 its first map so that the record carries what esac.cpp:189 returns; 0 otherwise */
 } esac_hip_params;
 
 /* esac_hip_forward / _batch: score EVERY hypothesis in the reference's mixed float/double arithmetic
@@ -71,12 +74,24 @@ typedef struct esac_hip_params {
 #define ESAC_FLAG_EXACT_SCORES 1
 /* Shape of the fp32 ranking score (results are the same to fp32 rounding; default: chosen from grid size and N).
  * TILED: map tiles stationary in registers, hypotheses bucketed by expert stream past them (large maps);
- * STREAM: one hypothesis per workgroup streams its expert's whole map (small, cache-resident maps). */
+ * STREAM: one hypothesis per workgroup streams its expert's whole map (small, cache-resident maps).
+ * Both rank only.  One documented difference from the reference's projection (esac_util.h:302-305, `z ? 1/z : 1`): a cell
+ * whose camera-frame depth is EXACTLY 0 in fp32 gets the clamped error maxReproj in the TILED stream (rcp(0) = inf)
+ * instead of the x,y-as-is projection; the exact re-score of the contenders and the refinement follow the reference. */
 #define ESAC_FLAG_SCORE_TILED 2
 #define ESAC_FLAG_SCORE_STREAM 4
 /* Sampling reads the maps through a packed (x,y,z,0)-per-cell copy made at the start of the call (default: only when
  * the maps are far larger than the caches and several experts are in play).  Results are unchanged. */
 #define ESAC_FLAG_PACK_MAPS 8
+/* Sampling without the screen: every try of every hypothesis is solved and decided by the fp64 route (the reference's own
+ * loop, esac_util.h:152-223, try by try).  The default route screens the tries of long searches (wrong-expert hypotheses)
+ * with a one-sided fp32 test first and decides only what the screen cannot rule out; the accepted
+ * try is the same either way -- this flag is the guaranteed route, several times slower on such hypotheses, like
+ * ESAC_FLAG_EXACT_SCORES for the scores. */
+#define ESAC_FLAG_EXACT_SAMPLING 16
+/* d_scores_out is indexed by GLOBAL hypothesis index (d_hyp_index[i], or hyp_offset + i) instead of by local position:
+ * a multi-GPU shard writes its scores straight into its slots of the exchange buffer. */
+#define ESAC_FLAG_SCORES_BY_INDEX 32
 
 #define ESAC_DEFAULT_MARGIN 1e-3f
 
@@ -181,6 +196,25 @@ int esac_hip_forward_batch(esac_hip_ctx* ctx, int B, const float* d_scene_coords
 int esac_hip_pick_record(esac_hip_ctx* ctx, const double* d_records, int world, void* stream, double* h_record_out);
 
 /*
+ * Load-balanced multi-GPU shard, built on the device (new; SURVEY.md 8e: "a load-balanced assignment from the
+ * hypAssignment histogram", test_esac.py:178).  The hypotheses are ordered by (expert, index) -- the stable counting sort
+ * of d_hyp_assign [N] -- and rank r of `world` takes the sorted positions [r*N/world, (r+1)*N/world) (remainder to the
+ * first ranks): every rank gets N/world hypotheses (+-1) whatever the gating distribution is, its hypotheses belong to a
+ * CONTIGUOUS range of experts [first, last], and only the experts at the two ends of that range are shared with a
+ * neighbour (their maps are needed on both ranks).  The plan is a pure function of the assignment vector, so every rank
+ * computes the same one without communication.
+ * d_index_out   int32[n_local]  global indices of this rank's hypotheses (pass as esac_hip_params.d_hyp_index)
+ * d_assign_out  int64[n_local]  their experts minus `expert_base` (pass as d_hyp_assign of the forward call; values
+ *               outside [0,E) are copied unchanged so that the forward call still reports them)
+ * d_info_out    optional int32[4]: first expert, last expert, n_local, 1 if a value was outside [0,E)
+ * n_local = N/world (+1 for rank < N % world) is known to the caller.  expert_base: 0 when the forward call sees all E
+ * maps; the rank's first expert when it sees only the maps [first, last] (then also esac_hip_params.expert_base).
+ * One launch on `stream`, asynchronous.  E <= 4096.
+ */
+int esac_hip_shard_balanced(esac_hip_ctx* ctx, const int64_t* d_hyp_assign, int N, int E, int world, int rank,
+                            int expert_base, void* stream, int32_t* d_index_out, int64_t* d_assign_out, int32_t* d_info_out);
+
+/*
  * esac_backward (esac.cpp:213-520): expected pose loss over the hypothesis distribution and its gradient wrt the
  * scene coordinates, everything on the device.
  * Status -10: hypAssignment held a value outside [0,E) (the reference reads out of bounds there).
@@ -215,8 +249,10 @@ int esac_hip_refine(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_
 int esac_hip_score_exact(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
                          const esac_hip_params* p, void* stream);
 
-/* Waits for the device; -10 when the most recent call on this context met a hypAssignment value outside [0,E)
- * (blocking calls report that themselves; asynchronous ones -- no host result pointer -- cannot), else 0.
+/* Waits for the device; -10 when the most recent SAMPLING launch on this context (esac_hip_forward / _batch / _sample /
+ * _backward) met a hypAssignment value outside [0,E), -12 when the cooperating workgroups of its most recent large-grid
+ * refinement could not synchronise (blocking calls report both themselves; asynchronous ones -- no host result pointer --
+ * cannot: their device record then lacks ESAC_RES_VALID), else 0.
  * Out-of-range values never cause an out-of-bounds read: such hypotheses are evaluated against expert 0. */
 int esac_hip_check(esac_hip_ctx* ctx);
 
@@ -246,7 +282,20 @@ int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
 /* debug options (off by default). ESAC_DEBUG_ERROR_IMAGE: the refinement also stores the reprojection-error image of
  * the pose it is refining (ESAC_BUF_WINNER_ERRS); nothing downstream needs it, so the stores are skipped otherwise. */
 #define ESAC_DEBUG_ERROR_IMAGE 1
+/* ESAC_DEBUG_COOP_STALL (tests only): the cooperating refinement workgroups of a large-grid call wait for one workgroup
+ * more than was launched, with a short spin limit -- exercises the "not all workgroups became resident" failure path
+ * (status -12) without having to occupy the GPU. */
+#define ESAC_DEBUG_COOP_STALL 2
 int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
+
+/* How a blocking call waits for its result record (written by the last kernel into pinned host memory):
+ * ESAC_WAIT_SPIN (default) polls the epoch word -- lowest latency, one host core busy for the ~0.2 ms of the call;
+ * ESAC_WAIT_YIELD polls with sched_yield() between reads (a DataLoader-heavy caller keeps its cores);
+ * ESAC_WAIT_BLOCK sleeps in hipStreamSynchronize (adds the completion-signal round trip, ~15-20 us). */
+#define ESAC_WAIT_SPIN 0
+#define ESAC_WAIT_YIELD 1
+#define ESAC_WAIT_BLOCK 2
+int esac_hip_set_wait(esac_hip_ctx* ctx, int mode);
 
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ def build():
 def run(lib, name, coords, f, n, seed=1, mode=None):
     mode = MODE if mode is None else mode
     margins = np.array([0.5, 1, 2, 5, 10, 20, 40, 80], np.float32)
-    out = np.zeros(52)
+    out = np.zeros(40)
     c = np.ascontiguousarray(coords, np.float32)
     _, H, W = c.shape
     lib.probe_screen(c.ctypes.data_as(C.c_void_p), H, W, f["sub"], f["shift"][0], f["shift"][1], C.c_float(f["focal"]), C.c_float(f["ppx"]),
@@ -32,11 +32,6 @@ def run(lib, name, coords, f, n, seed=1, mode=None):
     print("%-28s tries %.2e accepted %8d (%.2e) delicate %.3f%%  max screen err of an accepted try %.3f px  max |e32-e64| %.3f" % (
         name, t, acc, acc / t, 100 * out[2] / t, out[3], out[20]))
     print("      bail-outs (quartic triggers 1-5, other): " + " ".join("%.3f%%" % (100 * v / t) for v in out[23:29]))
-    if mode in (4, 5):
-        print("      coarse bail-outs 10..19: " + " ".join("%.3f%%" % (100 * v / t) for v in out[30:40]))
-        print("      lever: max (e-tau)/(tau*lam) img %.3f scene %.3f max(img,scene) %.3f; maybe frac at kappa 1..4: %s; false rejects: %s" % (
-            out[40], out[41], out[42], " ".join("%.4f" % (v / t) for v in out[43:47]), " ".join("%d" % v for v in out[47:51])))
-        print("      SHIPPED RULE (p3p_coarse_maybe): maybe frac %.4f  false rejects %d" % (out[51] / t, out[29]))
     print("      margin      : " + " ".join("%9g" % m for m in margins))
     print("      maybe frac  : " + " ".join("%9.5f" % (v / t) for v in out[4:12]))
     print("      false reject: " + " ".join("%9d" % v for v in out[12:20]))

@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Adversarial maps for the sampling screen (host build of esac_amd/csrc/p3p_screen.hpp vs the fp64 route,
+tests/native/p3p_screen_probe.cpp mode 3): planar / fronto-parallel / warped / quantised / mis-calibrated maps on which
+four random cells are near-degenerate P3P configurations (double roots of the quartic, collinear or coincident samples) or
+sit next to the tau boundary.  python scripts/dev/screen_adversarial.py [tries per map, default 1e7]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from esac_amd import synthetic as S  # noqa: E402
+from tests.native import build as nb  # noqa: E402
+
+
+def adversarial_maps(H=60, W=80, sub=8, focal=525.0, ppx=320.0, ppy=240.0):
+    """name -> float32 [3,H,W]: scene-coordinate maps that stress the P3P screen (see module docstring)."""
+    xs = np.arange(W) * sub + sub // 2
+    ys = np.arange(H) * sub + sub // 2
+    uu, vv = np.meshgrid(xs.astype(np.float64), ys.astype(np.float64))
+
+    def plane(depth=2.0, tilt=(0.0, 0.0), u=uu, v=vv, f=focal):
+        # points of the plane z = depth + tilt . (x, y) seen through pixel (u, v) of a camera at the origin
+        dx, dy = (u - ppx) / f, (v - ppy) / f
+        z = depth / (1.0 - tilt[0] * dx - tilt[1] * dy)
+        return np.stack([dx * z, dy * z, z]).astype(np.float32)
+
+    rng = np.random.default_rng(77)
+    maps = {}
+    maps["fronto-parallel exact"] = plane()
+    maps["fronto-parallel warped 1.3x0.8"] = plane(u=(uu - ppx) * 1.3 + ppx, v=(vv - ppy) * 0.8 + ppy)
+    maps["tilted plane warped"] = plane(tilt=(0.4, -0.3), u=(uu - ppx) * 0.7 + ppx + 40, v=(vv - ppy) * 1.2 + ppy)
+    maps["plane noise 1e-6"] = plane() + rng.normal(0, 1e-6, (3, H, W)).astype(np.float32)
+    maps["plane focal 600"] = plane(f=600.0)
+    maps["plane shifted 1 cell"] = np.roll(plane(tilt=(0.2, 0.1)), 1, axis=2)
+    maps["plane shifted 2 cells"] = np.roll(plane(tilt=(0.2, 0.1)), 2, axis=2)
+    q = plane(tilt=(0.1, 0.0)).copy()
+    q[0] = np.round(q[0] * 4) / 4  # x quantised to 25 cm: many coincident / collinear samples
+    maps["plane x quantised"] = q
+    line = plane().copy()
+    line[1] = 0.0  # all points on the plane y = 0, z = 2: a line in space per row -> collinear samples
+    maps["points on a line"] = line
+    dx, dy = (uu - ppx) / focal, (vv - ppy) / focal
+    d = np.stack([dx, dy, np.ones_like(dx)])
+    d /= np.linalg.norm(d, axis=0)
+    maps["sphere around the camera (r=2)"] = (2.0 * d).astype(np.float32)  # every scene triangle similar to its bearing triangle
+    maps["sphere warped"] = np.roll((2.0 * d).astype(np.float32), 3, axis=1)
+    f3 = S.make_frame(3)
+    c = f3["coords"][0].copy()
+    maps["room, rows swapped pairwise"] = c[:, np.arange(H) ^ 1, :]
+    maps["room, 1 cell right"] = np.roll(c, 1, axis=2)
+    return maps
+
+
+def run(lib, coords, n, seed, sub=8, focal=525.0, ppx=320.0, ppy=240.0, tau=10.0, margins=(0.5, 1.0, 2.0, 3.0), mode=3):
+    m = np.asarray(margins, np.float32)
+    out = np.zeros(40)
+    c = np.ascontiguousarray(coords, np.float32)
+    _, H, W = c.shape
+    lib.probe_screen(c.ctypes.data_as(C.c_void_p), H, W, sub, 0, 0, C.c_float(focal), C.c_float(ppx), C.c_float(ppy), C.c_float(tau),
+                     C.c_uint64(seed), C.c_longlong(int(n)), m.ctypes.data_as(C.c_void_p), len(m), mode, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+if __name__ == "__main__":
+    n = float(sys.argv[1]) if len(sys.argv) > 1 else 1e7
+    mode = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    lib = C.CDLL(nb.build_screen_probe())
+    tot = rej = 0
+    for k, (name, coords) in enumerate(adversarial_maps().items()):
+        out = run(lib, coords, n, 500 + k, mode=mode)
+        t, acc = out[0], out[1]
+        tot += acc
+        rej += out[15]
+        print("      guards fired (1 A, 2 R2, 3 D2/E2, 4 b0, 5 root, 6 b1, 7 b0 rel, 8 v): " + " ".join("%.4f%%" % (100 * v / t) for v in out[30:38]))
+        print("%-34s accepted %9d (%.2e)  maybe@3px %.5f  delicate %.3f%%  false rejects @0.5/1/2/3 px: %d %d %d %d  max screen err of accepted %.3f" % (
+            name, acc, acc / t, out[7] / t, 100 * out[2] / t, out[12], out[13], out[14], out[15], out[3]))
+    print("total fp64-accepted tries %d, false rejects at the kernel's margin %d" % (tot, rej))

@@ -34,7 +34,7 @@ SCREEN_LIB = os.path.join(HERE, "libp3p_screen_probe.so")
 
 def build_screen_probe(force=False):
     """Host build (OpenMP) of the fp32 sampling screen + the fp64 route it screens for."""
-    deps = [SCREEN_SRC] + [os.path.join(CSRC, h) for h in ("pose_math.hpp", "p3p_screen.hpp", "p3p_coarse.hpp")]
+    deps = [SCREEN_SRC] + [os.path.join(CSRC, h) for h in ("pose_math.hpp", "p3p_screen.hpp")]
     if force or not os.path.exists(SCREEN_LIB) or any(os.path.getmtime(d) > os.path.getmtime(SCREEN_LIB) for d in deps):
         hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

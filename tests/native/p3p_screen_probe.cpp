@@ -8,8 +8,19 @@
 #include <string.h>
 #include <stdio.h>
 
+// which guard of the screen's private copy turned a try into "maybe" (p3p_screen.hpp: ESAC_SCREEN_STAT)
+static thread_local long long g_screen_stat[10];
+#define ESAC_SCREEN_STAT(k) (g_screen_stat[k]++)
+// histograms of -log10 of selected ratios (calibration aid): ESAC_SCREEN_HIST(k, v)
+static long long g_screen_hist[12][24];
+#define ESAC_SCREEN_HIST(k, v)                                                           \
+    do {                                                                                 \
+        const double v_ = (v);                                                           \
+        int bin_ = !(v_ > 0) ? 23 : (int)floor(-log10(v_)) + 2;                          \
+        bin_ = bin_ < 0 ? 0 : bin_ > 22 ? 22 : bin_;                                     \
+        __atomic_fetch_add(&g_screen_hist[k][bin_], 1, __ATOMIC_RELAXED);                \
+    } while (0)
 #include "../../esac_amd/csrc/p3p_screen.hpp"
-#include "../../esac_amd/csrc/p3p_coarse.hpp"
 #include "../../esac_amd/csrc/pose_math.hpp"
 using namespace esac;
 
@@ -38,15 +49,12 @@ static bool accept64(const double Rp[9], const double Tp[3], const float Pf[4][3
     return true;
 }
 
-// modes 4 / 5: the coarse fp32 screen; out has 52 doubles: [29] fp64-accepted tries p3p_coarse_maybe() would drop, [51] tries it keeps,
-// [40..42] largest (err - tau) / (tau * lever) of an accepted try (image / scene / max lever)
 // out[0] tries, [1] accepted by fp64, [2] screen "delicate", [3] largest screen error among fp64-accepted tries,
 // [4 + k] tries the screen keeps ("maybe") at margin margins[k], [12 + k] fp64-accepted tries it would REJECT there;
-// [20] largest |screen err - fp64 4th-point err| over solved tries with fp64 err < 200 px; [21] fp64-solved tries
+// [20] largest |screen err - fp64 4th-point err| over solved tries with fp64 err < 200 px; [21] fp64-solved tries;
+// [30..38] how often guard 1..9 of the private copy (ESAC_SCREEN_STAT) fired
 extern "C" void probe_screen(const float* coords, int H, int W, int sub, int shx, int shy, float f, float cx, float cy, float tau,
                              uint64_t seed, long long n_tries, const float* margins, int n_margins, int mode, double* out) {
-    double* lever_out = (mode == 4 || mode == 5) ? out + 40 : nullptr;  // 12 more doubles in these modes
-    if (lever_out) memset(lever_out, 0, 12 * sizeof(double));
     const int P = H * W;
     const Cam cam{(double)f, (double)f, (double)cx, (double)cy};
     double acc[40];
@@ -55,7 +63,7 @@ extern "C" void probe_screen(const float* coords, int H, int W, int sub, int shx
     {
         double loc[40];
         memset(loc, 0, sizeof(loc));
-        double lever_loc[12] = {0};
+        memset(g_screen_stat, 0, sizeof(g_screen_stat));
         uint64_t s = seed;
 #ifdef _OPENMP
         s += 7919ull * (uint64_t)omp_get_thread_num();
@@ -89,73 +97,7 @@ extern "C" void probe_screen(const float* coords, int H, int W, int sub, int shx
             float e;
             if (mode == 0) {
                 e = p3p_screen_err(Pf, muf, mvf, f, cx, cy, &reason);
-            } else if (mode == 4 || mode == 5) {  // the coarse fp32 screen (p3p_coarse.hpp); 5 = also print false rejects
-                e = p3p_coarse_err(Pf, muf, mvf, f, cx, cy, &reason);
-                if (reason >= 10 && reason < 20) loc[30 + reason - 10] += 1;
-                if (lever_out) {  // the shipped rule
-                    const bool mb = p3p_coarse_maybe(Pf, muf, mvf, f, cx, cy, tau);
-                    lever_loc[11] += mb;
-                    if (ok && !mb) loc[29] += 1;
-                }
-                if (lever_out) {  // lever arms of the 4th point: image-side barycentrics, scene-side barycentrics + out-of-plane
-                    auto bary = [](double ax, double ay, double bx, double by, double cx_, double cy_, double px_, double py_) {
-                        const double d = (bx - ax) * (cy_ - ay) - (cx_ - ax) * (by - ay);
-                        const double w1 = ((px_ - ax) * (cy_ - ay) - (cx_ - ax) * (py_ - ay)) / d;
-                        const double w2 = ((bx - ax) * (py_ - ay) - (px_ - ax) * (by - ay)) / d;
-                        return fabs(1 - w1 - w2) + fabs(w1) + fabs(w2);
-                    };
-                    const double l_img = bary(muf[0], mvf[0], muf[1], mvf[1], muf[2], mvf[2], muf[3], mvf[3]);
-                    ScreenScene scn;
-                    double l_sc = 1e30;
-                    if (screen_scene(Pf, scn)) {
-                        const double x1 = sqrt((double)scn.l1);
-                        const double pe2x = Pf[2][0] - Pf[0][0], pe2y = Pf[2][1] - Pf[0][1], pe2z = Pf[2][2] - Pf[0][2];
-                        const double x2 = pe2x * scn.e1.x + pe2y * scn.e1.y + pe2z * scn.e1.z, y2 = pe2x * scn.e2.x + pe2y * scn.e2.y + pe2z * scn.e2.z;
-                        const double alt = x1 * fabs(y2) / sqrt(fmax(scn.l1, fmax(scn.l2, scn.l3)));
-                        l_sc = bary(0, 0, x1, 0, x2, y2, scn.c1, scn.c2) + fabs(scn.c3) / alt;
-                    }
-                    const double lam = l_img;
-                    if (ok && e != ESAC_SCREEN_MAYBE && e > tau && e < 1e30f) {
-                        const double r1 = (e - tau) / (tau * l_img), r2 = (e - tau) / (tau * l_sc), r3 = (e - tau) / (tau * lam);
-                        if (r1 > lever_loc[0]) lever_loc[0] = r1;
-                        if (r2 > lever_loc[1]) lever_loc[1] = r2;
-                        if (r3 > lever_loc[2]) lever_loc[2] = r3;
-                    }
-                    for (int k = 0; k < 4; k++) {  // maybe-rate under e <= tau (1 + kappa lam) + 5, kappa = 1, 2, 3, 4
-                        const bool mb = e == ESAC_SCREEN_MAYBE || !(e > tau * (1 + (k + 1) * lam) + 5.0);
-                        lever_loc[3 + k] += mb;
-                        lever_loc[7 + k] += ok && !mb;
-                    }
-                }
-                if (ok && e != ESAC_SCREEN_MAYBE && !(e <= tau + 2.0f)) {  // disagreement: how thin was the base triangle?
-                    float a3[3], a2[3];
-                    for (int k = 0; k < 3; k++) {
-                        const int i0 = k == 2 ? 1 : 0, i1 = k == 0 ? 1 : 2;
-                        a3[k] = 0;
-                        for (int c = 0; c < 3; c++) a3[k] += (Pf[i0][c] - Pf[i1][c]) * (Pf[i0][c] - Pf[i1][c]);
-                        a2[k] = (muf[i0] - muf[i1]) * (muf[i0] - muf[i1]) + (mvf[i0] - mvf[i1]) * (mvf[i0] - mvf[i1]);
-                    }
-                    const double r3 = fmin(a3[0], fmin(a3[1], a3[2])) / fmax(a3[0], fmax(a3[1], a3[2]));
-                    const double r2 = fmin(a2[0], fmin(a2[1], a2[2])) / fmax(a2[0], fmax(a2[1], a2[2]));
-                    if (mode == 5) {
-#pragma omp critical
-                        {
-                            printf("DISAGREE e=%g e64=%g r3=%g r2=%g minpx=%g\n", e, sqrt(reproj2), r3, r2, sqrt(fmin(a2[0], fmin(a2[1], a2[2]))));
-                            if (e > tau + 6) for (int j = 0; j < 4; j++) printf("   Q %a %a %a %.1f %.1f\n", Pf[j][0], Pf[j][1], Pf[j][2], muf[j], mvf[j]);
-                        }
-                    }
-                }
-                if (mode == 5 && ok && e != ESAC_SCREEN_MAYBE && !(e <= tau + 20.0f)) {
-#pragma omp critical
-                    {
-                        static int shown5 = 0;
-                        if (shown5++ < 12) {
-                            printf("FALSE REJECT coarse e=%g fp64 e=%g\n", e, sqrt(reproj2));
-                            for (int j = 0; j < 4; j++) printf("   P %a %a %a %.1f %.1f\n", Pf[j][0], Pf[j][1], Pf[j][2], muf[j], mvf[j]);
-                        }
-                    }
-                }
-            } else if (mode == 3 || mode == 7) {  // 7 = also print false rejects  // what k_sample_fine / k_sample_prescreen / k_sample_screened run: the screen's private fast copy of the roots
+            } else if (mode == 3 || mode == 7) {  // 7 = also print false rejects; what k_sample_prescreen / k_sample_screened run: the screen's private fast copy of the roots
                 ScreenSetup S;
                 e = screen_setup(Pt, mu, mv, cam, S) ? p3p_screen_roots(S, Pf, muf[3], mvf[3], f, cx, cy) : INFINITY;
                 if (mode == 7 && ok && e != ESAC_SCREEN_MAYBE && !(e <= tau + 3.0f)) {
@@ -209,9 +151,9 @@ extern "C" void probe_screen(const float* coords, int H, int W, int sub, int shx
                 }
             }
         }
+        for (int k = 1; k < 10; k++) loc[29 + k] = (double)g_screen_stat[k];  // out[30..38]: guards 1..9 of the private copy
 #pragma omp critical
         {
-            if (lever_out) for (int k = 0; k < 12; k++) lever_out[k] = k < 3 ? fmax(lever_out[k], lever_loc[k]) : lever_out[k] + lever_loc[k];
             for (int k = 0; k < 40; k++) {
                 if (k == 3 || k == 20) acc[k] = loc[k] > acc[k] ? loc[k] : acc[k];
                 else acc[k] += loc[k];
@@ -226,7 +168,13 @@ extern "C" void probe_screen(const float* coords, int H, int W, int sub, int shx
 extern "C" void probe_quartic(double a, double b, double c, double d, double e, double* out) {
     double x[4] = {0, 0, 0, 0}, y[4] = {0, 0, 0, 0};
     out[0] = quartic_real_roots(a, b, c, d, e, x[0], x[1], x[2], x[3]);
-    out[5] = quartic_roots_fast(a, b, c, d, e, y[0], y[1], y[2], y[3]);
+    float rel[2] = {0, 0};
+    out[5] = quartic_roots_fast(a, b, c, d, e, 0, 0, 0, 0, 0, y[0], y[1], y[2], y[3], rel[0], rel[1]);
     for (int i = 0; i < 4; i++) { out[1 + i] = x[i]; out[6 + i] = y[i]; }
 }
 
+
+extern "C" void probe_hist(long long* out, int clear) {
+    memcpy(out, g_screen_hist, sizeof(g_screen_hist));
+    if (clear) memset(g_screen_hist, 0, sizeof(g_screen_hist));
+}

@@ -53,6 +53,8 @@ def _worker(rank, world, port, policy, q):
         if policy == "range":
             lo, hi = D.shard_range(n_total, rank, world)
             gidx = np.arange(lo, hi)
+        elif policy == "balanced":
+            gidx = D.shard_balanced_host(ha, rank, world, E=4)[0].astype(np.int64)
         else:
             gidx = D.shard_by_expert(ha, rank, world).astype(np.int64)
         scores_l, rec_l = _oracle_local(O, f, ha, gidx, call=4)
@@ -66,7 +68,7 @@ def _worker(rank, world, port, policy, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,policy", [(2, "range"), (2, "expert"), (3, "range")])
+@pytest.mark.parametrize("world,policy", [(2, "range"), (2, "expert"), (3, "range"), (2, "balanced"), (3, "balanced")])
 def test_sharded_forward_matches_single_process(oracle, world, policy):
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -98,6 +100,47 @@ def test_shard_helpers():
     parts = [D.shard_by_expert(ha, r, 2) for r in range(2)]
     assert sorted(np.concatenate(parts).tolist()) == list(range(8))
     assert all((ha[p] % 2 == r).all() for r, p in enumerate(parts))
+
+
+def _bench_assignments(cfg):
+    """The assignment vectors bench.py draws for a preset (same generators, same frames)."""
+    E, N, mode = {"cfg4": (12, 4096, "gating"), "cfg5a": (50, 16384, "dirichlet")}[cfg]
+    out = []
+    for k in range(3):
+        f = S.make_frame(k, E=E, H=6, W=8)  # the gating draw does not depend on the grid
+        out.append((E, S.gating_assignment(f, N, mode=mode)))
+    return out
+
+
+@pytest.mark.parametrize("cfg,world", [("cfg4", 4), ("cfg5a", 8), ("cfg4", 3), ("cfg5a", 5)])
+def test_balanced_policy_balances_where_expert_ownership_does_not(cfg, world):
+    """"a load-balanced assignment from the hypAssignment histogram".  On the bench's own generators the
+    e % world split puts most hypotheses on one rank (cfg4 on 4 ranks: ~3990 of 4096); the balanced split gives every
+    rank N / world (+-1), is a partition of the hypotheses, keeps a rank's experts contiguous and shares only the
+    experts at the cuts."""
+    for E, ha in _bench_assignments(cfg):
+        n = len(ha)
+        parts = [D.shard_balanced_host(ha, r, world, E=E) for r in range(world)]
+        sizes = np.array([len(idx) for idx, _ in parts])
+        assert sizes.max() / sizes.mean() <= 1.10 and sizes.max() - sizes.min() <= 1
+        assert sorted(np.concatenate([idx for idx, _ in parts]).tolist()) == list(range(n))
+        plan = D.plan_balanced(np.bincount(ha, minlength=E), world)
+        for r, (idx, rng) in enumerate(parts):
+            assert rng == plan[r]                                   # the histogram alone gives every rank's expert range
+            assert ha[idx].min() == rng[0] and ha[idx].max() == rng[1]
+            assert (np.diff(ha[idx]) >= 0).all()                    # (expert, index) order
+            if r:
+                assert plan[r][0] >= plan[r - 1][1]                 # ranges only touch at the cut experts
+        naive = np.array([len(D.shard_by_expert(ha, r, world)) for r in range(world)])
+        assert naive.max() / naive.mean() > 1.10                    # what the e % world split does on the same vector
+
+
+def test_plan_balanced_edge_cases():
+    assert D.plan_balanced([0, 5, 0], 2) == [(1, 1), (1, 1)]            # one expert, split by index
+    assert D.plan_balanced([2, 0, 2], 2) == [(0, 0), (2, 2)]            # empty experts in between are nobody's
+    assert D.plan_balanced([1, 1], 4) == [(0, 0), (1, 1), (0, -1), (0, -1)]  # more ranks than hypotheses
+    idx, rng = D.shard_balanced_host(np.array([7, -1, 1, 1]), 0, 2, E=2)  # out-of-range values count as expert 0
+    assert idx.tolist() == [0, 1] and rng == (0, 0)
 
 
 def test_pick_global_tie_rule_and_empty_shards():

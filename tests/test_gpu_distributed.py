@@ -16,7 +16,7 @@ from esac_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("policy", ["range", "expert"])
+@pytest.mark.parametrize("policy", ["range", "expert", "balanced"])
 def test_forward_sharded_world1_matches_plain(engine, policy):
     import torch.distributed as dist
     s = socket.socket()
@@ -73,6 +73,76 @@ def test_range_contributions_of_several_ranks_on_one_device(engine, world):
     np.testing.assert_allclose(got[~flags], full[~flags], rtol=0, atol=2e-3)
 
 
+@pytest.mark.parametrize("N,E,world", [(250, 3, 2), (4096, 12, 4), (16384, 50, 8), (5, 2, 8), (1000, 1, 3), (777, 4096, 5)])
+def test_device_built_shard_equals_the_host_plan(engine, N, E, world):
+    """esac_hip_shard_balanced (one launch, no host round trip) against its CPU mirror: every rank's index SET, its
+    local assignment, its expert range and n_local -- incl. more ranks than hypotheses, a single expert split by index,
+    the 4096-expert limit and out-of-range values (counted as expert 0, copied unchanged)."""
+    rng = np.random.default_rng(N + E)
+    p = rng.dirichlet(np.full(E, 0.3)) if E > 1 else np.ones(1)
+    ha = rng.choice(E, size=N, p=p).astype(np.int64)
+    if N > 100:
+        ha[17], ha[N // 2] = -3, E + 5
+    hat = torch.from_numpy(ha).cuda()
+    seen = []
+    for rank in range(world):
+        ref_idx, ref_rng = D.shard_balanced_host(ha, rank, world, E=E)
+        for base_mode in (0, 1):
+            base = ref_rng[0] if base_mode and len(ref_idx) else 0
+            gidx, ha_local, info = engine.shard_balanced(hat, world, rank, E, expert_base=base)
+            torch.cuda.synchronize()
+            g, hl, info = gidx.cpu().numpy(), ha_local.cpu().numpy(), info.cpu().numpy()
+            assert len(g) == len(ref_idx) == info[2]
+            assert sorted(g.tolist()) == sorted(ref_idx.tolist())
+            raw = ha[g]
+            ok = (raw >= 0) & (raw < E)
+            np.testing.assert_array_equal(hl[ok], raw[ok] - base)
+            np.testing.assert_array_equal(hl[~ok], raw[~ok])       # out-of-range values travel unchanged
+            if len(g):
+                assert (int(info[0]), int(info[1])) == ref_rng
+                e_clamped = np.where(ok, raw, 0)
+                assert (np.diff(e_clamped) >= 0).all()             # sorted by expert inside the shard
+            assert int(info[3]) == int(((ha < 0) | (ha >= E)).any())
+        seen.append(g)
+    assert sorted(np.concatenate(seen).tolist()) == list(range(N))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_balanced_contributions_of_several_ranks_on_one_device(engine, world):
+    """The per-rank half of the balanced exchange for every rank of a `world`-rank job, one after the other on this box's
+    single GPU (summing the buffers is what the all-reduce does), with the real per-frame path: device-built shard, scores
+    written by global index, record with the global expert id -- full maps and owned expert ranges."""
+    E, N = 6, 1500
+    f = S.make_frame(63, E=E, true_expert=4)
+    ha = S.gating_assignment(f, N, mode="dirichlet")
+    ha[::7] = 4
+    sc_full = torch.from_numpy(f["coords"]).cuda()
+    hat = torch.from_numpy(ha).cuda()
+    kw = dict(seed=1305, call=11)
+    res = engine.forward_device(sc_full, hat, engine.make_params(E, 60, 80, N, **kw))
+    flags = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
+    full = engine.read(api.BUF_SCORES)
+    plan = D.plan_balanced(np.bincount(ha, minlength=E), world)
+    for maps in ("full", "owned"):
+        total = torch.zeros(N + world * D.RES_DOUBLES, dtype=torch.float64, device="cuda")
+        for rank in range(world):
+            pk = dict(kw)
+            sc = sc_full
+            if maps == "owned":
+                first, last = plan[rank]
+                sc = sc_full[first:last + 1].contiguous()
+                pk.update(total_experts=E, expert_range=(first, last))
+            total_experts = pk.pop("total_experts", None)
+            total += D.contribute_balanced(engine, sc, hat, pk, total_experts, rank, world, maps)
+        scores_g, best = D.pick_global(total, N, world)
+        assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]) and int(best[api.RES_EXPERT]) == int(res[api.RES_EXPERT]), maps
+        np.testing.assert_array_equal(best[api.RES_POSE:api.RES_POSE + 16], res[api.RES_POSE:api.RES_POSE + 16])
+        assert best[api.RES_SCORE] == res[api.RES_SCORE]
+        got = scores_g.cpu().numpy()
+        np.testing.assert_array_equal(got[flags], full[flags])
+        np.testing.assert_allclose(got[~flags], full[~flags], rtol=0, atol=2e-3)
+
+
 def _two_rank_worker(rank, world, port, policy, q):
     """One of `world` processes sharing this box's single GPU: own engine / context, gloo group (RCCL refuses two
     ranks on one device), the real forward_sharded."""
@@ -87,9 +157,15 @@ def _two_rank_worker(rank, world, port, policy, q):
         f = S.make_frame(62, E=3, true_expert=1)
         ha = torch.from_numpy(S.gating_assignment(f, 250, mode="gating")).cuda()
         maps = "full"
+        extra = {}
         if policy == "expert-owned":  # this rank holds ONLY its experts' maps (e % world == rank)
             policy, maps = "expert", "owned"
             sc = torch.from_numpy(np.ascontiguousarray(f["coords"][D.owned_experts(3, rank, world)])).cuda()
+        elif policy == "balanced-owned":  # ... only the maps of its expert range under the balanced plan
+            policy, maps = "balanced", "owned"
+            first, last = D.plan_balanced(np.bincount(ha.cpu().numpy(), minlength=3), world)[rank]
+            sc = torch.from_numpy(np.ascontiguousarray(f["coords"][first:last + 1])).cuda()
+            extra = dict(expert_range=(first, last))
         else:
             sc = torch.from_numpy(f["coords"]).cuda()
         out = []
@@ -97,6 +173,7 @@ def _two_rank_worker(rank, world, port, policy, q):
             kw = dict(seed=1305, call=call)
             if maps == "owned":
                 kw["total_experts"] = 3
+            kw.update(extra)
             scores_g, best = D.forward_sharded(eng, sc, ha, kw, policy=policy, maps=maps)
             out.append((scores_g.cpu().numpy().copy(), best.copy()))
         q.put((rank, out))
@@ -104,7 +181,8 @@ def _two_rank_worker(rank, world, port, policy, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,policy", [(2, "range"), (3, "range"), (2, "expert"), (2, "expert-owned"), (3, "expert-owned")])
+@pytest.mark.parametrize("world,policy", [(2, "range"), (3, "range"), (2, "expert"), (2, "expert-owned"), (3, "expert-owned"),
+                                          (2, "balanced"), (3, "balanced"), (2, "balanced-owned"), (3, "balanced-owned")])
 def test_forward_sharded_across_processes_on_one_device(engine, world, policy):
     """The whole multi-rank path as the bench drives it -- forward_sharded in `world` processes, one collective per
     frame -- with gloo standing in for RCCL: every rank ends with the same winner, and it is the unsharded winner."""
@@ -168,10 +246,14 @@ def test_bench_multi_rank_path_on_one_device():
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_expert_sharded_strong_scaling_on_one_device(world):
-    """BASELINE configs[3] as the driver would run it on several GPUs: experts (and their maps) owned by rank e % world,
-    hypotheses sharded by expert ownership, strong scaling -- here 2 and 3 ranks on the one GPU."""
+    """BASELINE configs[3] as the driver would run it on several GPUs: the load-balanced split (every rank N / world
+    hypotheses of a contiguous expert range, holding only those experts' maps, shard built on the device inside the
+    step), strong scaling -- here 2 and 3 ranks on the one GPU."""
     d = _run_bench(world, ["--config", "cfg4", "--steps", "6", "--warmup", "2"])
-    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["policy"] == "expert"
-    assert d["config"]["hypotheses_total"] == 4096 and sum(d["config"]["shard_sizes"]) == 4096 and len(d["config"]["shard_sizes"]) == world
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["policy"] == "balanced"
+    sizes = d["config"]["shard_sizes"]
+    assert d["config"]["hypotheses_total"] == 4096 and sum(sizes) == 4096 and len(sizes) == world
+    assert max(sizes) / (sum(sizes) / world) <= 1.10
     assert d["value"] > 0 and abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert "only its own experts' maps" in d["config"]["parallelism"]
+    assert "only the maps of its own expert range" in d["config"]["parallelism"]
+    assert d["shard_build_ms"] is not None and d["shard_build_ms"] > 0  # built per frame, inside the timed step

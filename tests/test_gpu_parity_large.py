@@ -121,3 +121,20 @@ def test_packed_map_copy_for_the_sampler(engine, oracle):
     ref2 = oracle.forward(f["coords"], ha2, **kw)
     res2 = engine.forward_device(sc, torch.from_numpy(ha2).cuda(), engine.make_params(3, 120, 160, 300, pack_maps=True, **kw))
     _check_full(engine, res2, ref2)
+
+
+def test_config5b_true_50_experts_16384_hypotheses_full_resolution(engine, oracle):
+    """BASELINE configs[4] itself -- 50 experts, Dirichlet(0.3) gating, 16384 hypotheses, 480x640 maps (subSampling 1) --
+    the one call in which the packed map copy of the sampler (default trigger: E*P*12 >= 32 MB), the tile-stationary score
+    with dozens of chunks per expert, the 16-way split selection and the cooperating refinement workgroups all run
+    together: the FULL forward against the oracle, stage by stage (5.0e9 cell evaluations: ~20 s of the host's cores)."""
+    E, N, H, W = 50, 16384, 480, 640
+    f = S.make_frame(230, E=E, true_expert=11, H=H, W=W, sub=1)
+    ha = S.gating_assignment(f, N, mode="dirichlet")
+    ha[::131] = 11  # the Dirichlet draw may starve the true expert: keep ~125 hypotheses on it
+    assert E * H * W * 12 >= 32 << 20  # the default want_pack trigger (esac_capi.hip) fires: no flag is passed below
+    res, ref = _run_both(engine, oracle, f, ha, call=6)
+    _check_full(engine, res, ref)
+    assert ref["expert"] == 11 and ref["tries"].max() > 64
+    assert ref["ref_steps"] >= 1 and ref["inlier_counts"][0] > 100000  # 38 cooperating workgroups refine 307,200 cells
+    engine.check()  # neither an out-of-range assignment nor a barrier time-out

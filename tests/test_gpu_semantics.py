@@ -7,6 +7,7 @@ import torch
 
 from esac_amd import api
 from esac_amd import synthetic as S
+from tests.test_gpu_parity import _check_full, _run_both
 
 pytestmark = pytest.mark.gpu
 
@@ -277,3 +278,147 @@ def test_bench_default_line_has_the_contract_fields():
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] in ("port", "reference")
     assert d["accuracy"]["winner_match"] == 1.0 and d["accuracy"]["max_rot_err_rad"] <= 1e-4 and d["accuracy"]["max_trans_err_m"] <= 1e-3
     assert [k["stage"] for k in d["kernels"]] == ["sample", "score", "select_rescore", "refine"]
+
+
+def _adversarial_frame(kind, E=3):
+    """Maps on which four random cells are near-degenerate P3P configurations (scripts/dev/screen_adversarial.py): experts
+    1.. hold planar / spherical / warped maps that are INCONSISTENT with the pixel grid, so their hypotheses need many
+    tries and walk the screened chain; expert 0 is an ordinary room."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "screen_adversarial", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "dev", "screen_adversarial.py"))
+    A = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(A)
+    maps = A.adversarial_maps()
+    f = S.make_frame(300, E=E, true_expert=0)
+    names = {"planar": ["fronto-parallel warped 1.3x0.8", "tilted plane warped"],
+             "degenerate": ["plane x quantised", "points on a line"],
+             "curved": ["sphere warped", "room, rows swapped pairwise"]}[kind]
+    for e, n in enumerate(names, start=1):
+        f["coords"][e] = maps[n]
+    return f
+
+
+@pytest.mark.parametrize("kind", ["planar", "degenerate", "curved"])
+def test_screened_sampling_on_adversarial_geometry(engine, oracle, kind):
+    """The sampling screen (p3p_screen.hpp) on the geometry that breaks a naive one: wrong-expert hypotheses on planar /
+    fronto-parallel / quantised / collinear / spherical maps -- near-double roots of the P3P quartic, collinear and
+    coincident samples -- in numbers that run the whole screened chain (N = 6144: k_sample_first x2, prescreen, decide,
+    commit, resume).  The accepted try and the sampled cells must be the oracle's, bit for bit, and the unscreened route
+    (ESAC_FLAG_EXACT_SAMPLING) must give the same.  ~1e7 tries per case on the degenerate maps (budget capped)."""
+    f = _adversarial_frame(kind)
+    N = 6144
+    ha = np.arange(N, dtype=np.int64) % 3
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    kw = dict(focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=77, call=3, max_tries=20000)
+    ref = oracle.forward(f["coords"], ha, **kw)
+    out = {}
+    for exact in (False, True):
+        p = engine.make_params(3, 60, 80, N, exact_sampling=exact, **kw)
+        engine.sample(sc, hat, p)
+        out[exact] = (engine.read(api.BUF_TRIES), engine.read(api.BUF_SAMPLE_XY), engine.read(api.BUF_HYPS))
+    np.testing.assert_array_equal(out[False][0], out[True][0])   # screened == unscreened on the device
+    np.testing.assert_array_equal(out[False][1], out[True][1])
+    np.testing.assert_array_equal(out[False][2], out[True][2])
+    np.testing.assert_array_equal(out[False][0], ref["tries"])    # == the oracle
+    np.testing.assert_array_equal(out[False][1], ref["sample_xy"])
+    tries = np.where(ref["tries"] < 0, 20000, ref["tries"] + 1)
+    assert tries.sum() > 2e5 and (ref["tries"][ha > 0] > 64).any()  # the screened chain really ran
+
+
+def test_exact_sampling_flag_is_the_reference_loop(engine, oracle):
+    """ESAC_FLAG_EXACT_SAMPLING / esac.set_exact_sampling: no screen anywhere -- and nothing else changes: full forward
+    against the oracle at the shapes that otherwise hand stragglers to the screened chain (latency shape with several
+    experts, throughput shape)."""
+    import esac
+    for N, seed in ((512, 5), (6000, 6)):
+        f = S.make_frame(310 + seed, E=4, true_expert=2)
+        ha = S.gating_assignment(f, N, mode="dirichlet")
+        ha[::5] = 2
+        res, ref = _run_both(engine, oracle, f, ha, seed=seed, call=2, exact_sampling=True)
+        _check_full(engine, res, ref)
+    f = S.make_frame(312, E=2, true_expert=1)
+    ha = S.gating_assignment(f, 300, mode="gating")
+    pose_a, pose_b = torch.zeros(4, 4), torch.zeros(4, 4)
+    args = (0, 0, f["focal"], f["ppx"], f["ppy"], 10.0, 100.0, 0.5, 100.0, f["sub"])
+    try:
+        esac.set_seed(9, 0)
+        ea = esac.forward(torch.from_numpy(f["coords"]), torch.from_numpy(ha), pose_a, *args)
+        esac.set_exact_sampling(True)
+        esac.set_seed(9, 0)
+        eb = esac.forward(torch.from_numpy(f["coords"]), torch.from_numpy(ha), pose_b, *args)
+    finally:
+        esac.set_exact_sampling(False)
+    assert ea == eb and torch.equal(pose_a, pose_b)
+
+
+def test_status_word_follows_the_sampling_launch_not_the_last_call(engine):
+    """An out-of-range hypAssignment (device-resident tensor) is reported for the launch that SAMPLED it: by a staged
+    refine that runs several entry points later, by esac_hip_check after an asynchronous call followed by other entry
+    points (pick_record bumps the context's epoch) -- and no longer once a clean call has sampled."""
+    f = S.make_frame(320, E=2, true_expert=1)
+    ha = S.gating_assignment(f, 128, mode="gating")
+    bad = ha.copy()
+    bad[5] = 7
+    sc = torch.from_numpy(f["coords"]).cuda()
+    p = engine.make_params(2, 60, 80, 128, seed=3, call=1)
+    rec = torch.zeros(64, dtype=torch.float64, device="cuda")
+    engine.forward_device(sc, torch.from_numpy(bad).cuda(), p, result_out=rec[:32], want_host=False)
+    engine.pick_record(rec, 2)  # another entry point in between
+    with pytest.raises(RuntimeError, match="outside"):
+        engine.check()
+    # staged: sample (flags it) ... refine delivers the status to a later blocking call's record
+    for stage in (engine.sample, engine.score, engine.select):
+        stage(sc, torch.from_numpy(bad).cuda(), p)
+    with pytest.raises(RuntimeError, match="outside"):
+        engine.check()
+    engine.forward_device(sc, torch.from_numpy(ha).cuda(), p)  # a clean call
+    engine.check()
+
+
+def test_blocking_wait_modes_agree(engine):
+    """esac_hip_set_wait: spin (default), yield and block deliver the same record."""
+    f = S.make_frame(321)
+    ha = S.gating_assignment(f, 256)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    recs = []
+    try:
+        for mode in (api.WAIT_SPIN, api.WAIT_YIELD, api.WAIT_BLOCK):
+            engine.set_wait(mode)
+            recs.append(engine.forward_device(sc, hat, engine.make_params(1, 60, 80, 256, seed=4, call=4)).copy())
+    finally:
+        engine.set_wait(api.WAIT_SPIN)
+    np.testing.assert_array_equal(recs[0], recs[1])
+    np.testing.assert_array_equal(recs[0], recs[2])
+    with pytest.raises(RuntimeError):
+        engine.set_wait(7)
+
+
+def test_cooperative_refinement_reports_a_barrier_time_out(engine):
+    """The cooperating refinement workgroups of a large-grid call must all be resident; when one never arrives (a shared
+    or partitioned GPU) the barrier times out ONCE (the counter is poisoned: every later barrier falls through), the
+    blocking call fails with status -12, an asynchronous call leaves a record WITHOUT the valid marker and
+    esac_hip_check reports it.  ESAC_DEBUG_COOP_STALL makes the barrier wait for one workgroup more than was launched."""
+    import time
+    f = S.make_frame(322, H=120, W=160, sub=4)
+    ha = S.gating_assignment(f, 64)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    p = engine.make_params(1, 120, 160, 64, seed=2, call=2)
+    good = engine.forward_device(sc, hat, p).copy()
+    engine.set_debug(coop_stall=True)
+    try:
+        t0 = time.time()
+        with pytest.raises(RuntimeError, match="status -12"):
+            engine.forward_device(sc, hat, p)
+        assert time.time() - t0 < 5.0  # one bounded spin, not one per barrier
+        rec = torch.full((32,), 7.0, dtype=torch.float64, device="cuda")
+        engine.forward_device(sc, hat, p, result_out=rec, want_host=False)
+        with pytest.raises(RuntimeError, match="status -12"):
+            engine.check()
+        assert float(rec[31]) == 0.0  # no ESAC_RES_VALID on a failed record
+    finally:
+        engine.set_debug()
+    again = engine.forward_device(sc, hat, p)
+    np.testing.assert_array_equal(again, good)  # the context recovers
+    engine.check()

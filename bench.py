@@ -295,7 +295,7 @@ def main():
         if plans is not None:
             pk["expert_range"] = plans[k]
         _, rec = D.forward_sharded(eng, d_coords[k], d_assign[k], pk, policy=policy, maps="owned" if owned else "full",
-                                   timers=ar_timers if i % PHASE_EVERY == 0 else None)
+                                   timers=ar_timers if (i - warmup) % PHASE_EVERY == 0 else None)
         return rec
 
     def sync():

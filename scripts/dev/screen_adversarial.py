@@ -40,13 +40,29 @@ def adversarial_maps(H=60, W=80, sub=8, focal=525.0, ppx=320.0, ppy=240.0):
     q[0] = np.round(q[0] * 4) / 4  # x quantised to 25 cm: many coincident / collinear samples
     maps["plane x quantised"] = q
     line = plane().copy()
-    line[1] = 0.0  # all points on the plane y = 0, z = 2: a line in space per row -> collinear samples
+    line[1] = 0.0  # y = 0, z = 2: EVERY point on one line in space -> every sample exactly collinear.  Known divergence of
+    # the device's exact route from the oracle here: Horn's eigenvector alignment returns a pose with
+    # an arbitrary roll about the line, which reprojects four collinear points correctly and is accepted by the reference
+    # ~2e-5 of the time; the device's triad alignment yields NaN and never accepts.  Host probe only.
     maps["points on a line"] = line
     dx, dy = (uu - ppx) / focal, (vv - ppy) / focal
     d = np.stack([dx, dy, np.ones_like(dx)])
     d /= np.linalg.norm(d, axis=0)
     maps["sphere around the camera (r=2)"] = (2.0 * d).astype(np.float32)  # every scene triangle similar to its bearing triangle
     maps["sphere warped"] = np.roll((2.0 * d).astype(np.float32), 3, axis=1)
+    # low acceptance (1e-4 .. 1e-2 per try): hypotheses on these walk the screened chain for thousands of tries
+    maps["plane warped 3x0.33 tilted"] = plane(tilt=(0.5, 0.2), u=(uu - ppx) * 3.0 + ppx, v=(vv - ppy) * 0.33 + ppy)
+    maps["plane warped 2x0.5"] = plane(u=(uu - ppx) * 2.0 + ppx, v=(vv - ppy) * 0.5 + ppy)
+    nl = plane().copy()
+    nl[1] = rng.normal(0, 1e-3, (H, W))
+    nl[2] = 2 + rng.normal(0, 1e-3, (H, W))
+    maps["points within 1 mm of a line"] = nl.astype(np.float32)  # every sample a sliver triangle
+    qw = plane(u=(uu - ppx) * 1.6 + ppx, v=(vv - ppy) * 0.6 + ppy).copy()
+    qw[0], qw[1] = np.round(qw[0] * 4) / 4, np.round(qw[1] * 4) / 4
+    maps["plane warped, x and y quantised"] = qw  # coincident and collinear samples
+    dw = np.stack([(uu - ppx) * 2.0 / focal, (vv - ppy) * 0.5 / focal, np.ones_like(uu)])
+    dw /= np.linalg.norm(dw, axis=0)
+    maps["sphere warped 2x0.5"] = (2.0 * dw).astype(np.float32)
     f3 = S.make_frame(3)
     c = f3["coords"][0].copy()
     maps["room, rows swapped pairwise"] = c[:, np.arange(H) ^ 1, :]

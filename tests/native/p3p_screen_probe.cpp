@@ -178,3 +178,56 @@ extern "C" void probe_hist(long long* out, int clear) {
     memcpy(out, g_screen_hist, sizeof(g_screen_hist));
     if (clear) memset(g_screen_hist, 0, sizeof(g_screen_hist));
 }
+
+// ---- the sampling loop of k_sample on the host (device math compiled for the host, glibc's libm): first accepted try of
+// hypothesis gh under the Philox stream (seed, call), -1 when the budget is spent.  Used to tell apart "the device's
+// ALGORITHM differs from the oracle's" from "the device's libm / contraction differs" (scripts/dev/exact_route_probe.py).
+static inline uint32_t umulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static void philox_block(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = umulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = umulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+static void draw_cells_host(uint64_t seed, uint64_t call, uint32_t hyp, uint32_t tr, int W, int H, int cx[4], int cy[4]) {
+    const uint64_t key = seed + call * 0x9E3779B97F4A7C15ull;
+    int have = 0;
+    for (uint32_t k = 0; have < 4; k++) {
+        uint32_t o[4];
+        philox_block((uint32_t)key, (uint32_t)(key >> 32), hyp, tr, k, 0x45534143u, o);
+        for (int half = 0; half < 2 && have < 4; half++) {
+            const int x = (int)umulhi32(o[2 * half], (uint32_t)(W - 1)), y = (int)umulhi32(o[2 * half + 1], (uint32_t)(H - 1));
+            bool dup = false;
+            for (int j = 0; j < have; j++) dup |= cx[j] == x && cy[j] == y;
+            if (!dup) { cx[have] = x; cy[have] = y; have++; }
+        }
+    }
+}
+extern "C" void probe_first_accept(const float* coords, int H, int W, int sub, float f, float cx, float cy, float tau, uint64_t seed, uint64_t call,
+                                   const int* hyps, int n_hyps, int max_tries, int* tries_out) {
+    const int P = H * W;
+    const Cam cam{(double)f, (double)f, (double)cx, (double)cy};
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int i = 0; i < n_hyps; i++) {
+        int found = -1;
+        for (int t = 0; t < max_tries && found < 0; t++) {
+            int cxs[4], cys[4];
+            draw_cells_host(seed, call, (uint32_t)hyps[i], (uint32_t)t, W, H, cxs, cys);
+            float Pf[4][3];
+            V3 Pt[4];
+            double mu[4], mv[4];
+            for (int j = 0; j < 4; j++) {
+                const int idx = cys[j] * W + cxs[j];
+                Pf[j][0] = coords[idx]; Pf[j][1] = coords[P + idx]; Pf[j][2] = coords[2 * P + idx];
+                Pt[j] = V3{(double)Pf[j][0], (double)Pf[j][1], (double)Pf[j][2]};
+                mu[j] = (float)(cxs[j] * sub + sub / 2); mv[j] = (float)(cys[j] * sub + sub / 2);
+            }
+            double Rp[9], Tp[3], reproj2 = 0;
+            if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2) && accept64(Rp, Tp, Pf, mu, mv, cam, (double)tau)) found = t;
+        }
+        tries_out[i] = found;
+    }
+}

@@ -292,9 +292,9 @@ def _adversarial_frame(kind, E=3):
     spec.loader.exec_module(A)
     maps = A.adversarial_maps()
     f = S.make_frame(300, E=E, true_expert=0)
-    names = {"planar": ["fronto-parallel warped 1.3x0.8", "tilted plane warped"],
-             "degenerate": ["plane x quantised", "points on a line"],
-             "curved": ["sphere warped", "room, rows swapped pairwise"]}[kind]
+    names = {"planar": ["plane warped 3x0.33 tilted", "plane warped 2x0.5"],
+             "degenerate": ["points within 1 mm of a line", "plane warped, x and y quantised"],
+             "curved": ["sphere warped 2x0.5", "room, rows swapped pairwise"]}[kind]
     for e, n in enumerate(names, start=1):
         f["coords"][e] = maps[n]
     return f
@@ -303,28 +303,45 @@ def _adversarial_frame(kind, E=3):
 @pytest.mark.parametrize("kind", ["planar", "degenerate", "curved"])
 def test_screened_sampling_on_adversarial_geometry(engine, oracle, kind):
     """The sampling screen (p3p_screen.hpp) on the geometry that breaks a naive one: wrong-expert hypotheses on planar /
-    fronto-parallel / quantised / collinear / spherical maps -- near-double roots of the P3P quartic, collinear and
-    coincident samples -- in numbers that run the whole screened chain (N = 6144: k_sample_first x2, prescreen, decide,
-    commit, resume).  The accepted try and the sampled cells must be the oracle's, bit for bit, and the unscreened route
-    (ESAC_FLAG_EXACT_SAMPLING) must give the same.  ~1e7 tries per case on the degenerate maps (budget capped)."""
+    tilted / quantised / sliver-triangle / spherical maps -- near-double roots of the P3P quartic, near-collinear and
+    coincident samples -- in numbers that run the whole screened chain (N = 12288: k_sample_first x2, prescreen, decide,
+    commit, resume).  The screened route must give the unscreened route's (ESAC_FLAG_EXACT_SAMPLING) accepted try, cells
+    and pose bit for bit -- that is the screen's guarantee -- and both must be the oracle's, except where a try's three
+    base points are collinear in space (the documented divergence of the exact route's alignment, checked below).
+    ~2e6 / 1.5e7 / 2e5 tries in the three cases (budget capped at 5000)."""
     f = _adversarial_frame(kind)
-    N = 6144
+    N = 12288
     ha = np.arange(N, dtype=np.int64) % 3
     sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
-    kw = dict(focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=77, call=3, max_tries=20000)
+    kw = dict(focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=77, call=3, max_tries=5000)
     ref = oracle.forward(f["coords"], ha, **kw)
     out = {}
     for exact in (False, True):
         p = engine.make_params(3, 60, 80, N, exact_sampling=exact, **kw)
         engine.sample(sc, hat, p)
         out[exact] = (engine.read(api.BUF_TRIES), engine.read(api.BUF_SAMPLE_XY), engine.read(api.BUF_HYPS))
-    np.testing.assert_array_equal(out[False][0], out[True][0])   # screened == unscreened on the device
+    np.testing.assert_array_equal(out[False][0], out[True][0])   # screened == unscreened on the device: the screen's guarantee
     np.testing.assert_array_equal(out[False][1], out[True][1])
     np.testing.assert_array_equal(out[False][2], out[True][2])
-    np.testing.assert_array_equal(out[False][0], ref["tries"])    # == the oracle
-    np.testing.assert_array_equal(out[False][1], ref["sample_xy"])
-    tries = np.where(ref["tries"] < 0, 20000, ref["tries"] + 1)
-    assert tries.sum() > 2e5 and (ref["tries"][ha > 0] > 64).any()  # the screened chain really ran
+    # ... == the oracle, except the ONE documented divergence of the exact route (DESIGN.md section 3, "collinear base
+    # points"): a try whose three base points are collinear in space (on an exactly planar map: three cells of one image
+    # line) has no unique pose -- the reference's eigenvector alignment (p3p::align / jacobi_4x4) returns an arbitrary
+    # roll about that line, decided by rounding noise, and the 4th point then passes tau by chance; the device's triad
+    # alignment takes another roll (or none: NaN).  Every disagreement must be of exactly that kind, and rare.
+    bad = np.nonzero(out[False][0] != ref["tries"])[0]
+    assert len(bad) <= 16, len(bad)  # ~2e-6 per try on the exactly planar maps, none elsewhere
+    for h in bad:
+        t_dev, t_ref = int(out[False][0][h]), int(ref["tries"][h])
+        t_first = min(t for t in (t_dev, t_ref) if t >= 0)  # the try the two sides decided differently
+        xy = oracle.draw_cells(77, 3, int(h), t_first, 80, 60)
+        P = np.array([[f["coords"][ha[h], c, y, x] for c in range(3)] for x, y in xy[:3]], np.float64)
+        e1, e2 = P[1] - P[0], P[2] - P[0]
+        sin2 = np.dot(np.cross(e1, e2), np.cross(e1, e2)) / max(np.dot(e1, e1) * np.dot(e2, e2), 1e-300)
+        assert sin2 < 1e-8, (int(h), t_dev, t_ref, sin2)  # a sliver: base points collinear to 1e-4 rad
+    same = out[False][0] == ref["tries"]
+    np.testing.assert_array_equal(out[False][1][same], ref["sample_xy"][same])
+    tries = np.where(ref["tries"] < 0, 5000, ref["tries"] + 1)
+    assert tries.sum() > {"planar": 1.5e6, "degenerate": 5e6, "curved": 1e5}[kind] and (ref["tries"][ha > 0] > 64).any()  # the screened chain really ran
 
 
 def test_exact_sampling_flag_is_the_reference_loop(engine, oracle):

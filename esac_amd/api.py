@@ -147,7 +147,8 @@ class Engine:
 
     # -- helpers
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # the raw hipStream_t of torch's current stream on this device (no Stream object: this sits on the per-call path)
+        return torch._C._cuda_getCurrentRawStream(self.device.index)
 
     def make_params(self, E, H, W, N, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
                     inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0,
@@ -179,13 +180,13 @@ class Engine:
         sc = scene_coords if scene_coords.is_cuda else scene_coords.to(self.device, non_blocking=True)
         ha = hyp_assign if hyp_assign.is_cuda else hyp_assign.to(self.device, non_blocking=True)
         # accessor<> honours strides (incl. the stride-0 expand() of test_esac.py:171-173); the kernels want dense
-        return sc.contiguous(), ha.contiguous()
+        return (sc if sc.is_contiguous() else sc.contiguous()), (ha if ha.is_contiguous() else ha.contiguous())
 
     # -- whole path
     def forward_device(self, scene_coords, hyp_assign, params, scores_out=None, result_out=None, want_host=True):
         """scene_coords [E,3,H,W] f32 / hyp_assign [N] i64 on this device. Returns host result (np.float64[32]) or None."""
         sc, ha = self._dev_inputs(scene_coords, hyp_assign)
-        host = np.zeros(RES_DOUBLES, np.float64) if want_host else None
+        host = np.empty(RES_DOUBLES, np.float64) if want_host else None
         self._call(self.lib.esac_hip_forward, sc.data_ptr(), ha.data_ptr(), C.byref(params), self._stream(),
                    scores_out.data_ptr() if scores_out is not None else None,
                    result_out.data_ptr() if result_out is not None else None,

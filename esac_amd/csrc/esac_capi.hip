@@ -98,7 +98,7 @@ static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.samp_count, c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.sel_partials, c->ws.sel_arrived, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
-                    c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials};
+                    c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials, c->ws.bucket_fill};
     c->tN = c->tChunks = 0;
     c->tPart = 0;
     for (void* p : ptrs)
@@ -263,10 +263,11 @@ static int ensure_tiled_ws(esac_hip_ctx* c, int N, int P, int E) {
     const long long part = (long long)n_sub * N;
     if (N <= c->tN && chunks <= c->tChunks && part <= c->tPart) return 0;
     HIP_OK(hipDeviceSynchronize());
-    void* ptrs[] = {c->ws.order, c->ws.rt_sorted, c->ws.chunks, c->ws.n_chunks, c->ws.partials};
+    void* ptrs[] = {c->ws.order, c->ws.rt_sorted, c->ws.chunks, c->ws.n_chunks, c->ws.partials, c->ws.bucket_fill};
     for (void* q : ptrs)
         if (q) (void)hipFree(q);
     c->ws.order = nullptr; c->ws.rt_sorted = nullptr; c->ws.chunks = nullptr; c->ws.n_chunks = nullptr; c->ws.partials = nullptr;
+    c->ws.bucket_fill = nullptr;
     const int nN = N > c->tN ? N : c->tN, nC = chunks > c->tChunks ? chunks : c->tChunks;
     const long long nP = part > c->tPart ? part : c->tPart;
     c->tN = c->tChunks = 0;
@@ -277,6 +278,7 @@ static int ensure_tiled_ws(esac_hip_ctx* c, int N, int P, int E) {
     rc |= alloc(&c->ws.chunks, (size_t)nC * 4);
     rc |= alloc(&c->ws.n_chunks, (size_t)4);
     rc |= alloc(&c->ws.partials, (size_t)nP);
+    rc |= alloc(&c->ws.bucket_fill, (size_t)ESAC_TILED_MAX_EXPERTS);
     if (rc) return rc;
     c->tN = nN; c->tChunks = nC; c->tPart = nP;
     return 0;

@@ -110,6 +110,7 @@ struct KArgs {
     float* rt_sorted;     // [N,12] rt32 rows in sorted order
     int* chunks;          // [n_chunks_max,4] expert, first sorted position, count (<= ESAC_TILED_HC), 0
     int* n_chunks;        // [1]
+    int* bucket_fill;     // [E] hypotheses per expert, then (k_bucket_scan) the next free sorted position of each expert
     float* partials;      // [n_sub,N] partial sums per (sub-tile, sorted position)
     int n_sub, n_chunks_max;
     // caller-visible outputs written by the kernels themselves (no copy kernels on the critical path)

@@ -6,8 +6,8 @@
 // served by L2 while a map fits there (57.6 KB at 60x80).  A 480x640 map is 3.7 MB per expert -- 50 experts x 16384
 // hypotheses pull 60 GB through the cache hierarchy (11 GB reached the fabric in the round-1 profile) for 184 MB of
 // distinct data.  Here the loop nest is turned inside out:
-//   1. k_bucket: counting sort of the hypotheses by expert (the histogram test_esac.py:178 also takes), a table of
-//      chunks (expert, first position, count <= TILE_HC) and the fp32 poses copied into sorted order;
+//   1. k_bucket_{count,scan,scatter}: counting sort of the hypotheses by expert (the histogram test_esac.py:178 also
+//      takes), a table of chunks (expert, first position, count <= TILE_HC) and the fp32 poses copied into sorted order;
 //   2. k_score_tiled: ONE WAVEFRONT owns (chunk, sub-tile of 768 cells): it loads its 768 cells once -- 16-byte
 //      coalesced loads, 12 cells per lane kept in registers together with their pixel positions -- and walks the
 //      chunk's hypotheses: pose through scalar loads into SGPRs (the next pose is fetched while the current one is
@@ -35,28 +35,40 @@ constexpr int TILE_CELLS = 64 * TILE_CPT;   // cells per sub-tile (one wavefront
 constexpr int BUCKET_B = 1024;
 
 // ---------------------------------------------------------------- 1. bucket the hypotheses by expert
-// One workgroup.  s_cnt[e] = hypotheses of expert e, exclusive scans give the first sorted position of every expert
-// and its first chunk; `order[pos]` = hypothesis at sorted position pos (order inside an expert is whatever the atomics
-// produce -- nothing downstream depends on it: every hypothesis' partial sums are its own).
-__global__ __launch_bounds__(BUCKET_B) void k_bucket(KArgs a) {
+// Counting sort in three small launches (one 1024-thread workgroup walking all N hypotheses with dependent loads and LDS
+// atomics took 66 us at N = 16384):
+//   k_bucket_count    every workgroup histograms its 1024 hypotheses in LDS and adds the non-zero bins to counts[E];
+//   k_bucket_scan     one workgroup: exclusive scans of the counts and of the chunk counts -> first sorted position of
+//                     every expert (start[e], also the running fill pointer of the scatter) and the chunk table;
+//   k_bucket_scatter  pos = atomicAdd(fill[e], 1): order[pos] = h and the pose in the form the tile kernel consumes.
+// The order inside an expert is whatever the atomics produce -- nothing downstream depends on it: every hypothesis'
+// partial sums are its own (k_score_tiled_reduce scatters them back through `order`).
+__global__ __launch_bounds__(BUCKET_B) void k_bucket_count(KArgs a) {
     __shared__ int s_cnt[ESAC_TILED_MAX_EXPERTS];
-    __shared__ int s_start[ESAC_TILED_MAX_EXPERTS];
-    __shared__ int s_scan[2][BUCKET_B];
-    const int E = a.E, N = a.N, HC = ESAC_TILED_HC;
+    const int E = a.E;
     for (int e = threadIdx.x; e < E; e += BUCKET_B) s_cnt[e] = 0;
     __syncthreads();
-    for (int h = threadIdx.x; h < N; h += BUCKET_B) atomicAdd(&s_cnt[expert_of(a, h)], 1);
+    const int h = blockIdx.x * BUCKET_B + threadIdx.x;
+    if (h < a.N) atomicAdd(&s_cnt[expert_of(a, h)], 1);
     __syncthreads();
-    // exclusive scans of the counts and of the chunk counts: every thread owns EPT consecutive experts, the per-thread
-    // totals are scanned across the workgroup (Hillis-Steele in LDS), twice
+    for (int e = threadIdx.x; e < E; e += BUCKET_B)
+        if (s_cnt[e]) atomicAdd(a.bucket_fill + e, s_cnt[e]);
+}
+
+__global__ __launch_bounds__(BUCKET_B) void k_bucket_scan(KArgs a) {
+    __shared__ int s_scan[2][BUCKET_B];
+    const int E = a.E, HC = ESAC_TILED_HC;
+    // every thread owns EPT consecutive experts, the per-thread totals are scanned across the workgroup (Hillis-Steele
+    // in LDS), once for the counts and once for the chunk counts
     constexpr int EPT = ESAC_TILED_MAX_EXPERTS / BUCKET_B;
+    int cnt[EPT];
     int mine_cnt = 0, mine_chunks = 0;
 #pragma unroll
     for (int k = 0; k < EPT; k++) {
         const int e = threadIdx.x * EPT + k;
-        const int c = e < E ? s_cnt[e] : 0;
-        mine_cnt += c;
-        mine_chunks += (c + HC - 1) / HC;
+        cnt[k] = e < E ? a.bucket_fill[e] : 0;
+        mine_cnt += cnt[k];
+        mine_chunks += (cnt[k] + HC - 1) / HC;
     }
     int excl[2];
 #pragma unroll
@@ -75,48 +87,66 @@ __global__ __launch_bounds__(BUCKET_B) void k_bucket(KArgs a) {
         if (which == 1 && threadIdx.x == BUCKET_B - 1) a.n_chunks[0] = s_scan[cur][threadIdx.x];
         __syncthreads();
     }
-    {
-        int pos = excl[0], ch = excl[1];
+    int pos = excl[0], ch = excl[1];
 #pragma unroll
-        for (int k = 0; k < EPT; k++) {
-            const int e = threadIdx.x * EPT + k;
-            if (e < E) {
-                const int c = s_cnt[e];
-                s_start[e] = pos;
-                for (int j = 0, first = 0; first < c; j++, first += HC) {
-                    int* row = a.chunks + 4 * (size_t)(ch + j);
-                    row[0] = e;
-                    row[1] = pos + first;
-                    row[2] = c - first < HC ? c - first : HC;
-                    row[3] = 0;
-                }
-                pos += c;
-                ch += (c + HC - 1) / HC;
+    for (int k = 0; k < EPT; k++) {
+        const int e = threadIdx.x * EPT + k;
+        if (e < E) {
+            const int c = cnt[k];
+            a.bucket_fill[e] = pos;  // from here on: where the next hypothesis of expert e goes
+            for (int j = 0, first = 0; first < c; j++, first += HC) {
+                int* row = a.chunks + 4 * (size_t)(ch + j);
+                row[0] = e;
+                row[1] = pos + first;
+                row[2] = c - first < HC ? c - first : HC;
+                row[3] = 0;
             }
+            pos += c;
+            ch += (c + HC - 1) / HC;
         }
     }
+}
+
+__global__ __launch_bounds__(BUCKET_B) void k_bucket_scatter(KArgs a) {
+    // ranks inside the workgroup through LDS, ONE global atomic per (workgroup, expert) to reserve the range: 16384 global
+    // atomics on 50 addresses serialise (45 us measured); 16 workgroups x 50 experts do not
+    __shared__ int s_cnt[ESAC_TILED_MAX_EXPERTS];
+    __shared__ int s_base[ESAC_TILED_MAX_EXPERTS];
+    const int E = a.E;
+    for (int e = threadIdx.x; e < E; e += BUCKET_B) s_cnt[e] = 0;
     __syncthreads();
-    for (int e = threadIdx.x; e < E; e += BUCKET_B) s_cnt[e] = 0;  // now: fill level
-    __syncthreads();
-    for (int h = threadIdx.x; h < N; h += BUCKET_B) {
-        const int e = expert_of(a, h);
-        const int pos = s_start[e] + atomicAdd(&s_cnt[e], 1);
-        a.order[pos] = h;
-        // the pose in the form the tile kernel consumes: camera folded into the rows (see PoseU)
-        const float4* src = reinterpret_cast<const float4*>(a.rt32 + (size_t)h * 12);
-        const float4 q0 = src[0], q1 = src[1], q2 = src[2];  // r0 r1 r2 r3 | r4 r5 r6 r7 | r8 t0 t1 t2
-        const float f = a.focal, cx = a.ppx, cy = a.ppy;
-        float4* dst = reinterpret_cast<float4*>(a.rt_sorted + (size_t)pos * 12);
-        dst[0] = make_float4(fmaf(f, q0.x, cx * q1.z), fmaf(f, q0.y, cx * q1.w), fmaf(f, q0.z, cx * q2.x), fmaf(f, q2.y, cx * q2.w));
-        dst[1] = make_float4(fmaf(f, q0.w, cy * q1.z), fmaf(f, q1.x, cy * q1.w), fmaf(f, q1.y, cy * q2.x), fmaf(f, q2.z, cy * q2.w));
-        dst[2] = make_float4(q1.z, q1.w, q2.x, q2.w);
+    const int h = blockIdx.x * BUCKET_B + threadIdx.x;
+    int e = 0, local = 0;
+    if (h < a.N) {
+        e = expert_of(a, h);
+        local = atomicAdd(&s_cnt[e], 1);
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < E; k += BUCKET_B)
+        if (s_cnt[k]) s_base[k] = atomicAdd(a.bucket_fill + k, s_cnt[k]);
+    __syncthreads();
+    if (h >= a.N) return;
+    const int pos = s_base[e] + local;
+    a.order[pos] = h;
+    // the pose in the form the tile kernel consumes: camera folded into the rows, rows A and B and (in the kernel) the
+    // pixel positions scaled by |beta| log2(e) so that the exponent of the sigmoid needs no arithmetic of its own (see PoseU)
+    const float4* src = reinterpret_cast<const float4*>(a.rt32 + (size_t)h * 12);
+    const float4 q0 = src[0], q1 = src[1], q2 = src[2];  // r0 r1 r2 r3 | r4 r5 r6 r7 | r8 t0 t1 t2
+    const float kb = fabsf(a.beta) * 1.4426950408889634f;
+    const float f = a.focal * kb, cx = a.ppx * kb, cy = a.ppy * kb;
+    float4* dst = reinterpret_cast<float4*>(a.rt_sorted + (size_t)pos * 12);
+    dst[0] = make_float4(fmaf(f, q0.x, cx * q1.z), fmaf(f, q0.y, cx * q1.w), fmaf(f, q0.z, cx * q2.x), fmaf(f, q2.y, cx * q2.w));
+    dst[1] = make_float4(fmaf(f, q0.w, cy * q1.z), fmaf(f, q1.x, cy * q1.w), fmaf(f, q1.y, cy * q2.x), fmaf(f, q2.z, cy * q2.w));
+    dst[2] = make_float4(q1.z, q1.w, q2.x, q2.w);
 }
 
 // ---------------------------------------------------------------- 2. the tile-stationary score
 // Pose rows with the camera folded in: u = (A . X + ta) / (C . X + tc),  v = (B . X + tb) / (C . X + tc),
 // A = f R0 + cx R2, B = f R1 + cy R2, C = R2 (likewise the translation): two FMAs per cell less than projecting first
-// and applying (f, c) afterwards.  k_bucket stores the rows in this form; the tile kernel keeps them in SGPRs.
+// and applying (f, c) afterwards.  Rows A and B and the pixel positions also carry the factor k = |beta| log2(e): the
+// distance the kernel forms is k * err, the exponent of the sigmoid 2^(k err - k tau) needs no multiply-add of its own
+// and the constant 2^(-k tau) rides in the FMA that forms 1 + exp.  k_bucket_scatter stores the rows in this form; the
+// tile kernel keeps them in SGPRs.
 struct PoseU {
     float a0, a1, a2, ta, b0, b1, b2, tb, c0, c1, c2, tc;
 };
@@ -137,9 +167,10 @@ __device__ __forceinline__ PoseU pose_of(const sgpr4& q0, const sgpr4& q1, const
     return PoseU{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
 }
 
-// one cell: 1 / (1 + exp(beta (min(err, maxReproj) - tau))), err = |pixel - projection|; kb = beta log2(e), k0 = -tau kb
-__device__ __forceinline__ float soft_inlier_tile(const PoseU& p, float X, float Y, float Z, float px, float py, float max_reproj,
-                                                  float kb, float k0) {
+// one cell: 1 / (1 + exp(beta (min(err, maxReproj) - tau))), err = |pixel - projection|.  Everything arrives scaled by
+// k = |beta| log2(e) (rows A, B, px, py, kmax = k maxReproj); c0 = 2^(-k tau); NEG: beta < 0 (the exponent changes sign).
+template <bool NEG>
+__device__ __forceinline__ float soft_inlier_tile(const PoseU& p, float X, float Y, float Z, float px, float py, float kmax, float c0) {
     const float un = fmaf(p.a0, X, fmaf(p.a1, Y, fmaf(p.a2, Z, p.ta)));
     const float vn = fmaf(p.b0, X, fmaf(p.b1, Y, fmaf(p.b2, Z, p.tb)));
     const float zc = fmaf(p.c0, X, fmaf(p.c1, Y, fmaf(p.c2, Z, p.tc)));
@@ -147,16 +178,16 @@ __device__ __forceinline__ float soft_inlier_tile(const PoseU& p, float X, float
     const float iz = __builtin_amdgcn_rcpf(zc);
     const float du = fmaf(-un, iz, px);
     const float dv = fmaf(-vn, iz, py);
-    const float err = fminf(__builtin_amdgcn_sqrtf(fmaf(du, du, dv * dv)), max_reproj);  // fminf drops a NaN operand
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(err, kb, k0)));
+    const float err = fminf(__builtin_amdgcn_sqrtf(fmaf(du, du, dv * dv)), kmax);  // fminf drops a NaN operand
+    return __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(NEG ? -err : err), c0, 1.0f));
 }
 
-// two cells at a time with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: 4.9 cycles for two
-// operations against 3.0 for one, scripts/dev/valu_rate.hip); the four transcendentals and the clamp have no packed form
+// two cells at a time with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: 4.9 cycles for two operations against
+// 3.0 for one, scripts/dev/valu_rate.hip); the four transcendentals and the clamp have no packed form
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
-__device__ __forceinline__ f32x2 soft_inlier_tile2(const PoseU& p, f32x2 X, f32x2 Y, f32x2 Z, f32x2 px, float py, float max_reproj, float kb,
-                                                   float k0) {
+template <bool NEG>
+__device__ __forceinline__ f32x2 soft_inlier_tile2(const PoseU& p, f32x2 X, f32x2 Y, f32x2 Z, f32x2 px, float py, float kmax, float c0) {
     const f32x2 un = __builtin_elementwise_fma(splat2(p.a0), X, __builtin_elementwise_fma(splat2(p.a1), Y, __builtin_elementwise_fma(splat2(p.a2), Z, splat2(p.ta))));
     const f32x2 vn = __builtin_elementwise_fma(splat2(p.b0), X, __builtin_elementwise_fma(splat2(p.b1), Y, __builtin_elementwise_fma(splat2(p.b2), Z, splat2(p.tb))));
     const f32x2 zc = __builtin_elementwise_fma(splat2(p.c0), X, __builtin_elementwise_fma(splat2(p.c1), Y, __builtin_elementwise_fma(splat2(p.c2), Z, splat2(p.tc))));
@@ -164,12 +195,13 @@ __device__ __forceinline__ f32x2 soft_inlier_tile2(const PoseU& p, f32x2 X, f32x
     const f32x2 du = __builtin_elementwise_fma(-un, iz, px);
     const f32x2 dv = __builtin_elementwise_fma(-vn, iz, splat2(py));
     const f32x2 d2 = __builtin_elementwise_fma(du, du, dv * dv);
-    const f32x2 err = {fminf(__builtin_amdgcn_sqrtf(d2.x), max_reproj), fminf(__builtin_amdgcn_sqrtf(d2.y), max_reproj)};
-    const f32x2 arg = __builtin_elementwise_fma(err, splat2(kb), splat2(k0));
-    const f32x2 den = f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)} + splat2(1.0f);
+    const f32x2 err = {fminf(__builtin_amdgcn_sqrtf(d2.x), kmax), fminf(__builtin_amdgcn_sqrtf(d2.y), kmax)};
+    const f32x2 ex = {__builtin_amdgcn_exp2f(NEG ? -err.x : err.x), __builtin_amdgcn_exp2f(NEG ? -err.y : err.y)};
+    const f32x2 den = __builtin_elementwise_fma(ex, splat2(c0), splat2(1.0f));
     return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
 }
 
+template <bool NEG>
 __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
     // block -> (sub-tile, chunk): all chunks of one sub-tile are neighbours in dispatch order AND on one XCD
     // (workgroup b runs on XCD b % 8): the tile's bytes come from HBM once, the other chunks hit that XCD's L2
@@ -187,7 +219,10 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
     const Centre o = map_centre(a, mx);
     // this lane's TILE_CPT cells: groups of 4 consecutive cells (W % 4 == 0: a group never straddles a row), group g of lane l = group g * 64 + l of the sub-tile
     float X[TILE_CPT], Y[TILE_CPT], Z[TILE_CPT], px[TILE_CPT], py[TILE_CPT / 4], m[TILE_CPT / 4];  // py, weight: per group of 4
-    const float step = (float)a.sub;
+    // everything the distance is formed from carries k = |beta| log2(e) (see PoseU); e0 = 2^(-k tau) for beta > 0, 2^(k tau) else
+    const float kb = fabsf(a.beta) * 1.4426950408889634f, kmax = kb * a.max_reproj;
+    const float e0 = __builtin_amdgcn_exp2f(NEG ? kb * a.tau : -kb * a.tau);
+    const float step = kb * (float)a.sub;
 #pragma unroll
     for (int g = 0; g < TILE_CPT / 4; g++) {
         const int cell = st * TILE_CELLS + (g * 64 + lane) * 4;
@@ -197,7 +232,7 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
         const float4 vy = *reinterpret_cast<const float4*>(mx + P + cc);
         const float4 vz = *reinterpret_cast<const float4*>(mx + 2 * P + cc);
         const int r = cc / a.W, c0 = cc - r * a.W;
-        const float pxf = cell_px(a, c0), pyf = cell_py(a, r);
+        const float pxf = kb * cell_px(a, c0), pyf = kb * cell_py(a, r);
         X[4 * g] = vx.x - o.x; X[4 * g + 1] = vx.y - o.x; X[4 * g + 2] = vx.z - o.x; X[4 * g + 3] = vx.w - o.x;
         Y[4 * g] = vy.x - o.y; Y[4 * g + 1] = vy.y - o.y; Y[4 * g + 2] = vy.z - o.y; Y[4 * g + 3] = vy.w - o.y;
         Z[4 * g] = vz.x - o.z; Z[4 * g + 1] = vz.y - o.z; Z[4 * g + 2] = vz.z - o.z; Z[4 * g + 3] = vz.w - o.z;
@@ -208,8 +243,6 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
         py[g] = pyf;
         m[g] = valid ? 1.0f : 0.0f;
     }
-    const float kb = a.beta * 1.4426950408889634f, k0 = -a.tau * kb;
-    const float maxr = a.max_reproj;
     const float* __restrict__ poses = a.rt_sorted + (size_t)first * 12;
     float* __restrict__ out = a.partials + (size_t)st * a.N + first;
     float res = 0.0f;
@@ -225,15 +258,15 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
 #pragma unroll
         for (int u = 0; u < TILE_CPT; u += 2)
             acc = __builtin_elementwise_fma(splat2(m[u >> 2]),
-                                            soft_inlier_tile2(cur, f32x2{X[u], X[u + 1]}, f32x2{Y[u], Y[u + 1]}, f32x2{Z[u], Z[u + 1]},
-                                                              f32x2{px[u], px[u + 1]}, py[u >> 2], maxr, kb, k0), acc);
+                                            soft_inlier_tile2<NEG>(cur, f32x2{X[u], X[u + 1]}, f32x2{Y[u], Y[u + 1]}, f32x2{Z[u], Z[u + 1]},
+                                                                   f32x2{px[u], px[u + 1]}, py[u >> 2], kmax, e0), acc);
         const float acc0 = acc.x, acc1 = acc.y;
 #else
         float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
         for (int u = 0; u < TILE_CPT; u += 2) {
-            acc0 = fmaf(m[u >> 2], soft_inlier_tile(cur, X[u], Y[u], Z[u], px[u], py[u >> 2], maxr, kb, k0), acc0);
-            acc1 = fmaf(m[u >> 2], soft_inlier_tile(cur, X[u + 1], Y[u + 1], Z[u + 1], px[u + 1], py[u >> 2], maxr, kb, k0), acc1);
+            acc0 = fmaf(m[u >> 2], soft_inlier_tile<NEG>(cur, X[u], Y[u], Z[u], px[u], py[u >> 2], kmax, e0), acc0);
+            acc1 = fmaf(m[u >> 2], soft_inlier_tile<NEG>(cur, X[u + 1], Y[u + 1], Z[u + 1], px[u + 1], py[u >> 2], kmax, e0), acc1);
         }
 #endif
         const float tot = wave_sum(acc0 + acc1);  // the same total in every lane
@@ -271,9 +304,13 @@ __global__ __launch_bounds__(256) void k_score_tiled_reduce(KArgs a) {
 int tiled_sub_tiles(int P) { return (P + TILE_CELLS - 1) / TILE_CELLS; }
 
 void launch_score_tiled(const KArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_bucket, dim3(1), dim3(BUCKET_B), 0, s, a);
+    (void)hipMemsetAsync(a.bucket_fill, 0, (size_t)a.E * sizeof(int), s);
+    hipLaunchKernelGGL(k_bucket_count, dim3((a.N + BUCKET_B - 1) / BUCKET_B), dim3(BUCKET_B), 0, s, a);
+    hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(BUCKET_B), 0, s, a);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3((a.N + BUCKET_B - 1) / BUCKET_B), dim3(BUCKET_B), 0, s, a);
     const long long per_xcd = (long long)((a.n_sub + 7) / 8) * a.n_chunks_max;
-    hipLaunchKernelGGL(k_score_tiled, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, s, a);
+    if (a.beta < 0) hipLaunchKernelGGL(k_score_tiled<true>, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, s, a);
+    else            hipLaunchKernelGGL(k_score_tiled<false>, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, s, a);
     hipLaunchKernelGGL(k_score_tiled_reduce, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
 }
 

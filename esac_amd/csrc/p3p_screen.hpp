@@ -27,189 +27,10 @@ ESAC_HD V3f operator*(float s, V3f a) { return {s * a.x, s * a.y, s * a.z}; }
 ESAC_HD float dotf(V3f a, V3f b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 ESAC_HD V3f crossf(V3f a, V3f b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
-// Real roots of a x^4 + b x^3 + c x^2 + d x + e (Ferrari, same route as quartic_real_roots).  `delicate` is raised
-// whenever a branch is taken within rounding distance of its threshold: the fp64 route may then see a different root set.
-ESAC_HD int quartic_roots_f32(float a, float b, float c, float d, float e, float (&x)[4], int& delicate) {
-    const float kPi = 3.14159265358979f;
-    const float tol = 2e-3f;  // relative width of "within rounding distance" for this fp32 evaluation
-    if (!(fabsf(a) > 1e-20f)) {
-        delicate = 1;
-        return 0;
-    }
-    const float ia = 1.0f / a;
-    b *= ia; c *= ia; d *= ia; e *= ia;
-    const float b2 = b * b, bc = b * c, b3 = b2 * b;
-    // resolvent cubic y^3 - c y^2 + (d b - 4 e) y + (4 c e - d^2 - b^2 e), first real root
-    const float cb = -c, cc = d * b - 4 * e, cd = 4 * c * e - d * d - b2 * e;
-    const float Q = (3 * cc - cb * cb) * (1.0f / 9), R = (9 * cb * cc - 27 * cd - 2 * cb * cb * cb) * (1.0f / 54);
-    const float Q3 = Q * Q * Q, D = Q3 + R * R;
-    const float cb3 = cb * (1.0f / 3);
-    const float mag = fabsf(Q3) + R * R;
-    if (fabsf(D) <= tol * mag) delicate = 2;  // branch of the cubic undecided at fp32
-    float r0;
-    if (D <= 0) {
-        const float sq = sqrtf(fmaxf(-Q3, 0.0f));
-        float arg = sq > 0 ? R / sq : 0.0f;
-        arg = fminf(1.0f, fmaxf(-1.0f, arg));
-        r0 = 2 * sqrtf(fmaxf(-Q, 0.0f)) * cosf(acosf(arg) * (1.0f / 3)) - cb3;
-    } else {
-        const float AD = cbrtf(fabsf(R) + sqrtf(D)) * (R > 0 ? 1.0f : (R < 0 ? -1.0f : 0.0f));
-        const float BD = (AD == 0) ? 0 : -Q / AD;
-        r0 = AD + BD - cb3;
-    }
-    const float R2 = 0.25f * b2 - c + r0;
-    const float scale = 0.25f * b2 + fabsf(c) + fabsf(r0);
-    if (fabsf(R2) <= tol * scale) delicate = 3;
-    if (R2 < 0) return 0;
-    const float Rr = sqrtf(R2);
-    float D2, E2;
-    if (Rr < 1e-5f * (1.0f + sqrtf(scale))) {
-        delicate = 4;
-        const float t = r0 * r0 - 4 * e;
-        if (t < 0) return 0;
-        const float sq = sqrtf(t);
-        D2 = 0.75f * b2 - 2 * c + 2 * sq;
-        E2 = D2 - 4 * sq;
-    } else {
-        const float u = 0.75f * b2 - 2 * c - R2, v = 0.25f * (4 * bc - 8 * d - b3) / Rr;
-        D2 = u + v;
-        E2 = u - v;
-        const float s2 = fabsf(u) + fabsf(v);
-        if (fabsf(D2) <= tol * s2 || fabsf(E2) <= tol * s2) delicate = 5;
-    }
-    const float b4 = 0.25f * b, R_2 = 0.5f * Rr;
-    int n = 0;
-    if (D2 >= 0) {
-        const float Ds = sqrtf(D2);
-        x[0] = R_2 + 0.5f * Ds - b4;
-        x[1] = x[0] - Ds;
-        n = 2;
-    }
-    if (E2 >= 0) {
-        const float Es = sqrtf(E2);
-        x[n] = -R_2 + 0.5f * Es - b4;
-        x[n + 1] = x[n] - Es;
-        n += 2;
-    }
-    return n;
-}
-
-// Smallest 4th-point reprojection error (pixels) over the candidate poses of this try, evaluated in fp32;
-// -1 when the configuration is numerically delicate (the caller must treat the try as "maybe"), +inf without candidate.
-// Pf: the 4 scene points, (mu, mv): their pixel positions.
 #define ESAC_SCREEN_MAYBE (-1.0f)
 #ifndef ESAC_SCREEN_CONGRUENCE
 #define ESAC_SCREEN_CONGRUENCE 1e-3f
 #endif
-#define SCREEN_BAIL(code) do { if (reason) *reason = (code); return ESAC_SCREEN_MAYBE; } while (0)
-ESAC_HD float p3p_screen_err(const float (&Pf)[4][3], const float (&mu_px)[4], const float (&mv_px)[4], float f, float cx, float cy,
-                             int* reason = nullptr) {
-    int delicate = 0;
-    const float inv_f = 1.0f / f;
-    float mu[4], mv[4], mk[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const float u = (mu_px[i] - cx) * inv_f, v = (mv_px[i] - cy) * inv_f;
-        const float k = 1.0f / sqrtf(u * u + v * v + 1.0f);
-        mu[i] = u * k; mv[i] = v * k; mk[i] = k;
-    }
-    const V3f P0{Pf[0][0], Pf[0][1], Pf[0][2]}, P1{Pf[1][0], Pf[1][1], Pf[1][2]}, P2{Pf[2][0], Pf[2][1], Pf[2][2]},
-        P3{Pf[3][0], Pf[3][1], Pf[3][2]};
-    const V3f d12 = P1 - P2, d02 = P0 - P2, d01 = P0 - P1;
-    const float s0 = dotf(d12, d12), s1 = dotf(d02, d02), s2 = dotf(d01, d01);
-    if (!(s2 > 1e-12f) || !(s0 > 1e-12f) || !(s1 > 1e-12f)) SCREEN_BAIL(10);  // coincident points: let fp64 decide
-    const float cos0 = mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2];
-    const float cos1 = mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2];
-    const float cos2 = mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1];
-    const float p = 2 * cos0, q = 2 * cos1, r = 2 * cos2;
-    const float inv_d22 = 1.0f / s2;
-    const float a = inv_d22 * s0, b = inv_d22 * s1;
-    const float a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
-    const float pr = p * r, pqr = q * pr;
-    const float ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
-    const float A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
-    const float B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
-    const float C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
-    const float Dq = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
-    const float E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
-    const float temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
-    const float b0 = b * temp * temp;
-    // coefficient magnitudes: a coefficient that is small against the terms it was summed from carries no digits
-    const float cmag = 1.0f + a2 + b2 + ab;
-    if (!(fabsf(A) > 1e-4f * cmag) || !(fabsf(b0) > 1e-7f * b * (p2 + r2 + fabsf(pqr)) * (p2 + r2 + fabsf(pqr)) * (1 + a + b) * (1 + a + b))) SCREEN_BAIL(11);
-    float xr[4] = {0, 0, 0, 0};
-    const int n = quartic_roots_f32(A, B, C, Dq, E, xr, delicate);
-    if (delicate) SCREEN_BAIL(delicate);
-    float best = INFINITY;
-    if (n == 0) return best;
-    const float dist2 = sqrtf(s2);
-    const float inv_b0 = 1.0f / b0;
-    const float r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i >= n) break;
-        const float x = xr[i];
-        if (!(x == x)) SCREEN_BAIL(12);
-        if (x <= 0) {
-            if (x > -1e-3f) SCREEN_BAIL(13);  // sign of a root at rounding distance from zero
-            continue;
-        }
-        const float xx = x * x;
-        const float b1 =
-            ((1 - a - b) * xx + (q * a - q) * x + 1 - a + b) *
-            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
-              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * xx +
-             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
-              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
-             2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
-             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
-        // b1 is the difference of large products: its sign (validity of the root) and its value (the depth ratio y) are
-        // only as good as fp32 cancellation allows -- the calibration decides how much of that the margin absorbs
-        const float y = inv_b0 * b1;
-        if (!(y == y)) SCREEN_BAIL(14);
-        if (b1 <= 0) continue;
-        const float v = xx + y * y - x * y * r;
-        if (v <= 0) {
-            if (v > -1e-3f * (xx + y * y)) SCREEN_BAIL(15);
-            continue;
-        }
-        const float Z = dist2 / sqrtf(v);
-        const float X = x * Z, Y = y * Z;
-        // camera-frame positions of the three base points and the rigid motion taking the scene triangle onto them
-        // (orthonormal triads: exact for congruent triangles, which is what an accurate root gives)
-        const V3f Q0{X * mu[0], X * mv[0], X * mk[0]}, Q1{Y * mu[1], Y * mv[1], Y * mk[1]}, Q2{Z * mu[2], Z * mv[2], Z * mk[2]};
-        const V3f pe1 = P1 - P0, pe2 = P2 - P0, qe1 = Q1 - Q0, qe2 = Q2 - Q0;
-        const float ip1 = 1.0f / sqrtf(dotf(pe1, pe1)), iq1 = 1.0f / sqrtf(dotf(qe1, qe1));
-        const V3f e1 = ip1 * pe1, f1 = iq1 * qe1;
-        V3f e3 = crossf(e1, pe2), f3 = crossf(f1, qe2);
-        const float n3 = dotf(e3, e3), m3 = dotf(f3, f3);
-        if (!(n3 > 1e-12f * dotf(pe2, pe2)) || !(m3 > 1e-12f * dotf(qe2, qe2))) SCREEN_BAIL(16);  // collinear sample
-        e3 = (1.0f / sqrtf(n3)) * e3;
-        f3 = (1.0f / sqrtf(m3)) * f3;
-        const V3f e2 = crossf(e3, e1), f2 = crossf(f3, f1);
-        // 4th point in the scene triad, carried over to the camera triad
-        const V3f w = P3 - P0;
-        const float c1 = dotf(w, e1), c2 = dotf(w, e2), c3 = dotf(w, e3);
-        const float Xc = Q0.x + c1 * f1.x + c2 * f2.x + c3 * f3.x;
-        const float Yc = Q0.y + c1 * f1.y + c2 * f2.y + c3 * f3.y;
-        const float Zc = Q0.z + c1 * f1.z + c2 * f2.z + c3 * f3.z;
-        if (!(fabsf(Zc) > 1e-3f * (fabsf(Xc) + fabsf(Yc) + 1e-6f))) SCREEN_BAIL(17);  // 4th point next to the camera plane
-        const float iz = 1.0f / Zc;
-        const float du = cx + f * Xc * iz - mu_px[3], dv = cy + f * Yc * iz - mv_px[3];
-        const float epx = sqrtf(du * du + dv * dv);
-        if (!(epx == epx)) SCREEN_BAIL(18);
-        best = fminf(best, epx);
-    }
-    return best;
-}
-
-// true = "maybe acceptable": hand the try to the fp64 route.  false = no candidate of this try can pass.
-// thr = tau + screening margin (pixels).
-ESAC_HD bool p3p_screen_f32(const float (&Pf)[4][3], const float (&mu_px)[4], const float (&mv_px)[4], float f, float cx, float cy,
-                            float thr) {
-    const float e = p3p_screen_err(Pf, mu_px, mv_px, f, cx, cy);
-    return !(e > thr);  // delicate (-1), NaN and anything within the threshold: maybe
-}
 
 // ---- the screen's private copy of the roots and depths ------------------------------------------------------------------------
 // p3p_setup / p3p_candidate_lengths (pose_math.hpp) follow the CPU solver operation by operation -- IEEE mul and add, the
@@ -225,6 +46,29 @@ ESAC_HD bool p3p_screen_f32(const float (&Pf)[4][3], const float (&mu_px)[4], co
 // square root estimate + Newton steps.  Arguments here are squared lengths, cosines and polynomial coefficients of
 // ordinary magnitude; zero, negative and non-finite arguments give what the callers' tests expect (inf / NaN / 0).
 ESAC_HD double scr_rcp(double d) { return fast_rcp(d); }
+// 1 / v, 1 / sqrt(v), sqrt(v) in single precision to the hardware's 1 ulp: the bookkeeping of the bounds and the fp32
+// geometry of the screen (triads, projection) need no correct rounding, and the IEEE sequences cost ~10 instructions each
+ESAC_HD float scr_rcpf(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(v);
+#else
+    return 1.0f / v;
+#endif
+}
+ESAC_HD float scr_rsqf(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rsqf(v);
+#else
+    return 1.0f / sqrtf(v);
+#endif
+}
+ESAC_HD float scr_sqrtf(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(v);
+#else
+    return sqrtf(v);
+#endif
+}
 ESAC_HD double scr_sqrt(double d) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma clang fp contract(fast)
@@ -370,7 +214,7 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
     // r0) / (its slope there); ec: what the coefficient differences do to it, through the same slope.  Both blow up next
     // to a multiple root of the cubic, which is where a double root of the quartic puts it.
     const float fr = (float)fabs(r0);
-    const float islope = 1.0f / (float)fabs((3 * r0 + 2 * cb) * r0 + cc);  // slope 0: inf -> "maybe" below
+    const float islope = scr_rcpf((float)fabs((3 * r0 + 2 * cb) * r0 + cc));  // slope 0: inf -> "maybe" below
     const float er = 4e-16f * (((fr + fc) * fr + (float)fabs(cc)) * fr + (float)fabs(cd)) * islope;
     const float ec = ((uc * fr + ucc) * fr + ucd) * islope;
     // Ferrari takes square roots of quantities that cancel: R2 = (half the difference of the two quadratic factors'
@@ -412,13 +256,13 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
         const double Ds = scr_sqrt(D2);
         x0 = R_2 + 0.5 * Ds - b_4;
         x1 = x0 - Ds;
-        dx01 = dxR + 0.25f * (uD + rD) / (float)Ds;
+        dx01 = dxR + 0.25f * (uD + rD) * scr_rcpf((float)Ds);
         nb = 2;
     }
     if (E2 >= 0) {
         const double Es = scr_sqrt(E2);
         const double xa = -R_2 + 0.5 * Es - b_4, xb = xa - Es;
-        const float dx = dxR + 0.25f * (uD + rD) / (float)Es;
+        const float dx = dxR + 0.25f * (uD + rD) * scr_rcpf((float)Es);
         if (nb == 0) {
             x0 = xa; x1 = xb;
             dx01 = dx;
@@ -471,16 +315,13 @@ ESAC_HD bool screen_setup(const V3 P[4], const double mu_px[4], const double mv_
     const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
     const double b0 = b * temp * temp;
     if (b0 == 0) return false;
-    // magnitudes of the terms each coefficient is summed from (a, b > 0), in single precision like every bound here
-    const float af = (float)a, bf = (float)b, fp = (float)fabs(p), fq = (float)fabs(q), fr = (float)fabs(r), fpr = fp * fr, fpqr = fq * fpr;
-    const float a2f = af * af, b2f = bf * bf, abf = af * bf, p2f = fp * fp, q2f = fq * fq, r2f = fr * fr;
-    const float sf = 1 + af + bf;
-    const float mA = 2 * sf * sf;
-    const float mB = fq * (2 * (abf + a2f + 1 + bf) + r2f * abf + 4 * af) + fpr * (bf + b2f + abf);
-    const float mC = q2f + b2f * (r2f + p2f + 2) + bf * (p2f + fpqr) + abf * (r2f + fpqr) + (a2f + 2 * af) * (2 + q2f) + 2;
-    const float mD = fpr * (abf + b2f + bf) + fq * ((p2f + 2) * bf + 2 * (abf + a2f) + 4 * af + 2);
-    const float mE = 1 + 2 * (bf + af + abf) + b2f + bf * p2f + a2f;
-    const float mT = (p2f + r2f) * sf + fpqr * (1 + af);
+    // magnitudes of the terms each coefficient is summed from (a, b > 0; single precision like every bound here), in units
+    // of M = (1 + a + b)^2: A <= 2 M, B and D <= (6 |q| + |p r|) M, C <= 16 M, E <= 4 M (|p|, |q|, |r| <= 2; each bound is
+    // within ~3x of the exact sum of magnitudes, which SCREEN_SIG absorbs)
+    const float sf = 1 + (float)a + (float)b, M = sf * sf;
+    const float fpr = (float)fabs(pr), fq = (float)fabs(q);
+    const float mA = 2 * M, mB = (6 * fq + fpr) * M, mC = 16 * M, mD = mB, mE = 4 * M;
+    const float mT = ((float)p2 + (float)r2 + fq * fpr) * sf;
     const float cu = (float)SCREEN_CU;
     if (!((float)fabs(temp) > (float)SCREEN_SIG * cu * mT)) {  // b0's sign / zero test is rounding
         ESAC_SCREEN_STAT(4);
@@ -508,9 +349,8 @@ ESAC_HD int screen_lengths(const ScreenSetup& S, double x, float dx, double& X, 
     const double a = S.a, b = S.b, p = S.p, q = S.q, r = S.r;
     const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
     const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
-    const double relx = (double)dx * scr_rcp(fabs(x));
-    ESAC_SCREEN_HIST(4, relx);
-    if (!(relx <= SCREEN_REL)) {  // the root's sign or value is not reproducible (NaN included)
+    ESAC_SCREEN_HIST(4, dx / (float)fabs(x));
+    if (!(dx <= (float)SCREEN_REL * (float)fabs(x))) {  // the root's sign or value is not reproducible (NaN included)
         ESAC_SCREEN_STAT(5);
         return -1;
     }
@@ -527,22 +367,22 @@ ESAC_HD int screen_lengths(const ScreenSetup& S, double x, float dx, double& X, 
     const double f1 = g2 * xx + g1 * x + g0;
     const double f2 = (k3 * x + k2) * xx + k1 * x + k0;
     const double b1 = f1 * f2;
-    // magnitudes of the terms of the two factors: |p|, |q|, |r| <= 2 bounds the bracketed sums of f2 by 8 M, 72 M, 136 M,
-    // 136 M with M = (1 + a + b)^2 -- loose by up to ~30x, which only matters where f2 has lost
-    // ten digits to cancellation
-    const double s = 1 + a + b;
-    const double m1 = s * (xx + 1) + 2 * (1 + a) * x;
-    const double m2 = 136 * s * s * (x + 1) * (xx + 1);
-    // two evaluations of b1 differ by the rounding of the factors (SCREEN_CU of their term magnitudes) and by what the
-    // root's own difference does to it (first order: |b1'(x)| dx)
-    const double db1 = (fabs(f1) * m2 + fabs(f2) * m1) * SCREEN_CU +
-                       fabs((2 * g2 * x + g1) * f2 + f1 * ((3 * k3 * x + 2 * k2) * x + k1)) * x * relx;
-    const double fb1 = fabs(b1);
-    ESAC_SCREEN_HIST(5, (fabs(f1) * m2 + fabs(f2) * m1) * SCREEN_CU / fb1);
-    ESAC_SCREEN_HIST(6, fabs((2 * g2 * x + g1) * f2 + f1 * ((3 * k3 * x + 2 * k2) * x + k1)) * x * relx / fb1);
-    ESAC_SCREEN_HIST(7, fabs(f1) / m1);
-    ESAC_SCREEN_HIST(8, fabs(f2) / m2);
-    if (!(fb1 * SCREEN_REL > db1)) {  // sign of b1 or the value of y = b1 / b0 not reproducible (covers b1 ~ 0 and NaN)
+    // How far can b1 -- its sign, and the depth ratio y = b1 / b0 -- be from the exact route's?  By the rounding of the two
+    // factors (SCREEN_CU of the magnitudes of their terms: |p|, |q|, |r| <= 2 bounds the bracketed sums of f2 by 8 M, 72 M,
+    // 136 M, 136 M with M = (1 + a + b)^2 -- loose by up to ~30x, which only matters where f2 has lost ten digits to
+    // cancellation) and by what the root's own difference does to it (first order: |b1'(x)| dx).  Bookkeeping: fp32.
+    const float xf = (float)x, xxf = xf * xf, sf = 1 + (float)a + (float)b;
+    const float f1f = (float)fabs(f1), f2f = (float)fabs(f2);
+    const float m1 = sf * (xxf + 1) + 2 * (1 + (float)a) * xf;
+    const float m2 = 136 * sf * sf * (xf + 1) * (xxf + 1);
+    const float db1x = fabsf((2 * (float)g2 * xf + (float)g1) * (float)f2 + (float)f1 * ((3 * (float)k3 * xf + 2 * (float)k2) * xf + (float)k1)) * dx;
+    const float db1 = (f1f * m2 + f2f * m1) * (float)SCREEN_CU + db1x;
+    const float fb1 = f1f * f2f;
+    ESAC_SCREEN_HIST(5, (f1f * m2 + f2f * m1) * (float)SCREEN_CU / fb1);
+    ESAC_SCREEN_HIST(6, db1x / fb1);
+    ESAC_SCREEN_HIST(7, f1f / m1);
+    ESAC_SCREEN_HIST(8, f2f / m2);
+    if (!(fb1 * (float)SCREEN_REL > db1)) {  // sign of b1 or the value of y = b1 / b0 not reproducible (covers b1 ~ 0 and NaN)
         ESAC_SCREEN_STAT(6);
         return -1;
     }
@@ -584,11 +424,11 @@ ESAC_HD bool screen_scene(const float (&Pf)[4][3], ScreenScene& sc) {
     sc.P0 = P0;
     sc.l1 = dotf(pe1, pe1); sc.l2 = dotf(pe2, pe2); sc.l3 = dotf(pe3, pe3);
     if (!(sc.l1 > 0) || !(sc.l2 > 0) || !(sc.l3 > 0)) return false;
-    sc.e1 = (1.0f / sqrtf(sc.l1)) * pe1;
+    sc.e1 = scr_rsqf(sc.l1) * pe1;
     V3f e3 = crossf(sc.e1, pe2);
     const float n3 = dotf(e3, e3);
     if (!(n3 > 1e-8f * sc.l2)) return false;  // (near-)collinear sample
-    sc.e3 = (1.0f / sqrtf(n3)) * e3;
+    sc.e3 = scr_rsqf(n3) * e3;
     sc.e2 = crossf(sc.e3, sc.e1);
     const V3f w = P3 - P0;
     sc.c1 = dotf(w, sc.e1); sc.c2 = dotf(w, sc.e2); sc.c3 = dotf(w, sc.e3);
@@ -606,19 +446,19 @@ ESAC_HD float screen_candidate(const ScreenScene& sc, const float (&mu)[3], cons
     const float m1 = dotf(qe1, qe1), m2 = dotf(qe2, qe2), m3s = dotf(qe3, qe3);
     if (!(fabsf(m1 - sc.l1) <= congruence * sc.l1) || !(fabsf(m2 - sc.l2) <= congruence * sc.l2) || !(fabsf(m3s - sc.l3) <= congruence * sc.l3))
         return ESAC_SCREEN_MAYBE;
-    const V3f f1 = (1.0f / sqrtf(m1)) * qe1;
+    const V3f f1 = scr_rsqf(m1) * qe1;
     V3f f3 = crossf(f1, qe2);
     const float m3 = dotf(f3, f3);
     if (!(m3 > 1e-8f * m2)) return ESAC_SCREEN_MAYBE;
-    f3 = (1.0f / sqrtf(m3)) * f3;
+    f3 = scr_rsqf(m3) * f3;
     const V3f f2 = crossf(f3, f1);
     const float Xc = Q0.x + sc.c1 * f1.x + sc.c2 * f2.x + sc.c3 * f3.x;
     const float Yc = Q0.y + sc.c1 * f1.y + sc.c2 * f2.y + sc.c3 * f3.y;
     const float Zc = Q0.z + sc.c1 * f1.z + sc.c2 * f2.z + sc.c3 * f3.z;
     if (!(fabsf(Zc) > 1e-3f * (fabsf(Xc) + fabsf(Yc) + 1e-6f))) return ESAC_SCREEN_MAYBE;  // 4th point next to the camera plane
-    const float iz = 1.0f / Zc;
+    const float iz = scr_rcpf(Zc);
     const float du = cx + f * Xc * iz - mu3_px, dv = cy + f * Yc * iz - mv3_px;
-    const float epx = sqrtf(du * du + dv * dv);
+    const float epx = scr_sqrtf(du * du + dv * dv);
     if (!(epx == epx)) return ESAC_SCREEN_MAYBE;
     return epx;
 }

@@ -95,9 +95,7 @@ extern "C" void probe_screen(const float* coords, int H, int W, int sub, int shx
             const bool ok = solved && accept64(Rp, Tp, Pf, mu, mv, cam, (double)tau);
             int reason = 0;
             float e;
-            if (mode == 0) {
-                e = p3p_screen_err(Pf, muf, mvf, f, cx, cy, &reason);
-            } else if (mode == 3 || mode == 7) {  // 7 = also print false rejects; what k_sample_prescreen / k_sample_screened run: the screen's private fast copy of the roots
+            if (mode == 3 || mode == 7) {  // 7 = also print false rejects; what k_sample_prescreen / k_sample_screened run: the screen's private fast copy of the roots
                 ScreenSetup S;
                 e = screen_setup(Pt, mu, mv, cam, S) ? p3p_screen_roots(S, Pf, muf[3], mvf[3], f, cx, cy) : INFINITY;
                 if (mode == 7 && ok && e != ESAC_SCREEN_MAYBE && !(e <= tau + 3.0f)) {

@@ -4,6 +4,8 @@
 is written next to this file so that it travels with the source tree (it is
 git-ignored, not gpurun-ignored).
 """
+import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -12,13 +14,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libesac_hip.so")
 SOURCES = ["esac_kernels.hip", "esac_score_tiled.hip", "esac_refine.hip", "esac_backward.hip", "esac_capi.hip"]
-import glob
-
 # every header under csrc/ (a new one must not be forgotten here: a stale library would be tested against new headers)
 HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join("..", "..", "include", "esac_hip.h")]
 # -ffp-contract=off: the fp64 "exact" kernels follow IEEE op-by-op like the CPU
 # code they are compared with; the fp32 streaming kernel asks for FMAs explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources, headers and the C ABI header: what a profile under profiles/
+    was measured on (scripts/profile_to_json.py stamps it, bench.py compares it with the running tree)."""
+    h = hashlib.sha256()
+    for name in sorted(SOURCES + HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(os.path.basename(name).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def _hipcc():

@@ -154,8 +154,7 @@ __device__ __forceinline__ void block_sum28(double (&v)[NV], double* s_part, dou
 // Batched calls (esac_hip_forward_batch): workgroups with blockIdx.y = b serve frame b.  Every per-call
 // buffer is laid out frame-major, so a frame's view is the same KArgs with offset pointers; frame b draws
 // the RNG streams of call + b, which makes a batch bit-identical to B sequential calls.
-__device__ __forceinline__ void frame_view(KArgs& a) {
-    const int fr = blockIdx.y;
+__device__ __forceinline__ void frame_view(KArgs& a, int fr) {
     if (fr == 0) return;
     const size_t N = (size_t)a.N, P = (size_t)a.H * a.W, f = (size_t)fr;
     a.sc += f * a.sc_frame_stride;
@@ -185,6 +184,8 @@ __device__ __forceinline__ void frame_view(KArgs& a) {
     if (a.result_user) a.result_user += f * 32;
     if (a.result_pin) a.result_pin += f * ESAC_PIN_DOUBLES;
 }
+
+__device__ __forceinline__ void frame_view(KArgs& a) { frame_view(a, (int)blockIdx.y); }
 
 // expert of hypothesis h.  With a single expert the answer is known without the (dependent, ~0.5 us) load every kernel
 // would otherwise start with; hypAssignment values other than 0 are meaningless there (esac.cpp:189 would return them).

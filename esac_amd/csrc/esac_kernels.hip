@@ -140,6 +140,22 @@ __device__ __forceinline__ size_t user_slot(const KArgs& a, int h) {
 }
 
 constexpr int SAMPLE_PENDING = -2;  // tries[h] between the two phases of the throughput-shaped sampling
+// hypothesis h of this frame goes on to the screened chain (k_sample_prescreen works from the list).  Called by the
+// lanes of a wavefront that have one (`mine`; all lanes must call): one atomic per wavefront reserves the list slots.
+__device__ __forceinline__ void mark_pending(const KArgs& a, int h, bool mine) {
+    const unsigned long long m = __ballot(mine);
+    if (!m) return;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(a.samp_count + 1, __popcll(m));
+    base = __shfl(base, leader);
+    if (!mine) return;
+    a.tries[h] = SAMPLE_PENDING;
+    a.best_try[h] = ~0ull;          // k_sample_decide: lowest accepted try << 32 | its list position
+    a.samp_resume[h] = 0x7fffffff;  // k_sample_prescreen: first try not screened yet
+    a.samp_round[h] = 0;
+    a.samp_pending[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)blockIdx.y * a.N + h;
+}
 constexpr int FIRST_PHASE_TRIES = 16;
 #ifndef ESAC_FIRST_PHASE_PASSES
 #define ESAC_FIRST_PHASE_PASSES 2
@@ -179,18 +195,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     const unsigned long long m = __ballot(accepted);
     const unsigned mine = (unsigned)(m >> (16 * grp)) & 0xffffu;
-    if (!mine_pending) return;
-    if (mine) {
-        const int first = __ffs((int)mine) - 1;
-        if ((lane & 15) == first) store_hypothesis(a, h, map, rvec, T, R, cx, cy, a.first_try + first);
-    } else if (a.max_tries <= a.first_try + FIRST_PHASE_TRIES) {
-        if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
-    } else if ((lane & 15) == 0) {
-        a.tries[h] = SAMPLE_PENDING;
-        a.best_try[h] = ~0ull;          // k_sample_decide: lowest accepted try << 32 | its list position
-        a.samp_resume[h] = 0x7fffffff;  // k_sample_prescreen: first try not screened yet
-        a.samp_round[h] = 0;
+    bool to_chain = false;  // this lane lists its hypothesis for the screened chain
+    if (mine_pending) {
+        if (mine) {
+            const int first = __ffs((int)mine) - 1;
+            if ((lane & 15) == first) store_hypothesis(a, h, map, rvec, T, R, cx, cy, a.first_try + first);
+        } else if (a.max_tries <= a.first_try + FIRST_PHASE_TRIES) {
+            if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
+        } else if ((lane & 15) == 0) {
+            // only the pass that leaves a hypothesis pending for the chain -- the last one -- lists it (a later pass of
+            // k_sample_first finds it pending already)
+            if (a.first_try + FIRST_PHASE_TRIES >= a.handover) to_chain = true;
+            else a.tries[h] = SAMPLE_PENDING;
+        }
     }
+    mark_pending(a, h, to_chain);  // (wave-uniform call: one atomic per wavefront)
 }
 
 // SAMPLE_B = tries evaluated per round.  A single call wants latency (256 tries = 4 wavefronts per hypothesis:
@@ -290,12 +309,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             return;
         }
         if (base + TRIES >= a.handover) {  // a straggler (wrong expert): the spread, screened search takes over from here
-            if (threadIdx.x == 0) {
-                a.tries[h] = SAMPLE_PENDING;
-                a.best_try[h] = ~0ull;
-                a.samp_resume[h] = 0x7fffffff;
-                a.samp_round[h] = 0;
-            }
+            if (threadIdx.x < 64) mark_pending(a, h, threadIdx.x == 0);
             return;
         }
     }
@@ -327,10 +341,10 @@ constexpr int SCREEN_QUEUE = 128;  // >= SCREEN_FLUSH - 1 + 64
 //                       but a handful of cases), or when the budget is spent;
 //   k_sample_decide     one LANE per listed try, all hypotheses together (a wrong-expert hypothesis lists 2-3 tries out
 //                       of ~10^3): the full fp64 decision, atomicMin of the accepted try per hypothesis;
-//   k_sample_commit     one lane per pending hypothesis: re-solves the accepted try (same code, same result) and stores
-//                       the hypothesis -- or the state of the last try when the budget ran out without one;
-//   k_sample_screened<true>  the rare hypothesis whose stop turned out a false alarm continues from its resume round,
-//                       screening and deciding in one kernel as before.
+//   k_sample_screened<true>  one wavefront per pending hypothesis: commits the accepted try (copies the record the
+//                       decision parked with its list entry); the rare hypothesis whose stop turned out a false alarm
+//                       continues from its resume round, screening and deciding in one kernel; a spent budget leaves the
+//                       state of the last try.
 // Every try below a hypothesis' resume point has been screened, every "maybe" among them decided: the minimum accepted
 // try is the try the reference's sequential loop stops at (esac_util.h:152-223).
 // gridDim.z wavefronts share a hypothesis.  The rounds (64 tries each) are handed out IN ORDER by a per-hypothesis counter
@@ -341,9 +355,16 @@ constexpr int SCREEN_QUEUE = 128;  // >= SCREEN_FLUSH - 1 + 64
 // wavefront saw a strong candidate (atomicMin; 0x7fffffff until then).  With few hypotheses pending (a single frame with
 // some wrong-expert stragglers) that divides the length of the tail by the number of wavefronts that are resident.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_prescreen(KArgs a) {
-    frame_view(a);
-    const int h = blockIdx.x, lane = threadIdx.x;
-    if (a.tries[h] != SAMPLE_PENDING) return;
+    // Every wavefront of the launch works: wavefront L serves pending hypothesis L % count of the list the first passes
+    // built (k_sample / k_sample_first: mark_pending), so a frame with 50 stragglers among 1024 hypotheses puts ~80
+    // wavefronts on each of them instead of dispatching 65,000 workgroups that find their own hypothesis settled, and a
+    // launch sized for the chip (a few thousand wavefronts) is enough whatever the number of pending hypotheses is.
+    const int count = min(a.samp_count[1], a.N * a.frames);
+    if (count == 0) return;
+    const long long L = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int entry = a.samp_pending[(int)(L % count)];
+    const int fr = entry / a.N, h = entry - fr * a.N, lane = threadIdx.x;
+    frame_view(a, fr);
     const int e = expert_of(a, h);
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
@@ -381,7 +402,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (lane == 0) pos0 = atomicAdd(a.samp_count, cnt);
             pos0 = __shfl(pos0, 0);
             const int pos = pos0 + __popcll(m & ((1ull << lane) - 1ull));
-            if (maybe && pos < a.samp_cap) reinterpret_cast<int2*>(a.samp_entries)[pos] = make_int2(blockIdx.y * a.N + h, t);
+            if (maybe && pos < a.samp_cap) reinterpret_cast<int2*>(a.samp_entries)[pos] = make_int2(entry, t);
             // list full (the counter stays beyond the capacity, readers clamp; every slot below the capacity is written by
             // exactly one lane): this round is not fully listed, so the hypothesis resumes AT it
             if (pos0 + cnt > a.samp_cap) {
@@ -449,53 +470,8 @@ __global__ __launch_bounds__(64) void k_sample_decide(KArgs a0) {
     if (accepted) atomicMin(a0.best_try + hg, ((unsigned long long)(unsigned)t << 32) | (unsigned)i);
 }
 
-// one lane per pending hypothesis: copy the accepted try's record, or re-solve the last try when the budget is spent
-// without one (its state remains: esac_util.h:152-223 leaves the pose of the final iteration, a failed solve the zero pose)
-__global__ __launch_bounds__(64) void k_sample_commit(KArgs a0) {
-    KArgs a = a0;
-    frame_view(a);
-    const int h = blockIdx.x * 64 + threadIdx.x;
-    if (h >= a.N || a.tries[h] != SAMPLE_PENDING) return;
-    const unsigned long long found = a.best_try[h];
-    // An accepted try only counts if every try below it has been screened: with several wavefronts per hypothesis one of
-    // them may have run ahead of the final resume point (a "strong" candidate that the decision then rejected) -- such an
-    // entry is ignored here and found again, in order, by k_sample_screened<true>.
-    if (found != ~0ull && (int)(found >> 32) < a.samp_resume[h]) {
-        const double* cd = a0.samp_cand + (size_t)(unsigned)found * 16;
-        double* hp = a.hyps + (size_t)h * 6;
-#pragma unroll
-        for (int k = 0; k < 6; k++) hp[k] = cd[k];
-        const float* cf = reinterpret_cast<const float*>(cd + 6);
-        float* rt = a.rt32 + (size_t)h * 12;
-#pragma unroll
-        for (int k = 0; k < 12; k++) rt[k] = cf[k];
-        const int* ci = reinterpret_cast<const int*>(cd + 12);
-        int* sx = a.sample_xy + (size_t)h * 8;
-#pragma unroll
-        for (int k = 0; k < 8; k++) sx[k] = ci[k];
-        a.tries[h] = (int)(found >> 32);
-        return;
-    }
-    if (a.samp_resume[h] > a.max_tries) a.samp_resume[h] = a.max_tries;  // no stop: the whole budget has been screened
-    if (a.samp_resume[h] < a.max_tries) return;  // false alarm / full list: k_sample_screened<true> continues
-    const int t = a.max_tries - 1;
-    const int e = expert_of(a, h);
-    const int P = a.H * a.W;
-    const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
-    const Philox rng(a.seed, a.call);
-    const Cam cam = make_cam(a);
-    int cx[4], cy[4];
-    V3 Pt[4];
-    float Pf[4][3];
-    double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
-    double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
-    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    gather_sample(a, map, P, rng, (uint32_t)global_hyp(a, h), (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-    if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2)) accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
-    store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);
-}
-
-// RESUME: continue where k_sample_prescreen stopped (its parked tries preloaded into the queue).
+// RESUME: the end of the screened chain -- commit the accepted try of a pending hypothesis, or continue where
+// k_sample_prescreen stopped.
 template <bool RESUME>
 __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
     __shared__ int s_queue[SCREEN_QUEUE];
@@ -513,7 +489,25 @@ __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
     const float thr = a.tau + SCREEN_MARGIN;
     int qcount = 0;  // wave-uniform
     long long first = a.first_try;
-    if (RESUME) first = a.samp_resume[h];  // everything below it has been screened and decided (k_sample_decide)
+    if (RESUME) {
+        // COMMIT: the lowest accepted try the decision kernel found for this hypothesis.  It only counts if every try below
+        // it has been screened: with several wavefronts per hypothesis one of them may have run ahead of the final resume
+        // point (a "strong" candidate that the decision then rejected) -- such an entry is ignored here and found again, in
+        // order, by the search below.  The record (rvec, tvec | 12 floats rt32 | 8 ints cells = 16 doubles) is copied by 16 lanes.
+        const unsigned long long found = a.best_try[h];
+        int resume = a.samp_resume[h];
+        if (found != ~0ull && (int)(found >> 32) < resume) {
+            const double* cd = a.samp_cand + (size_t)(unsigned)found * 16;
+            if (lane < 6) a.hyps[(size_t)h * 6 + lane] = cd[lane];
+            else if (lane < 12) reinterpret_cast<double*>(a.rt32 + (size_t)h * 12)[lane - 6] = cd[lane];   // 12 floats = 6 doubles (48-byte rows: 8-byte aligned)
+            else if (lane < 16) reinterpret_cast<double*>(a.sample_xy + (size_t)h * 8)[lane - 12] = cd[lane];  // 8 ints = 4 doubles
+            if (lane == 0) a.tries[h] = (int)(found >> 32);
+            return;
+        }
+        // no accepted try below the resume point: a false alarm / a full list (continue from there), or no stop at all
+        // (the whole budget has been screened: the pass below re-solves the last try, whose state remains)
+        first = resume > a.max_tries ? a.max_tries : resume;
+    }
     for (long long base = first;; base += 64) {
         const bool more = base < a.max_tries;
         bool strong = false;
@@ -1095,18 +1089,20 @@ void launch_shard_balanced(const int64_t* assign, int N, int E, int world, int r
 void launch_stats_exact(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_stats_exact<256>, dim3(1, a.frames), dim3(256), 0, s, a);
 }
-// the chain that finishes hypotheses left SAMPLE_PENDING at try b.first_try (see k_sample_prescreen)
-static void launch_sample_stragglers(const KArgs& b, int waves_per_hyp, hipStream_t s) {
-    (void)hipMemsetAsync(b.samp_count, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_sample_prescreen, dim3(b.N, b.frames, waves_per_hyp), dim3(64), 0, s, b);
+// the chain that finishes hypotheses left SAMPLE_PENDING at try b.first_try (see k_sample_prescreen); `waves` wavefronts
+// in all work through the list of pending hypotheses
+static void launch_sample_stragglers(const KArgs& b, int waves, hipStream_t s) {
+    const int gx = b.N < waves ? b.N : waves;  // (the shape only spreads the linear wavefront index over three dimensions)
+    const int gz = (waves + gx * b.frames - 1) / (gx * b.frames);
+    hipLaunchKernelGGL(k_sample_prescreen, dim3(gx, b.frames, gz < 1 ? 1 : gz), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sample_decide, dim3((b.samp_cap + 63) / 64), dim3(64), 0, s, b);
-    hipLaunchKernelGGL(k_sample_commit, dim3((b.N + 63) / 64, b.frames), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sample_screened<true>, dim3(b.N, b.frames), dim3(64), 0, s, b);
 }
 
 void launch_sample(const KArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.frames;
     if (a.sc4) hipLaunchKernelGGL(k_pack_cells, dim3(2048), dim3(256), 0, s, a);
+    (void)hipMemsetAsync(a.samp_count, 0, 2 * sizeof(int), s);  // entries of the "maybe" list, hypotheses of the pending list
     KArgs b = a;
     b.handover = 0x7fffffff;
     // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on four lanes at first)
@@ -1125,29 +1121,45 @@ void launch_sample(const KArgs& a, hipStream_t s) {
 #ifndef ESAC_HANDOVER
 #define ESAC_HANDOVER 64
 #endif
-#ifndef ESAC_WPH_K
-#define ESAC_WPH_K 131072  // A/B on one box: 32768 / 65536 / 131072 / 524288 -> config 5a 2.18 / 2.00 / 1.95 / 2.18 ms, config 4 0.399 / 0.357 / 0.348 / 0.372 ms
+    // wavefronts of the screened chain: every one of them works whatever the number of pending hypotheses is (they take the
+    // 64-try rounds of the hypotheses on the list in order), so the launch is sized for the chip -- 2048 wavefronts are
+    // resident at two per SIMD -- with some slack for the tail; when (nearly) every hypothesis is pending, as in the
+    // 50-expert workloads, eight per hypothesis measured best (A/B on one box, config 5a: 4 / 8 / 32 per hypothesis ->
+    // 2.00 / 1.95 / 2.18 ms)
+#ifndef ESAC_CHAIN_WAVES
+#define ESAC_CHAIN_WAVES 8192
 #endif
-    const int wph = (int)(ESAC_WPH_K / total) < 1 ? 1 : (int)(ESAC_WPH_K / total) > 64 ? 64 : (int)(ESAC_WPH_K / total);
+    const long long w8 = 8 * total;
+    const int waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > 131072 ? 131072 : w8));
     if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
         if (handover) b.handover = ESAC_HANDOVER;
-        hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, b);
+        // up to 256 hypotheses: four wavefronts each (64 tries per round, one workgroup per CU at this kernel's ~440
+        // registers).  Beyond that the workgroups queue up behind each other (1024 hypotheses: four ~12 us rounds back to
+        // back, 51 us measured): two wavefronts per hypothesis (32 tries per round -- 93 % of the hypotheses of a usable
+        // map are settled in it) put two hypotheses on a CU at a time.
+        if (total <= 256) hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, b);
+        else              hipLaunchKernelGGL((k_sample<128, true>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else if (total <= 4096 && !handover) {
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
+        b.handover = FIRST_PHASE_PASSES * FIRST_PHASE_TRIES;  // the pass that reaches it lists what it leaves pending
         for (int pass = 0; pass < FIRST_PHASE_PASSES && b.first_try < a.max_tries; pass++) {
             hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
             b.first_try += FIRST_PHASE_TRIES;
         }
         if (b.first_try < a.max_tries) {
-            if (exact) hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);  // every try solved in full
-            else       launch_sample_stragglers(b, wph, s);
+            if (exact) {
+                b.handover = 0x7fffffff;
+                hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);  // every try solved in full
+            } else {
+                launch_sample_stragglers(b, waves, s);
+            }
         }
         return;
     }
     if (handover) {
         b.first_try = b.handover;
-        launch_sample_stragglers(b, wph, s);
+        launch_sample_stragglers(b, waves, s);
     }
 }
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {

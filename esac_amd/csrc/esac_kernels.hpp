@@ -81,7 +81,8 @@ struct KArgs {
     unsigned long long* best_try;  // [N] k_sample_decide: (lowest accepted try << 32 | list position) among the listed ones, ~0: none
     double* samp_cand;    // [samp_cap,16] solved hypothesis of an accepted list entry: rvec,tvec | 12 floats rt32 | 8 ints cells
     int* samp_entries;    // [samp_cap] (frame * N + hypothesis, try) pairs: the tries the screen could not rule out
-    int* samp_count;      // [1] entries appended (may exceed samp_cap: clamp)
+    int* samp_count;      // [2] entries appended to samp_entries (may exceed samp_cap: clamp); hypotheses appended to samp_pending
+    int* samp_pending;    // [N] (frame * N + hypothesis) of every hypothesis the first passes left SAMPLE_PENDING
     int samp_cap;
     float* fast_scores;   // [N]
     double* scores;       // [N]

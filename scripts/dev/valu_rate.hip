@@ -1,6 +1,10 @@
-// valu_rate.hip -- issue cost of fp32 VALU instruction classes on gfx950, one wavefront per SIMD and eight:
-// cycles per wave-instruction for v_fma_f32, v_rcp_f32, v_exp_f32, v_sqrt_f32 (8 independent chains each, so the
-// dependent-op latency does not show).   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
+// valu_rate.hip -- issue cost of VALU instruction classes on gfx950, one wavefront per SIMD and four: v_fma_f32,
+// v_rcp_f32, v_exp_f32, v_sqrt_f32, v_pk_fma_f32, v_fma_f64 (8 independent chains each, so the dependent-op latency does
+// not show).  The figure scripts/profile_to_json.py prices instruction counts with is the FIRST column: kernel wall time
+// (HIP events) x the nominal 2.4 GHz / wave-instructions issued per SIMD.  clock64() is printed next to it for
+// reference only: it is NOT the shader clock under load (its rate against wall time wanders between 0.6 and 2.4 GHz
+// with occupancy), so "cycles" read from it do not convert to time.
+//   hipcc --offload-arch=gfx950 -O3 valu_rate.hip -o valu_rate && ./valu_rate
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
@@ -52,17 +56,14 @@ void run(const char* name, int per_iter, int threads) {
     float ms; hipEventElapsedTime(&ms, a, b);
     long long h[256]; hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
     double mean = 0; for (int i = 0; i < 256; i++) mean += h[i]; mean /= 256;
-    const double insts = (double)iters * 64 * per_iter;  // wave-instructions per wave
+    const double insts = (double)iters * (KIND == 5 ? 32 : 64) * per_iter;  // wave-instructions per wave (KIND 5: a packed instruction every other slot)
     const int waves_per_simd = threads / 256;
-    printf("%-28s %2d wave(s)/SIMD: %.2f shader cycles per wave-instruction per wave, %.2f per SIMD; kernel %.3f ms -> %.2f GHz-equivalent\n",
-           name, waves_per_simd, mean / insts, mean / insts / waves_per_simd, ms, mean / (ms * 1e-3) / 1e9);
+    printf("%-28s %d wave(s)/SIMD: %5.2f cycles per wave-instruction (wall time x 2.4 GHz / instructions per SIMD)   [kernel %.3f ms; clock64: %.2f ticks per instruction per wave = %.2f GHz against wall time]\n",
+           name, waves_per_simd, ms * 1e-3 * 2.4e9 / (insts * waves_per_simd), ms, mean / insts, mean / (ms * 1e-3) / 1e9);
     hipFree(out); hipFree(cyc);
 }
 
 int main() {
-    for (int threads : {256, 1024, 2048 / 2}) {
-        (void)threads;
-    }
     run<0>("v_fma_f32", 1, 256);
     run<0>("v_fma_f32", 1, 1024);
     run<1>("v_rcp_f32", 1, 256);
@@ -73,7 +74,7 @@ int main() {
     run<3>("v_sqrt_f32", 1, 1024);
     run<4>("v_rcp + 3 v_fma", 4, 256);
     run<4>("v_rcp + 3 v_fma", 4, 1024);
-    run<5>("v_pk_fma_f32 (per pk instr)", 1, 256);   // 4 pk instructions per 8 slots: per_iter counts the slots
+    run<5>("v_pk_fma_f32 (per pk instr)", 1, 256);
     run<5>("v_pk_fma_f32 (per pk instr)", 1, 1024);
     run<6>("v_fma_f64", 1, 256);
     run<6>("v_fma_f64", 1, 1024);

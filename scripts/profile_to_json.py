@@ -15,6 +15,10 @@ import argparse
 import json
 import os
 import sqlite3
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from esac_amd import build as _build  # noqa: E402
 
 CYC_PLAIN, CYC_TRANS32, CYC_F64, CLOCK_MHZ, SIMDS = 3.0, 8.7, 4.9, 2400.0, 1024
 
@@ -27,6 +31,7 @@ def main():
     ap.add_argument("--pmc", nargs="*", default=[])
     ap.add_argument("--command", default="")
     ap.add_argument("--out-dir", default="profiles")
+    ap.add_argument("--head", default="", help="git commit the profiled tree belongs to (the GPU box has no .git: stamped when the summary is copied into profiles/)")
     a = ap.parse_args()
     db = sqlite3.connect(a.stats)
     kernels = {}
@@ -73,6 +78,9 @@ def main():
                 k["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (k["avg_us"] * CLOCK_MHZ * simds)
         k["counters"] = {n: v for n, v in c.items()}
     out = {"config": a.config, "round": a.round, "command": a.command, "steps_profiled": steps,
+           # what was measured: hash of esac_amd/csrc + include/esac_hip.h (bench.py flags the profile as stale when the
+           # running tree differs) and the commit it belongs to
+           "csrc_sha16": _build.source_hash(), "head": a.head,
            "issue_cost_model": {"cycles_per_wave_instruction": {"plain_valu": CYC_PLAIN, "fp32_transcendental": CYC_TRANS32, "fp64": CYC_F64},
                                 "clock_mhz": CLOCK_MHZ, "source": "scripts/dev/valu_rate.hip on MI355X (profiles/%s_valu_rate.txt)" % a.round},
            "kernels": sorted(kernels.values(), key=lambda k: -k["total_us"])}

@@ -278,6 +278,7 @@ def test_bench_default_line_has_the_contract_fields():
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] in ("port", "reference")
     assert d["accuracy"]["winner_match"] == 1.0 and d["accuracy"]["max_rot_err_rad"] <= 1e-4 and d["accuracy"]["max_trans_err_m"] <= 1e-3
     assert [k["stage"] for k in d["kernels"]] == ["sample", "score", "select_rescore", "refine"]
+    assert d["value_seed1305"] > 0 and d["profile_stale"] in (True, False, None)
 
 
 def _adversarial_frame(kind, E=3):

@@ -353,7 +353,11 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
         // fp32 screening: a cell whose fp32 error is farther from tau than the bound above cannot change
         // side under the reference arithmetic.  Only cells inside that band -- a few per ten thousand --
         // pay for the exact fp64 evaluation, so `err < tau` is decided exactly everywhere.
+        // Two cells per packed instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): with ONE wavefront on the SIMD a
+        // packed FMA issues in 6.5 cycles against 5.5 for a plain one (scripts/dev/valu_rate.hip) -- 1.7x on the
+        // arithmetic of this pass; component by component the same operations in the same order as the plain form.
         bool need[U];
+#ifdef ESAC_ERR_SCALAR  // A/B switch (scripts/dev/variants.sh): the plain form
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const float xc = fmaf(Rf[0], X[u], fmaf(Rf[1], Y[u], fmaf(Rf[2], Z[u], tf[0])));
@@ -365,9 +369,32 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
             errv[u] = __builtin_amdgcn_sqrtf(fmaf(du, du, dv * dv));
             const float aiz = fabsf(iz), axy = fabsf(xc) + fabsf(yc);
             const float guard = fmaf(kf * aiz * (axy + fabsf(zc) + tmag2), fmaf(axy, aiz, 1.0f), kpix);
-            // not finite, or within the band -> the second screen / the reference-exact evaluation decides
             need[u] = !(fabsf(errv[u] - a.tau) > guard);
         }
+#else
+#pragma unroll
+        for (int u = 0; u < U; u += 2) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            auto sp = [](float v) { return f2{v, v}; };
+            auto fma2 = [](f2 x, f2 y, f2 z) { return __builtin_elementwise_fma(x, y, z); };
+            auto abs2 = [](f2 v) { return f2{fabsf(v.x), fabsf(v.y)}; };
+            const f2 Xp = {X[u], X[u + 1]}, Yp = {Y[u], Y[u + 1]}, Zp = {Z[u], Z[u + 1]};
+            const f2 xc = fma2(sp(Rf[0]), Xp, fma2(sp(Rf[1]), Yp, fma2(sp(Rf[2]), Zp, sp(tf[0]))));
+            const f2 yc = fma2(sp(Rf[3]), Xp, fma2(sp(Rf[4]), Yp, fma2(sp(Rf[5]), Zp, sp(tf[1]))));
+            const f2 zc = fma2(sp(Rf[6]), Xp, fma2(sp(Rf[7]), Yp, fma2(sp(Rf[8]), Zp, sp(tf[2]))));
+            const f2 iz = {(zc.x != 0.0f) ? __builtin_amdgcn_rcpf(zc.x) : 1.0f, (zc.y != 0.0f) ? __builtin_amdgcn_rcpf(zc.y) : 1.0f};
+            const f2 du = f2{pxf[u], pxf[u + 1]} - fma2(sp(a.focal), xc * iz, sp(a.ppx));
+            const f2 dv = f2{pyf[u], pyf[u + 1]} - fma2(sp(a.focal), yc * iz, sp(a.ppy));
+            const f2 d2 = fma2(du, du, dv * dv);
+            errv[u] = __builtin_amdgcn_sqrtf(d2.x);
+            errv[u + 1] = __builtin_amdgcn_sqrtf(d2.y);
+            const f2 aiz = abs2(iz), axy = abs2(xc) + abs2(yc);
+            const f2 guard = fma2(sp(kf) * aiz * (axy + abs2(zc) + sp(tmag2)), fma2(axy, aiz, sp(1.0f)), sp(kpix));
+            // not finite, or within the band -> the second screen / the reference-exact evaluation decides
+            need[u] = !(fabsf(errv[u] - a.tau) > guard.x);
+            need[u + 1] = !(fabsf(errv[u + 1] - a.tau) > guard.y);
+        }
+#endif
         CYC_END(11);
         CYC_BEGIN();
         // Second screen, per sub-step and only where some lane asked for it (wave-uniform branches): the error in

@@ -1,7 +1,7 @@
 # profile one bench.py workload: kernel trace + the PMC passes (each its own run) -> profiles/<round>_<cfg>_kernels.{json,txt}
 # usage (on the GPU box): bash scripts/dev/profile_cfg.sh <cfg> <round> [extra bench args]
 R=$GRAFT_REPO_ROOT
-CFG=$1; RND=${2:-r02}; shift; shift
+CFG=$1; RND=${2:-r03}; shift; shift
 O=$R/gpurun_out/prof_${RND}_${CFG}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -161,6 +161,7 @@ __device__ __forceinline__ void frame_view(KArgs& a, int fr) {
     a.assign += f * N;
     a.call += (uint64_t)fr;
     a.hyps += f * N * 6;
+    a.hyps_R += f * N * 9;
     a.rt32 += f * N * 12;
     a.sample_xy += f * N * 8;
     a.tries += f * N;

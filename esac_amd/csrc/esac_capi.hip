@@ -95,7 +95,7 @@ extern "C" int esac_hip_device_count(void) {
 }
 
 static void free_ws(esac_hip_ctx* c) {
-    void* ptrs[] = {c->ws.hyps,       c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.samp_count, c->ws.samp_pending, c->ws.fast_scores,
+    void* ptrs[] = {c->ws.hyps,       c->ws.hyps_R,      c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.samp_count, c->ws.samp_pending, c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.sel_partials, c->ws.sel_arrived, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
                     c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials, c->ws.bucket_fill};
@@ -172,6 +172,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     free_ws(c);
     int rc = 0;
     rc |= alloc(&c->ws.hyps, (size_t)nN * 6);
+    rc |= alloc(&c->ws.hyps_R, (size_t)nN * 9);
     rc |= alloc(&c->ws.rt32, (size_t)nN * 12);
     rc |= alloc(&c->ws.status, (size_t)1);
     rc |= alloc(&c->ws.coop_partials, (size_t)2 * ESAC_REFINE_COOP_MAX * 32);
@@ -181,7 +182,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.samp_resume, (size_t)nN);
     rc |= alloc(&c->ws.samp_round, (size_t)nN);
     rc |= alloc(&c->ws.best_try, (size_t)nN);
-    rc |= alloc(&c->ws.samp_cand, (size_t)nN * ESAC_SAMPLE_LIST_PER_HYP * 16);
+    rc |= alloc(&c->ws.samp_cand, (size_t)nN * ESAC_SAMPLE_LIST_PER_HYP * ESAC_CAND_DOUBLES);
     rc |= alloc(&c->ws.samp_entries, (size_t)nN * 2 * ESAC_SAMPLE_LIST_PER_HYP);  // (hypothesis, try) pairs
     rc |= alloc(&c->ws.samp_count, (size_t)4);
     rc |= alloc(&c->ws.samp_pending, (size_t)nN);
@@ -397,14 +398,23 @@ extern "C" int esac_hip_score(esac_hip_ctx* c, const float* d_sc, const int64_t*
     });
 }
 extern "C" int esac_hip_select(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    return run_stage(c, d_sc, d_assign, p, stream, "k_select_rescore",
-                     [](esac_hip_ctx*, const KArgs& a, hipStream_t s) { launch_select_rescore(a, s); });
+    return run_stage(c, d_sc, d_assign, p, stream, "k_select_rescore", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) {
+        if (cc->rt32_stale) {  // hypotheses came from esac_hip_write_hyps: their rotation matrices have not been formed yet
+            launch_hyps_to_rt32(a, s);
+            cc->rt32_stale = false;
+        }
+        launch_select_rescore(a, s);
+    });
 }
 extern "C" int esac_hip_refine(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
     return run_stage(c, d_sc, d_assign, p, stream, "k_refine", [](esac_hip_ctx*, const KArgs& a, hipStream_t s) { launch_refine(a, s); });
 }
 extern "C" int esac_hip_score_exact(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    return run_stage(c, d_sc, d_assign, p, stream, "k_rescore(all)", [](esac_hip_ctx*, const KArgs& a, hipStream_t s) {
+    return run_stage(c, d_sc, d_assign, p, stream, "k_rescore(all)", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) {
+        if (cc->rt32_stale) {
+            launch_hyps_to_rt32(a, s);
+            cc->rt32_stale = false;
+        }
         launch_rescore_all(a, s);
         launch_stats_exact(a, s);  // softmax statistics of the exact scores (the record's probability / entropy)
     });

@@ -123,6 +123,9 @@ __device__ __forceinline__ void store_hypothesis(const KArgs& a, int h, const fl
     double* hp = a.hyps + (size_t)h * 6;
     hp[0] = rvec[0]; hp[1] = rvec[1]; hp[2] = rvec[2];
     hp[3] = T[0]; hp[4] = T[1]; hp[5] = T[2];
+    double* hr = a.hyps_R + (size_t)h * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) hr[k] = R[k];
     store_rt32(a, h, map, R, T);
     int* sx = a.sample_xy + (size_t)h * 8;
 #pragma unroll
@@ -195,7 +198,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
     const unsigned long long m = __ballot(accepted);
     const unsigned mine = (unsigned)(m >> (16 * grp)) & 0xffffu;
-    bool to_chain = false;  // this lane lists its hypothesis for the screened chain
     if (mine_pending) {
         if (mine) {
             const int first = __ffs((int)mine) - 1;
@@ -203,13 +205,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         } else if (a.max_tries <= a.first_try + FIRST_PHASE_TRIES) {
             if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
         } else if ((lane & 15) == 0) {
-            // only the pass that leaves a hypothesis pending for the chain -- the last one -- lists it (a later pass of
-            // k_sample_first finds it pending already)
-            if (a.first_try + FIRST_PHASE_TRIES >= a.handover) to_chain = true;
-            else a.tries[h] = SAMPLE_PENDING;
+            a.tries[h] = SAMPLE_PENDING;  // k_pending_list gathers what the last pass leaves pending
         }
     }
-    mark_pending(a, h, to_chain);  // (wave-uniform call: one atomic per wavefront)
+}
+
+// The hypotheses the first passes left pending, as a list for the screened chain (k_sample_prescreen): a ballot prefix per
+// wavefront, a block scan, ONE global atomic per 1024 hypotheses.  (Appending from k_sample_first itself -- 15,000 single-
+// lane atomics on one address at config 5a -- cost 20 us; one per wavefront still 10.)
+__global__ __launch_bounds__(1024) void k_pending_list(KArgs a) {
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
+    frame_view(a);
+    const int h = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool mine = h < a.N && a.tries[h] == SAMPLE_PENDING;
+    const unsigned long long m = __ballot(mine);
+    if (lane == 0) s_wave[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < 16; w++) {
+            const int c = s_wave[w];
+            s_wave[w] = tot;
+            tot += c;
+        }
+        s_base = tot ? atomicAdd(a.samp_count + 1, tot) : 0;
+    }
+    __syncthreads();
+    if (!mine) return;
+    a.best_try[h] = ~0ull;          // k_sample_decide: lowest accepted try << 32 | its list position
+    a.samp_resume[h] = 0x7fffffff;  // k_sample_prescreen: first try not screened yet
+    a.samp_round[h] = 0;
+    a.samp_pending[s_base + s_wave[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int)blockIdx.y * a.N + h;
 }
 
 // SAMPLE_B = tries evaluated per round.  A single call wants latency (256 tries = 4 wavefronts per hypothesis:
@@ -356,7 +383,7 @@ constexpr int SCREEN_QUEUE = 128;  // >= SCREEN_FLUSH - 1 + 64
 // some wrong-expert stragglers) that divides the length of the tail by the number of wavefronts that are resident.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_prescreen(KArgs a) {
     // Every wavefront of the launch works: wavefront L serves pending hypothesis L % count of the list the first passes
-    // built (k_sample / k_sample_first: mark_pending), so a frame with 50 stragglers among 1024 hypotheses puts ~80
+    // built (k_sample: mark_pending; k_pending_list after the first passes), so a frame with 50 stragglers among 1024 hypotheses puts ~80
     // wavefronts on each of them instead of dispatching 65,000 workgroups that find their own hypothesis settled, and a
     // launch sized for the chip (a few thousand wavefronts) is enough whatever the number of pending hypotheses is.
     const int count = min(a.samp_count[1], a.N * a.frames);
@@ -373,13 +400,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const float thr = a.tau + SCREEN_MARGIN;
     int* resume = a.samp_resume + h;
+    // Two round trips to L2 per 64-try round used to sit on this loop's critical path (~1.5 us each against ~6 us of
+    // arithmetic, at two wavefronts per SIMD): the ticket for the round (atomicAdd with return) and, whenever a lane said
+    // "maybe" (a third of the rounds), the slot in the global list.  The ticket for the NEXT round is now drawn while the
+    // current one is evaluated (a ticket drawn and never used is harmless: every way out of this loop means that later
+    // rounds need no screening), and the "maybe" tries are parked in LDS and flushed with one atomic when the wavefront
+    // leaves (or 64 of them have gathered).
+    __shared__ int s_park[128];  // tries; the wavefront serves ONE hypothesis
+    int parked = 0;              // wave-uniform
+    auto flush = [&]() {
+        // every parked try gets a slot of the global list; what does not fit any more moves the resume point of the
+        // hypothesis back to the (64-aligned) round of the first try that was dropped
+        for (int q0 = 0; q0 < parked; q0 += 64) {
+            const int nq = min(64, parked - q0);
+            int pos0 = 0;
+            if (lane == 0) pos0 = atomicAdd(a.samp_count, nq);
+            pos0 = __shfl(pos0, 0);
+            if (lane < nq) {
+                const int t = s_park[q0 + lane];
+                if (pos0 + lane < a.samp_cap) reinterpret_cast<int2*>(a.samp_entries)[pos0 + lane] = make_int2(entry, t);
+                else atomicMin(resume, a.first_try + ((t - a.first_try) & ~63));
+            }
+        }
+        parked = 0;
+    };
+    int r_next = 0;
+    if (lane == 0) r_next = atomicAdd(a.samp_round + h, 1);
+    int stop_at = __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
-        int r = 0;
-        if (lane == 0) r = atomicAdd(a.samp_round + h, 1);
-        r = __shfl(r, 0);
+        const int r = __shfl(r_next, 0);  // (waits for the ticket drawn one round ago)
         const long long base = a.first_try + 64LL * r;
         if (base >= a.max_tries) break;
-        if (base >= __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        if (base >= stop_at) break;  // (read one round ago as well: a stale value costs at most one superfluous round)
+        if (lane == 0) r_next = atomicAdd(a.samp_round + h, 1);
+        stop_at = __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int t = (int)base + lane;
         bool maybe = false, strong = false;
         if (t < a.max_tries) {
@@ -397,31 +451,32 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         const unsigned long long m = __ballot(maybe);
         if (m) {
-            const int cnt = __popcll(m);
-            int pos0 = 0;
-            if (lane == 0) pos0 = atomicAdd(a.samp_count, cnt);
-            pos0 = __shfl(pos0, 0);
-            const int pos = pos0 + __popcll(m & ((1ull << lane) - 1ull));
-            if (maybe && pos < a.samp_cap) reinterpret_cast<int2*>(a.samp_entries)[pos] = make_int2(entry, t);
-            // list full (the counter stays beyond the capacity, readers clamp; every slot below the capacity is written by
-            // exactly one lane): this round is not fully listed, so the hypothesis resumes AT it
-            if (pos0 + cnt > a.samp_cap) {
-                if (lane == 0) atomicMin(resume, (int)base);
-                break;
-            }
-            if (__any(strong)) {  // everything up to and including this round is listed: resume after it
+            if (maybe) s_park[parked + __popcll(m & ((1ull << lane) - 1ull))] = t;
+            parked += __popcll(m);
+            if (__any(strong)) {  // everything up to and including this round is (about to be) listed: resume after it
                 if (lane == 0) atomicMin(resume, (int)(base + 64 < a.max_tries ? base + 64 : a.max_tries));
                 break;
             }
+            if (parked > 64) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                flush();
+            }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    flush();
 }
 
-// one lane per listed try: the fp64 route's decision, lowest accepted try per hypothesis
+// the fp64 route's decision for every listed try, lowest accepted try per hypothesis.  One LANE per try when the list is
+// long (thousands of pending hypotheses: throughput); FOUR lanes per try -- lane q evaluates the candidate of quartic root
+// q, as in k_sample's first rounds -- when it holds few entries (a frame with some dozens of stragglers: the kernel is
+// then one dependent chain long, and the chain of a try is one candidate instead of up to four: 21 -> 12 us)
 __global__ __launch_bounds__(64) void k_sample_decide(KArgs a0) {
     const int n = min(a0.samp_count[0], a0.samp_cap);
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (blockIdx.x * 64 >= n) return;
+    const bool quad = 4LL * n <= (long long)gridDim.x * 64;  // kernel-uniform
+    const int slot = blockIdx.x * 64 + threadIdx.x;
+    const int i = quad ? slot >> 2 : slot;
+    if ((quad ? blockIdx.x * 16 : blockIdx.x * 64) >= n) return;
     bool accepted = false;
     int hg = 0, t = 0;
     if (i < n) {
@@ -444,20 +499,48 @@ __global__ __launch_bounds__(64) void k_sample_decide(KArgs a0) {
         float Pf[4][3];
         double mu[4], mv[4], Rp[9], Tp[3], reproj2 = 0;
         gather_sample(a0, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
-        if (p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2) && !cannot_pass(reproj2, (double)a0.tau)) {
+        bool solved;
+        if (quad) {  // the four lanes of this entry replay p3p_4pt's scan over the candidates (k_sample: same rule, same NaN behaviour)
+            const int lane = threadIdx.x, root = lane & 3, quad0 = lane & ~3;
+            P3PSetup S;
+            const bool ok = p3p_setup(Pt, mu, mv, cam, S);
+            const double x = root == 0 ? S.x[0] : root == 1 ? S.x[1] : root == 2 ? S.x[2] : S.x[3];
+            double reproj = 0;
+            const bool valid = ok && root < S.n && p3p_candidate(S, x, Pt, mu[3], mv[3], cam, Rp, Tp, reproj);
+            bool have = false;
+            double min_reproj = 0;
+            int win = -1;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool vi = __shfl((int)valid, quad0 + k) != 0;
+                const double ri = __shfl(reproj, quad0 + k);
+                if (vi && (!have || min_reproj > ri)) {
+                    have = true;
+                    min_reproj = ri;
+                    win = k;
+                }
+            }
+            solved = have && win == root;  // the lane that holds the chosen candidate carries on
+            reproj2 = min_reproj;
+        } else {
+            solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2);
+        }
+        if (solved && !cannot_pass(reproj2, (double)a0.tau)) {
             double rvec[3], T[3], R[9];
             accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a0.tau, rvec, T, R);
             if (accepted) {  // park the solved hypothesis with its list entry: the commit kernel only copies the winner's
-                double* cd = a0.samp_cand + (size_t)i * 16;
+                double* cd = a0.samp_cand + (size_t)i * ESAC_CAND_DOUBLES;
                 cd[0] = rvec[0]; cd[1] = rvec[1]; cd[2] = rvec[2]; cd[3] = T[0]; cd[4] = T[1]; cd[5] = T[2];
+#pragma unroll
+                for (int k = 0; k < 9; k++) cd[6 + k] = R[k];
                 const Centre c = map_centre(a0, map);
-                float* cf = reinterpret_cast<float*>(cd + 6);  // 12 floats: [R | t + R c] (store_rt32)
+                float* cf = reinterpret_cast<float*>(cd + 15);  // 12 floats: [R | t + R c] (store_rt32)
 #pragma unroll
                 for (int k = 0; k < 9; k++) cf[k] = (float)R[k];
                 cf[9] = (float)(R[0] * (double)c.x + R[1] * (double)c.y + R[2] * (double)c.z + T[0]);
                 cf[10] = (float)(R[3] * (double)c.x + R[4] * (double)c.y + R[5] * (double)c.z + T[1]);
                 cf[11] = (float)(R[6] * (double)c.x + R[7] * (double)c.y + R[8] * (double)c.z + T[2]);
-                int* ci = reinterpret_cast<int*>(cd + 12);     // 8 ints: the sampled cells
+                int* ci = reinterpret_cast<int*>(cd + 21);     // 8 ints: the sampled cells
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     ci[2 * j] = cx[j];
@@ -497,10 +580,11 @@ __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
         const unsigned long long found = a.best_try[h];
         int resume = a.samp_resume[h];
         if (found != ~0ull && (int)(found >> 32) < resume) {
-            const double* cd = a.samp_cand + (size_t)(unsigned)found * 16;
+            const double* cd = a.samp_cand + (size_t)(unsigned)found * ESAC_CAND_DOUBLES;
             if (lane < 6) a.hyps[(size_t)h * 6 + lane] = cd[lane];
-            else if (lane < 12) reinterpret_cast<double*>(a.rt32 + (size_t)h * 12)[lane - 6] = cd[lane];   // 12 floats = 6 doubles (48-byte rows: 8-byte aligned)
-            else if (lane < 16) reinterpret_cast<double*>(a.sample_xy + (size_t)h * 8)[lane - 12] = cd[lane];  // 8 ints = 4 doubles
+            else if (lane < 15) a.hyps_R[(size_t)h * 9 + lane - 6] = cd[lane];
+            else if (lane < 21) reinterpret_cast<double*>(a.rt32 + (size_t)h * 12)[lane - 15] = cd[lane];  // 12 floats = 6 doubles (48-byte rows: 8-byte aligned)
+            else if (lane < 25) reinterpret_cast<double*>(a.sample_xy + (size_t)h * 8)[lane - 21] = cd[lane];  // 8 ints = 4 doubles
             if (lane == 0) a.tries[h] = (int)(found >> 32);
             return;
         }
@@ -581,6 +665,8 @@ __global__ void k_hyps_to_rt32(KArgs a) {
     const double r[3] = {hp[0], hp[1], hp[2]};
     const double t[3] = {hp[3], hp[4], hp[5]};
     rodrigues_vec2mat<false>(r, R, nullptr);
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.hyps_R[(size_t)h * 9 + k] = R[k];
     store_rt32(a, h, a.sc + (size_t)expert_of(a, h) * 3 * a.H * a.W, R, t);
 }
 
@@ -768,10 +854,10 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
             const int e = expert_of(a, h);
             const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
             const double* hp = a.hyps + (size_t)h * 6;
-            const double rv[3] = {hp[0], hp[1], hp[2]};
             const double t[3] = {hp[3], hp[4], hp[5]};
-            double R[9];
-            rodrigues_vec2mat<false>(rv, R, nullptr);
+            double R[9];  // rodrigues_vec2mat(rvec) as the sampler stored it (the reference re-expands rvec, esac_util.h:302)
+#pragma unroll
+            for (int k = 0; k < 9; k++) R[k] = a.hyps_R[(size_t)h * 9 + k];
             double acc[1] = {0};
             for (int i = c0 + threadIdx.x; i < c1; i += B) {
                 const int row = i / a.W, col = i - row * a.W;
@@ -875,10 +961,10 @@ __global__ __launch_bounds__(B) void k_rescore(KArgs a) {
         const int e = expert_of(a, h);
         const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
         const double* hp = a.hyps + (size_t)h * 6;
-        const double rv[3] = {hp[0], hp[1], hp[2]};
         const double t[3] = {hp[3], hp[4], hp[5]};
         double R[9];
-        rodrigues_vec2mat<false>(rv, R, nullptr);
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = a.hyps_R[(size_t)h * 9 + k];
         double acc[1] = {0};
         for (int i = threadIdx.x; i < P; i += B) {
             const int row = i / a.W, col = i - row * a.W;
@@ -1129,7 +1215,10 @@ void launch_sample(const KArgs& a, hipStream_t s) {
 #ifndef ESAC_CHAIN_WAVES
 #define ESAC_CHAIN_WAVES 8192
 #endif
-    const long long w8 = 8 * total;
+#ifndef ESAC_CHAIN_PER_HYP
+#define ESAC_CHAIN_PER_HYP 8
+#endif
+    const long long w8 = (long long)ESAC_CHAIN_PER_HYP * total;
     const int waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > 131072 ? 131072 : w8));
     if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
         if (handover) b.handover = ESAC_HANDOVER;
@@ -1142,16 +1231,15 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     } else if (total <= 4096 && !handover) {
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
-        b.handover = FIRST_PHASE_PASSES * FIRST_PHASE_TRIES;  // the pass that reaches it lists what it leaves pending
         for (int pass = 0; pass < FIRST_PHASE_PASSES && b.first_try < a.max_tries; pass++) {
             hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
             b.first_try += FIRST_PHASE_TRIES;
         }
         if (b.first_try < a.max_tries) {
             if (exact) {
-                b.handover = 0x7fffffff;
                 hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);  // every try solved in full
             } else {
+                hipLaunchKernelGGL(k_pending_list, dim3((a.N + 1023) / 1024, a.frames), dim3(1024), 0, s, b);
                 launch_sample_stragglers(b, waves, s);
             }
         }
@@ -1183,7 +1271,10 @@ void launch_select_rescore(const KArgs& a, hipStream_t s) {
     const int split = (long long)a.H * a.W >= 32768 ? ESAC_SELECT_SPLIT : 1;
     const int cap = (a.frames > 1 ? 16 : 256) / split;
     const int grid = a.N < cap ? a.N : (cap < 1 ? 1 : cap);
-    if (split == 1 && a.N <= grid) hipLaunchKernelGGL((k_select_rescore<1024, false>), dim3(grid, a.frames), dim3(1024), 0, s, a);
+#ifndef ESAC_SELECT_B
+#define ESAC_SELECT_B 1024  // threads of the single-frame variant (A/B: scripts/dev/variants.sh)
+#endif
+    if (split == 1 && a.N <= grid) hipLaunchKernelGGL((k_select_rescore<ESAC_SELECT_B, false>), dim3(grid, a.frames), dim3(ESAC_SELECT_B), 0, s, a);
     else                           hipLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, a);
 }
 void launch_rescore_all(const KArgs& a, hipStream_t s) {

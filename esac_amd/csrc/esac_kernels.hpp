@@ -19,6 +19,7 @@ constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
 constexpr int ESAC_FLAG_EXACT_SAMPLING_K = 16, ESAC_FLAG_SCORES_BY_INDEX_K = 32;  // = ESAC_FLAG_* (checked in esac_capi.hip)
 constexpr int ESAC_SELECT_SPLIT = 16;          // cell ranges (workgroups) per contender in k_select_rescore when H*W >= 32768
+constexpr int ESAC_CAND_DOUBLES = 26;          // record parked with an accepted entry of the "maybe" list: 6 + 9 + 6 + 4 doubles (+1 pad)
 constexpr int ESAC_SAMPLE_LIST_PER_HYP = 16;   // capacity of the prescreen's global "maybe" list, per hypothesis in flight
 constexpr int ESAC_TILED_HC = 256;            // hypotheses per chunk of the tile-stationary score kernel
 constexpr int ESAC_TILED_MAX_EXPERTS = 4096;  // experts its bucketing kernel counts in LDS
@@ -72,6 +73,8 @@ struct KArgs {
     const int32_t* hyp_index;  // optional [N] global hypothesis indices
     // workspaces (device)
     double* hyps;         // [N,6]
+    double* hyps_R;       // [N,9] R(rvec) as the sampler formed it (rodrigues_vec2mat of the stored rvec): what the exact
+                          // re-score multiplies with -- recomputing it costs every re-scoring workgroup ~2.5 us of sin / cos latency
     float* rt32;          // [N,12] float(R(rvec)), float(t)
     int* sample_xy;       // [N,8]
     int* tries;           // [N]
@@ -79,7 +82,7 @@ struct KArgs {
     int* samp_resume;     // [N] k_sample_prescreen: first try it did NOT screen (k_sample_screened<true> resumes there)
     int* samp_round;      // [N] next 64-try round of a pending hypothesis: handed out IN ORDER to whichever wavefront asks (k_sample_prescreen)
     unsigned long long* best_try;  // [N] k_sample_decide: (lowest accepted try << 32 | list position) among the listed ones, ~0: none
-    double* samp_cand;    // [samp_cap,16] solved hypothesis of an accepted list entry: rvec,tvec | 12 floats rt32 | 8 ints cells
+    double* samp_cand;    // [samp_cap,ESAC_CAND_DOUBLES] solved hypothesis of an accepted list entry: rvec,tvec | R | 12 floats rt32 | 8 ints cells
     int* samp_entries;    // [samp_cap] (frame * N + hypothesis, try) pairs: the tries the screen could not rule out
     int* samp_count;      // [2] entries appended to samp_entries (may exceed samp_cap: clamp); hypotheses appended to samp_pending
     int* samp_pending;    // [N] (frame * N + hypothesis) of every hypothesis the first passes left SAMPLE_PENDING

@@ -553,6 +553,28 @@ __global__ __launch_bounds__(64) void k_sample_decide(KArgs a0) {
     if (accepted) atomicMin(a0.best_try + hg, ((unsigned long long)(unsigned)t << 32) | (unsigned)i);
 }
 
+// Commit pre-pass for calls with thousands of pending hypotheses: one LANE per hypothesis copies the record of its
+// accepted try (see the COMMIT block of k_sample_screened<true>, which does the same with a whole wavefront per
+// hypothesis -- fine for a frame's few stragglers, 33 us of dependent loads at 15,000); what it settles, the resume
+// kernel finds settled.
+__global__ __launch_bounds__(256) void k_sample_commit(KArgs a) {
+    frame_view(a);
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= a.N || a.tries[h] != SAMPLE_PENDING) return;
+    const unsigned long long found = a.best_try[h];
+    if (found == ~0ull || (int)(found >> 32) >= a.samp_resume[h]) return;  // not settled: k_sample_screened<true> decides
+    const double* cd = a.samp_cand + (size_t)(unsigned)found * ESAC_CAND_DOUBLES;
+#pragma unroll
+    for (int k = 0; k < 6; k++) a.hyps[(size_t)h * 6 + k] = cd[k];
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.hyps_R[(size_t)h * 9 + k] = cd[6 + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) reinterpret_cast<double*>(a.rt32 + (size_t)h * 12)[k] = cd[15 + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) reinterpret_cast<double*>(a.sample_xy + (size_t)h * 8)[k] = cd[21 + k];
+    a.tries[h] = (int)(found >> 32);
+}
+
 // RESUME: the end of the screened chain -- commit the accepted try of a pending hypothesis, or continue where
 // k_sample_prescreen stopped.
 template <bool RESUME>
@@ -1182,6 +1204,7 @@ static void launch_sample_stragglers(const KArgs& b, int waves, hipStream_t s) {
     const int gz = (waves + gx * b.frames - 1) / (gx * b.frames);
     hipLaunchKernelGGL(k_sample_prescreen, dim3(gx, b.frames, gz < 1 ? 1 : gz), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sample_decide, dim3((b.samp_cap + 63) / 64), dim3(64), 0, s, b);
+    if ((long long)b.N * b.frames > 2048) hipLaunchKernelGGL(k_sample_commit, dim3((b.N + 255) / 256, b.frames), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_sample_screened<true>, dim3(b.N, b.frames), dim3(64), 0, s, b);
 }
 

@@ -355,6 +355,9 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
 // wide: a lone maybe would otherwise cost the whole wavefront a full fp64 solve.  The queue is flushed when it holds
 // SCREEN_FLUSH tries, when the screen itself sees a 4th point within tau (almost certainly the accepted try), and at
 // the end of the budget.
+#ifndef ESAC_CHAIN_WAVES
+#define ESAC_CHAIN_WAVES 8192  // wavefronts of the screened search that work whatever the number of pending hypotheses is
+#endif
 constexpr float SCREEN_MARGIN = 3.0f;  // pixels; the largest screen error of an fp64-accepted try in calibration: tau + 0.008
 constexpr int SCREEN_FLUSH = 8;
 constexpr int SCREEN_QUEUE = 128;  // >= SCREEN_FLUSH - 1 + 64
@@ -389,6 +392,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int count = min(a.samp_count[1], a.N * a.frames);
     if (count == 0) return;
     const long long L = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    // ... but not more than eight per pending hypothesis once the chip is full (ESAC_CHAIN_WAVES): the launch is sized for
+    // "every hypothesis pending"; when a batch of frames leaves a few thousand EASY stragglers (true-expert hypotheses that
+    // missed their first 32 tries and need a dozen more), 28 wavefronts each would screen 1800 tries where one round
+    // settles it (200 us of a 256-frame batch; 8 per hypothesis: round 2's figure)
+    // With a single expert every pending hypothesis is such an easy one: one wavefront each.
+    if (L >= ESAC_CHAIN_WAVES && L >= (a.E == 1 ? 1LL : 8LL) * count) return;
     const int entry = a.samp_pending[(int)(L % count)];
     const int fr = entry / a.N, h = entry - fr * a.N, lane = threadIdx.x;
     frame_view(a, fr);
@@ -1235,13 +1244,10 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     // resident at two per SIMD -- with some slack for the tail; when (nearly) every hypothesis is pending, as in the
     // 50-expert workloads, eight per hypothesis measured best (A/B on one box, config 5a: 4 / 8 / 32 per hypothesis ->
     // 2.00 / 1.95 / 2.18 ms)
-#ifndef ESAC_CHAIN_WAVES
-#define ESAC_CHAIN_WAVES 8192
-#endif
 #ifndef ESAC_CHAIN_PER_HYP
 #define ESAC_CHAIN_PER_HYP 8
 #endif
-    const long long w8 = (long long)ESAC_CHAIN_PER_HYP * total;
+    const long long w8 = (a.E == 1 ? 1LL : (long long)ESAC_CHAIN_PER_HYP) * total;
     const int waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > 131072 ? 131072 : w8));
     if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
         if (handover) b.handover = ESAC_HANDOVER;

@@ -392,12 +392,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int count = min(a.samp_count[1], a.N * a.frames);
     if (count == 0) return;
     const long long L = ((long long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    // ... but not more than eight per pending hypothesis once the chip is full (ESAC_CHAIN_WAVES): the launch is sized for
-    // "every hypothesis pending"; when a batch of frames leaves a few thousand EASY stragglers (true-expert hypotheses that
-    // missed their first 32 tries and need a dozen more), 28 wavefronts each would screen 1800 tries where one round
-    // settles it (200 us of a 256-frame batch; 8 per hypothesis: round 2's figure)
-    // With a single expert every pending hypothesis is such an easy one: one wavefront each.
-    if (L >= ESAC_CHAIN_WAVES && L >= (a.E == 1 ? 1LL : 8LL) * count) return;
+    // ... with one exception: a single expert.  Every pending hypothesis is then an EASY one (a true-expert hypothesis that
+    // missed its first 32 tries and needs a dozen more): one wavefront each settles it in a round, and the 28 each that a
+    // launch sized for "every hypothesis pending" would put on the few thousand stragglers of a 256-frame batch are 28
+    // start-up chains of dependent loads for nothing.  (Wrong-expert stragglers want every helper they can get: capping
+    // them at eight per hypothesis cost config 4 18 us.)
+    if (a.E == 1 && L >= ESAC_CHAIN_WAVES && L >= count) return;
     const int entry = a.samp_pending[(int)(L % count)];
     const int fr = entry / a.N, h = entry - fr * a.N, lane = threadIdx.x;
     frame_view(a, fr);
@@ -1213,7 +1213,7 @@ static void launch_sample_stragglers(const KArgs& b, int waves, hipStream_t s) {
     const int gz = (waves + gx * b.frames - 1) / (gx * b.frames);
     hipLaunchKernelGGL(k_sample_prescreen, dim3(gx, b.frames, gz < 1 ? 1 : gz), dim3(64), 0, s, b);
     hipLaunchKernelGGL(k_sample_decide, dim3((b.samp_cap + 63) / 64), dim3(64), 0, s, b);
-    if ((long long)b.N * b.frames > 2048) hipLaunchKernelGGL(k_sample_commit, dim3((b.N + 255) / 256, b.frames), dim3(256), 0, s, b);
+    if ((long long)b.N * b.frames >= 8192) hipLaunchKernelGGL(k_sample_commit, dim3((b.N + 255) / 256, b.frames), dim3(256), 0, s, b);
     hipLaunchKernelGGL(k_sample_screened<true>, dim3(b.N, b.frames), dim3(64), 0, s, b);
 }
 

@@ -184,7 +184,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.best_try, (size_t)nN);
     rc |= alloc(&c->ws.samp_cand, (size_t)nN * ESAC_SAMPLE_LIST_PER_HYP * ESAC_CAND_DOUBLES);
     rc |= alloc(&c->ws.samp_entries, (size_t)nN * 2 * ESAC_SAMPLE_LIST_PER_HYP);  // (hypothesis, try) pairs
-    rc |= alloc(&c->ws.samp_count, (size_t)4);
+    rc |= alloc(&c->ws.samp_count, (size_t)4 + 2 * 1024);  // list counters + 1024 x 2 per-expert counters (esac_kernels.hip: expert_stats)
     rc |= alloc(&c->ws.samp_pending, (size_t)nN);
     rc |= alloc(&c->ws.fast_scores, (size_t)nN);
     rc |= alloc(&c->ws.scores, (size_t)nN);

@@ -142,10 +142,21 @@ __device__ __forceinline__ size_t user_slot(const KArgs& a, int h) {
     return (a.flags & ESAC_FLAG_SCORES_BY_INDEX_K) ? (size_t)global_hyp(a, h) : (size_t)h;
 }
 
+// How hard is an expert's map for the sampler?  Two counters per expert (bin e % 1024, behind the four list counters of
+// samp_count; a single frame, several experts, a few thousand hypotheses -- the shape in which most pending hypotheses are
+// easy ones): hypotheses assigned / hypotheses the first tries left pending.  An expert on whose map (nearly) every
+// hypothesis is still pending needs ~10^3 tries per hypothesis (wrong expert); one that settled most of its hypotheses
+// needs a dozen more for the few that missed.  k_sample_prescreen hands out its helper wavefronts by that -- scheduling
+// only: which wavefront screens which 64-try round never changes what is accepted.
+constexpr int ESAC_STAT_BINS = 1024;
+constexpr int ESAC_CLASSES_MAX_N = 8192;
+__host__ __device__ __forceinline__ bool expert_stats_on(const KArgs& a) { return a.E > 1 && a.frames == 1 && a.N <= ESAC_CLASSES_MAX_N; }
+__device__ __forceinline__ int* expert_stats(const KArgs& a, int e) { return a.samp_count + 4 + 2 * (e & (ESAC_STAT_BINS - 1)); }
+
 constexpr int SAMPLE_PENDING = -2;  // tries[h] between the two phases of the throughput-shaped sampling
 // hypothesis h of this frame goes on to the screened chain (k_sample_prescreen works from the list).  Called by the
 // lanes of a wavefront that have one (`mine`; all lanes must call): one atomic per wavefront reserves the list slots.
-__device__ __forceinline__ void mark_pending(const KArgs& a, int h, bool mine) {
+__device__ __forceinline__ void mark_pending(const KArgs& a, int h, int e, bool mine) {
     const unsigned long long m = __ballot(mine);
     if (!m) return;
     const int lane = threadIdx.x & 63, leader = __ffsll((long long)m) - 1;
@@ -158,26 +169,32 @@ __device__ __forceinline__ void mark_pending(const KArgs& a, int h, bool mine) {
     a.samp_resume[h] = 0x7fffffff;  // k_sample_prescreen: first try not screened yet
     a.samp_round[h] = 0;
     a.samp_pending[base + __popcll(m & ((1ull << lane) - 1ull))] = (int)blockIdx.y * a.N + h;
+    if (expert_stats_on(a)) atomicAdd(expert_stats(a, e) + 1, 1);
 }
-constexpr int FIRST_PHASE_TRIES = 16;
-#ifndef ESAC_FIRST_PHASE_PASSES
-#define ESAC_FIRST_PHASE_PASSES 2
+constexpr int FIRST_PHASE_TRIES = 32;  // tries per hypothesis before the screened chain takes over
+#ifndef ESAC_FIRST_WIDE_MAX
+#define ESAC_FIRST_WIDE_MAX 8192  // up to this many hypotheses: one pass, 32 lanes per hypothesis (else two passes of 16)
 #endif
-constexpr int FIRST_PHASE_PASSES = ESAC_FIRST_PHASE_PASSES;
 
-// Throughput shape, first phases: a hypothesis on a usable map is accepted within its first few tries, so a whole
-// wavefront per hypothesis solves ~60 P3P problems nobody needs.  Here a wavefront serves FOUR hypotheses, 16 tries
-// each: tries [first_try, first_try + 16).  What is not accepted stays pending for the next pass (launched with
-// first_try + 16) and finally for k_sample, one wavefront per hypothesis.
+// Throughput shape, first phase: a hypothesis on a usable map is accepted within its first few tries, so a whole
+// wavefront per hypothesis solves ~60 P3P problems nobody needs.  Here a wavefront serves SEVERAL hypotheses, TRIES tries
+// each: tries [first_try, first_try + TRIES).  What is not accepted stays pending for the next pass and finally for the
+// screened chain (k_pending_list -> k_sample_prescreen ...).
+// TRIES = 16: a wavefront serves four hypotheses, 16 tries each per pass (thousands of hypotheses: two passes, the second
+// one only for wavefronts with a hypothesis still open); TRIES = 32: two hypotheses, 32 tries in one pass -- with a few
+// thousand hypotheses (config 4: 4096) the 16-try shape is 1024 wavefronts, half of what the chip holds, twice in a row
+// (47 us; one pass of 32: 30 us).
+template <int TRIES>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sample_first(KArgs a) {
+    constexpr int HPW = 64 / TRIES;  // hypotheses per wavefront
     frame_view(a);
-    const int lane = threadIdx.x, grp = lane >> 4, t = a.first_try + (lane & 15);
-    const int h = blockIdx.x * 4 + grp;
+    const int lane = threadIdx.x, grp = lane / TRIES, t = a.first_try + (lane & (TRIES - 1));
+    const int h = blockIdx.x * HPW + grp;
     const int hc = h < a.N ? h : a.N - 1;
     const bool mine_pending = h < a.N && (a.first_try == 0 || a.tries[hc] == SAMPLE_PENDING);
-    if (!__any(mine_pending)) return;  // all four hypotheses of this wavefront are done
+    if (!__any(mine_pending)) return;  // all hypotheses of this wavefront are done
     const bool active = mine_pending && t < a.max_tries;
-    if (a.first_try == 0 && h < a.N && (lane & 15) == 0) flag_bad_assignment(a, h);
+    if (a.first_try == 0 && h < a.N && (lane & (TRIES - 1)) == 0) flag_bad_assignment(a, h);
     const int e = expert_of(a, hc);
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
@@ -197,14 +214,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             accepted = accept_sample(Rp, Tp, Pf, mu, mv, cam, (double)a.tau, rvec, T, R);
     }
     const unsigned long long m = __ballot(accepted);
-    const unsigned mine = (unsigned)(m >> (16 * grp)) & 0xffffu;
+    const unsigned mine = (unsigned)(m >> (TRIES * grp)) & (TRIES == 32 ? 0xffffffffu : 0xffffu);
     if (mine_pending) {
         if (mine) {
             const int first = __ffs((int)mine) - 1;
-            if ((lane & 15) == first) store_hypothesis(a, h, map, rvec, T, R, cx, cy, a.first_try + first);
-        } else if (a.max_tries <= a.first_try + FIRST_PHASE_TRIES) {
+            if ((lane & (TRIES - 1)) == first) store_hypothesis(a, h, map, rvec, T, R, cx, cy, a.first_try + first);
+        } else if (a.max_tries <= a.first_try + TRIES) {
             if (t == a.max_tries - 1) store_hypothesis(a, h, map, rvec, T, R, cx, cy, -1);  // budget exhausted: last state remains
-        } else if ((lane & 15) == 0) {
+        } else if ((lane & (TRIES - 1)) == 0) {
             a.tries[h] = SAMPLE_PENDING;  // k_pending_list gathers what the last pass leaves pending
         }
     }
@@ -216,12 +233,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 __global__ __launch_bounds__(1024) void k_pending_list(KArgs a) {
     __shared__ int s_wave[16];
     __shared__ int s_base;
+    __shared__ int s_stat[2 * ESAC_STAT_BINS];
     frame_view(a);
     const int h = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool mine = h < a.N && a.tries[h] == SAMPLE_PENDING;
     const unsigned long long m = __ballot(mine);
     if (lane == 0) s_wave[wave] = __popcll(m);
+    const bool stats = expert_stats_on(a);  // assigned / pending per expert (see expert_stats)
+    if (stats) {
+        s_stat[threadIdx.x] = 0;
+        s_stat[threadIdx.x + 1024] = 0;
+        __syncthreads();
+        if (h < a.N) {
+            const int bin = expert_of(a, h) & (ESAC_STAT_BINS - 1);
+            atomicAdd(s_stat + 2 * bin, 1);
+            if (mine) atomicAdd(s_stat + 2 * bin + 1, 1);
+        }
+    }
     __syncthreads();
+    if (stats) {
+        const int v0 = s_stat[threadIdx.x], v1 = s_stat[threadIdx.x + 1024];
+        if (v0) atomicAdd(a.samp_count + 4 + threadIdx.x, v0);
+        if (v1) atomicAdd(a.samp_count + 4 + threadIdx.x + 1024, v1);
+    }
     if (threadIdx.x == 0) {
         int tot = 0;
         for (int w = 0; w < 16; w++) {
@@ -262,6 +296,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
     const double tau = (double)a.tau;
     if (a.first_try > 0 && a.tries[h] != SAMPLE_PENDING) return;  // phase 2 of the throughput shape: done in phase 1
     if (a.first_try == 0 && threadIdx.x == 0) flag_bad_assignment(a, h);
+    if (a.handover != 0x7fffffff && threadIdx.x == 0 && expert_stats_on(a)) atomicAdd(expert_stats(a, e), 1);  // (see expert_stats)
 
     int parity = 0;
     for (int base = a.first_try, TRIES = 0; base < a.max_tries; base += TRIES, parity ^= 1) {
@@ -336,7 +371,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             return;
         }
         if (base + TRIES >= a.handover) {  // a straggler (wrong expert): the spread, screened search takes over from here
-            if (threadIdx.x < 64) mark_pending(a, h, threadIdx.x == 0);
+            if (threadIdx.x < 64) mark_pending(a, h, e, threadIdx.x == 0);
             return;
         }
     }
@@ -358,6 +393,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
 #ifndef ESAC_CHAIN_WAVES
 #define ESAC_CHAIN_WAVES 8192  // wavefronts of the screened search that work whatever the number of pending hypotheses is
 #endif
+constexpr int ESAC_RESIDENT_WAVES = 2048;  // k_sample_prescreen: 256 CUs x 4 SIMDs x 2
 constexpr float SCREEN_MARGIN = 3.0f;  // pixels; the largest screen error of an fp64-accepted try in calibration: tau + 0.008
 constexpr int SCREEN_FLUSH = 8;
 constexpr int SCREEN_QUEUE = 128;  // >= SCREEN_FLUSH - 1 + 64
@@ -398,10 +434,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // start-up chains of dependent loads for nothing.  (Wrong-expert stragglers want every helper they can get: capping
     // them at eight per hypothesis cost config 4 18 us.)
     if (a.E == 1 && L >= ESAC_CHAIN_WAVES && L >= count) return;
+    const int lane = threadIdx.x;
     const int entry = a.samp_pending[(int)(L % count)];
-    const int fr = entry / a.N, h = entry - fr * a.N, lane = threadIdx.x;
+    const int fr = entry / a.N, h = entry - fr * a.N;
     frame_view(a, fr);
     const int e = expert_of(a, h);
+#ifndef ESAC_NO_HELPER_CLASSES
+    // Few hypotheses pending (several helpers of a hypothesis are resident AT ONCE and walk its rounds in lockstep): an EASY
+    // hypothesis -- its expert settled most of its hypotheses in the first tries -- is accepted in its first round, and
+    // every further helper is a wasted round (and a dozen "maybe" tries for k_sample_decide) that a wrong-expert straggler
+    // (dozens of rounds) is waiting for.  Two helpers for those; the others take every wavefront they can get.
+    // (Config 4, ~500 pending of which ~110 on wrong experts: 81 -> 70 us, 62 with the fresh stop flag below; config 3,
+    // where up to half of the ~60 pending are easy: 40.5 -> 28.7 us with both, k_sample_decide 19.3 -> 12.6 us.)
+    // Measured and dropped (round 3): wavefronts that look for another open hypothesis instead of leaving (213 us: a
+    // search is three dependent gathers and costs more than a round), a list of the hard ones built by an extra kernel
+    // with the spare wavefronts leaving after one scalar load (60 + 5 us), late helpers redirected to an open neighbour
+    // (62 us) -- the kernel's length is neither the supply of helpers nor the wavefronts that find nothing to do.
+    if (expert_stats_on(a) && L >= 2LL * count) {
+        const int* st = expert_stats(a, e);
+        if (2 * st[1] < st[0]) return;
+    }
+#endif
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
     const Philox rng(a.seed, a.call);
@@ -409,6 +462,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const float thr = a.tau + SCREEN_MARGIN;
     int* resume = a.samp_resume + h;
+#ifndef ESAC_STALE_STOP
+    // the stop flag one round old is fine while a hypothesis has one helper at a time (thousands pending); with the chip's
+    // 2048 resident wavefronts on a few dozen hypotheses it is a whole superfluous round of every one of them
+    const bool fresh = count <= ESAC_RESIDENT_WAVES;
+#else
+    const bool fresh = false;
+#endif
     // Two round trips to L2 per 64-try round used to sit on this loop's critical path (~1.5 us each against ~6 us of
     // arithmetic, at two wavefronts per SIMD): the ticket for the round (atomicAdd with return) and, whenever a lane said
     // "maybe" (a third of the rounds), the slot in the global list.  The ticket for the NEXT round is now drawn while the
@@ -436,11 +496,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int r_next = 0;
     if (lane == 0) r_next = atomicAdd(a.samp_round + h, 1);
     int stop_at = __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
+    for (bool again = false;; again = true) {
         const int r = __shfl(r_next, 0);  // (waits for the ticket drawn one round ago)
         const long long base = a.first_try + 64LL * r;
         if (base >= a.max_tries) break;
-        if (base >= stop_at) break;  // (read one round ago as well: a stale value costs at most one superfluous round)
+        if (fresh && again) stop_at = __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (base >= stop_at) break;  // (otherwise read one round ago as well: a stale value costs at most one superfluous round)
         if (lane == 0) r_next = atomicAdd(a.samp_round + h, 1);
         stop_at = __hip_atomic_load(resume, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int t = (int)base + lane;
@@ -1220,12 +1281,13 @@ static void launch_sample_stragglers(const KArgs& b, int waves, hipStream_t s) {
 void launch_sample(const KArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.frames;
     if (a.sc4) hipLaunchKernelGGL(k_pack_cells, dim3(2048), dim3(256), 0, s, a);
-    (void)hipMemsetAsync(a.samp_count, 0, 2 * sizeof(int), s);  // entries of the "maybe" list, hypotheses of the pending list
+    // entries of the "maybe" list, hypotheses of the pending list (+ the per-expert counters behind them, see expert_stats)
+    (void)hipMemsetAsync(a.samp_count, 0, (expert_stats_on(a) ? 4 + 2 * ESAC_STAT_BINS : 4) * sizeof(int), s);
     KArgs b = a;
     b.handover = 0x7fffffff;
     // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on four lanes at first)
     // settles a hypothesis of the right expert within its first round; with several experts the stragglers are handed to
-    // the spread, screened search after `handover` tries, ESAC_WPH_K / total (at most 64) wavefronts each, rounds handed out in order.  Beyond ~10^3
+    // the spread, screened search after `handover` tries (every wavefront of that launch works, rounds handed out in order).  Beyond ~10^3
     // hypotheses (several experts) a workgroup per hypothesis no longer fits the chip in one wave of workgroups: the
     // first 32 tries run four hypotheses per wavefront and the screened chain finishes the rest.
     // ESAC_FLAG_EXACT_SAMPLING: no screen anywhere -- every try is solved and decided by the fp64 route (k_sample walks a
@@ -1237,7 +1299,7 @@ void launch_sample(const KArgs& a, hipStream_t s) {
 #define ESAC_LATENCY_MAX 1024
 #endif
 #ifndef ESAC_HANDOVER
-#define ESAC_HANDOVER 64
+#define ESAC_HANDOVER 32  // (64: k_sample<128> 41 us + screened search 29 us at config 3; 32: 30 + 31 us)
 #endif
     // wavefronts of the screened chain: every one of them works whatever the number of pending hypotheses is (they take the
     // 64-try rounds of the hypotheses on the list in order), so the launch is sized for the chip -- 2048 wavefronts are
@@ -1260,9 +1322,14 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     } else if (total <= 4096 && !handover) {
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
-        for (int pass = 0; pass < FIRST_PHASE_PASSES && b.first_try < a.max_tries; pass++) {
-            hipLaunchKernelGGL(k_sample_first, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
-            b.first_try += FIRST_PHASE_TRIES;
+        if (total <= ESAC_FIRST_WIDE_MAX) {
+            hipLaunchKernelGGL(k_sample_first<32>, dim3((a.N + 1) / 2, a.frames), dim3(64), 0, s, b);
+            b.first_try += 32;
+        } else {
+            for (int pass = 0; pass < FIRST_PHASE_TRIES / 16 && b.first_try < a.max_tries; pass++) {
+                hipLaunchKernelGGL(k_sample_first<16>, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
+                b.first_try += 16;
+            }
         }
         if (b.first_try < a.max_tries) {
             if (exact) {

@@ -84,7 +84,7 @@ struct KArgs {
     unsigned long long* best_try;  // [N] k_sample_decide: (lowest accepted try << 32 | list position) among the listed ones, ~0: none
     double* samp_cand;    // [samp_cap,ESAC_CAND_DOUBLES] solved hypothesis of an accepted list entry: rvec,tvec | R | 12 floats rt32 | 8 ints cells
     int* samp_entries;    // [samp_cap] (frame * N + hypothesis, try) pairs: the tries the screen could not rule out
-    int* samp_count;      // [2] entries appended to samp_entries (may exceed samp_cap: clamp); hypotheses appended to samp_pending
+    int* samp_count;      // [4 + 2048] entries appended to samp_entries (may exceed samp_cap: clamp); hypotheses appended to samp_pending
     int* samp_pending;    // [N] (frame * N + hypothesis) of every hypothesis the first passes left SAMPLE_PENDING
     int samp_cap;
     float* fast_scores;   // [N]

@@ -138,3 +138,15 @@ def test_config5b_true_50_experts_16384_hypotheses_full_resolution(engine, oracl
     assert ref["expert"] == 11 and ref["tries"].max() > 64
     assert ref["ref_steps"] >= 1 and ref["inlier_counts"][0] > 100000  # 38 cooperating workgroups refine 307,200 cells
     engine.check()  # neither an out-of-range assignment nor a barrier time-out
+
+
+def test_more_stragglers_than_resident_wavefronts(engine, oracle):
+    """3000 hypotheses, nearly all on WRONG experts (each needs ~10^3 tries): more pending hypotheses than the 2304
+    wavefronts of the migrating screened search (esac_kernels.hip: k_sample_prescreen<true>) -- every list entry must be
+    started by the wavefront that owns it or by one that found it, none may be left to the commit kernel unscreened."""
+    f = S.make_frame(240, E=4, true_expert=1)
+    ha = np.array([0, 2, 3], np.int64)[np.arange(3000) % 3]
+    ha[::50] = 1
+    res, ref = _run_both(engine, oracle, f, ha, call=7)
+    _check_full(engine, res, ref)
+    assert (ref["tries"] > 32).sum() > 2500 and ref["expert"] == 1

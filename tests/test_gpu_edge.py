@@ -265,3 +265,18 @@ def test_large_batch_equals_sequential_calls(engine):
         np.testing.assert_array_equal(res_b[b][:api.RES_PROB], res_1[:api.RES_PROB])
         assert res_b[b][api.RES_LM_ITERS] == res_1[api.RES_LM_ITERS]
         np.testing.assert_allclose(res_b[b][api.RES_PROB:api.RES_ENTROPY + 1], res_1[api.RES_PROB:api.RES_ENTROPY + 1], rtol=1e-5)
+
+
+def test_more_experts_than_helper_class_bins(engine, oracle):
+    """1500 experts (the per-expert counters that hand out the helpers of the screened search live in 1024 bins,
+    esac_kernels.hip: expert_stats -- experts e and e + 1024 share one): scheduling only, every stage must still equal the
+    oracle.  2048 hypotheses spread over all experts, a third of them on the true one; small try budget (a 12x16 grid of a
+    wrong expert offers few consistent 4-point samples: the budget is what ends most of those searches)."""
+    E = 1500
+    f = S.make_frame(250, E=E, true_expert=1100, H=12, W=16, sub=40)
+    rng = np.random.default_rng(5)
+    ha = rng.integers(0, E, size=2048).astype(np.int64)
+    ha[::3] = 1100
+    res, ref = _both(engine, oracle, f["coords"], ha, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=40, seed=1305, call=3, max_tries=700)
+    _same(engine, res, ref)
+    assert ref["expert"] == 1100 and (ref["tries"] < 0).sum() > 100  # budgets spent on wrong experts' maps

@@ -236,7 +236,12 @@ __global__ __launch_bounds__(1024) void k_pending_list(KArgs a) {
     __shared__ int s_stat[2 * ESAC_STAT_BINS];
     frame_view(a);
     const int h = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool mine = h < a.N && a.tries[h] == SAMPLE_PENDING;
+    // first_try == 0: no first phase has run (launch_sample: many hypotheses on several experts) -- everything is pending
+    const bool mine = h < a.N && (a.first_try == 0 || a.tries[h] == SAMPLE_PENDING);
+    if (a.first_try == 0 && h < a.N) {
+        flag_bad_assignment(a, h);
+        a.tries[h] = SAMPLE_PENDING;
+    }
     const unsigned long long m = __ballot(mine);
     if (lane == 0) s_wave[wave] = __popcll(m);
     const bool stats = expert_stats_on(a);  // assigned / pending per expert (see expert_stats)
@@ -652,8 +657,9 @@ __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
     __shared__ int s_queue[SCREEN_QUEUE];
     frame_view(a);
     const int h = blockIdx.x, lane = threadIdx.x;
-    if (a.first_try > 0 && a.tries[h] != SAMPLE_PENDING) return;
-    if (a.first_try == 0 && lane == 0) flag_bad_assignment(a, h);
+    // (RESUME: the list builders marked what is pending -- also when the chain started at try 0)
+    if ((RESUME || a.first_try > 0) && a.tries[h] != SAMPLE_PENDING) return;
+    if (!RESUME && a.first_try == 0 && lane == 0) flag_bad_assignment(a, h);
     const int e = expert_of(a, h);
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
@@ -1281,8 +1287,15 @@ static void launch_sample_stragglers(const KArgs& b, int waves, hipStream_t s) {
 void launch_sample(const KArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.frames;
     if (a.sc4) hipLaunchKernelGGL(k_pack_cells, dim3(2048), dim3(256), 0, s, a);
-    // entries of the "maybe" list, hypotheses of the pending list (+ the per-expert counters behind them, see expert_stats)
-    (void)hipMemsetAsync(a.samp_count, 0, (expert_stats_on(a) ? 4 + 2 * ESAC_STAT_BINS : 4) * sizeof(int), s);
+    // entries of the "maybe" list, hypotheses of the pending list (+ the per-expert counters behind them, see expert_stats):
+    // zeroed in front of the launches that append to them -- not on the single-expert latency path, where the fill and
+    // its kernel boundary sat in front of a 22 us sampler for nothing (headline call 0.2058 -> 0.2010 ms)
+    auto reset_lists = [&]() {
+        (void)hipMemsetAsync(a.samp_count, 0, (expert_stats_on(a) ? 4 + 2 * ESAC_STAT_BINS : 4) * sizeof(int), s);
+    };
+#ifdef ESAC_ALWAYS_RESET
+    reset_lists();
+#endif
     KArgs b = a;
     b.handover = 0x7fffffff;
     // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on four lanes at first)
@@ -1312,6 +1325,9 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     const long long w8 = (a.E == 1 ? 1LL : (long long)ESAC_CHAIN_PER_HYP) * total;
     const int waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > 131072 ? 131072 : w8));
     if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
+#ifndef ESAC_ALWAYS_RESET
+        if (handover) reset_lists();
+#endif
         if (handover) b.handover = ESAC_HANDOVER;
         // up to 256 hypotheses: four wavefronts each (64 tries per round, one workgroup per CU at this kernel's ~440
         // registers).  Beyond that the workgroups queue up behind each other (1024 hypotheses: four ~12 us rounds back to
@@ -1322,9 +1338,18 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     } else if (total <= 4096 && !handover) {
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
+#ifndef ESAC_ALWAYS_RESET
+        if (!exact) reset_lists();
+#endif
         if (total <= ESAC_FIRST_WIDE_MAX) {
             hipLaunchKernelGGL(k_sample_first<32>, dim3((a.N + 1) / 2, a.frames), dim3(64), 0, s, b);
             b.first_try += 32;
+#ifndef ESAC_KEEP_FIRST_PHASE
+        } else if (a.E > 1 && !exact) {
+            // tens of thousands of hypotheses over many experts (config 5: 16384 over 50, Dirichlet gating): nearly all of them
+            // sit on wrong experts, where 32 tries in full fp64 are 32 solves for nothing -- the screened chain takes them
+            // from try 0 (a hypothesis of the right expert costs it one screened round and a handful of fp64 decisions)
+#endif
         } else {
             for (int pass = 0; pass < FIRST_PHASE_TRIES / 16 && b.first_try < a.max_tries; pass++) {
                 hipLaunchKernelGGL(k_sample_first<16>, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);

@@ -74,6 +74,30 @@ def test_batched_forward_against_the_oracle(engine, oracle):
         assert r <= 1e-4 and t <= 1e-3, (b, r, t)
 
 
+def test_batched_multi_expert_frames_beyond_the_first_pass_limit(engine, oracle):
+    """24 frames x 400 hypotheses on 3 experts = 9600 hypotheses in one launch set: beyond 8192 the screened chain starts
+    at try 0 (no first pass: esac_kernels.hip, launch_sample) and runs per frame (pending list entries carry the frame,
+    RNG key call + b) -- every frame against the oracle: winner, expert, exact winner score, refinement trace, the whole
+    score vector within the fp32 stream's band (a hypothesis sampled at another try would score differently)."""
+    B, N = 24, 400
+    frames = [S.make_frame(430 + b, E=3, true_expert=(2 * b) % 3) for b in range(B)]
+    assigns = np.stack([S.gating_assignment(f, N, mode="gating") for f in frames])
+    assigns[:, ::9] = (assigns[:, ::9] + 1) % 3  # a good share of wrong-expert stragglers in every frame
+    coords = torch.from_numpy(np.stack([f["coords"] for f in frames])).cuda()
+    p = engine.make_params(3, 60, 80, N, seed=33, call=700)
+    scores = torch.empty(B, N, dtype=torch.float64, device="cuda")
+    res = engine.forward_batch(coords, torch.from_numpy(assigns).cuda(), p, scores_out=scores)
+    sc_host = scores.cpu().numpy()
+    for b in range(B):
+        ref = oracle.forward(frames[b]["coords"], assigns[b], seed=33, call=700 + b)
+        assert int(res[b][api.RES_HYP]) == ref["winner"] and int(res[b][api.RES_EXPERT]) == ref["expert"], b
+        assert int(res[b][api.RES_REF_STEPS]) == ref["ref_steps"] and int(res[b][api.RES_LM_ITERS]) == ref["lm_iters"], b
+        assert abs(res[b][api.RES_SCORE] - ref["scores"][ref["winner"]]) <= 1e-9
+        assert np.sort(np.abs(sc_host[b] - ref["scores"]))[-2] <= 2e-3 and np.abs(sc_host[b] - ref["scores"]).max() <= 5e-2, b
+        r, t = S.pose_errors(res[b][api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
+        assert r <= 1e-4 and t <= 1e-3, (b, r, t)
+
+
 def test_harness_localize_against_the_oracle(oracle):
     """esac_amd/harness.py:localize (the reference's test loop, test_esac.py:145-207) vs the oracle on the very tensors
     it handed to esac.forward, same (seed, call)."""

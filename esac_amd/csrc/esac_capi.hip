@@ -211,6 +211,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     }
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
     HIP_OK(hipMemset(c->ws.coop_counter, 0, 2 * sizeof(unsigned long long)));  // [1] is read by esac_hip_check
+    HIP_OK(hipMemset(c->ws.samp_count, 0, (4 + 2 * 1024) * sizeof(int)));       // the screened chain leaves them at zero (esac_kernels.hip)
     HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
     HIP_OK(hipMemcpy(c->ws.status, &old_status, sizeof(old_status), hipMemcpyHostToDevice));
     if (old_hyps) {

@@ -657,6 +657,13 @@ __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
     __shared__ int s_queue[SCREEN_QUEUE];
     frame_view(a);
     const int h = blockIdx.x, lane = threadIdx.x;
+#ifndef ESAC_ALWAYS_RESET
+    // the last kernel of the screened chain leaves the chain's counters (list lengths, per-expert counters) at zero for the
+    // next call: nothing after k_sample_decide reads them, and a fill in front of every sampling launch is a 3 us
+    // launch and a kernel boundary on a 250 us call (esac_capi.hip zeroes them when the workspace is allocated)
+    if (RESUME && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = lane; i < 4 + 2 * ESAC_STAT_BINS; i += 64) a.samp_count[i] = 0;
+#endif
     // (RESUME: the list builders marked what is pending -- also when the chain started at try 0)
     if ((RESUME || a.first_try > 0) && a.tries[h] != SAMPLE_PENDING) return;
     if (!RESUME && a.first_try == 0 && lane == 0) flag_bad_assignment(a, h);
@@ -1287,14 +1294,11 @@ static void launch_sample_stragglers(const KArgs& b, int waves, hipStream_t s) {
 void launch_sample(const KArgs& a, hipStream_t s) {
     const long long total = (long long)a.N * a.frames;
     if (a.sc4) hipLaunchKernelGGL(k_pack_cells, dim3(2048), dim3(256), 0, s, a);
-    // entries of the "maybe" list, hypotheses of the pending list (+ the per-expert counters behind them, see expert_stats):
-    // zeroed in front of the launches that append to them -- not on the single-expert latency path, where the fill and
-    // its kernel boundary sat in front of a 22 us sampler for nothing (headline call 0.2058 -> 0.2010 ms)
-    auto reset_lists = [&]() {
-        (void)hipMemsetAsync(a.samp_count, 0, (expert_stats_on(a) ? 4 + 2 * ESAC_STAT_BINS : 4) * sizeof(int), s);
-    };
+    // entries of the "maybe" list, hypotheses of the pending list (+ the per-expert counters behind them, see expert_stats)
+    // are zero between calls: the last kernel of the screened chain clears them (k_sample_screened<true>).  A fill in front
+    // of every sampling launch cost the headline call, which never appends to them, 5 us (0.2058 -> 0.2010 ms).
 #ifdef ESAC_ALWAYS_RESET
-    reset_lists();
+    (void)hipMemsetAsync(a.samp_count, 0, (4 + 2 * ESAC_STAT_BINS) * sizeof(int), s);
 #endif
     KArgs b = a;
     b.handover = 0x7fffffff;
@@ -1325,9 +1329,6 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     const long long w8 = (a.E == 1 ? 1LL : (long long)ESAC_CHAIN_PER_HYP) * total;
     const int waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > 131072 ? 131072 : w8));
     if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
-#ifndef ESAC_ALWAYS_RESET
-        if (handover) reset_lists();
-#endif
         if (handover) b.handover = ESAC_HANDOVER;
         // up to 256 hypotheses: four wavefronts each (64 tries per round, one workgroup per CU at this kernel's ~440
         // registers).  Beyond that the workgroups queue up behind each other (1024 hypotheses: four ~12 us rounds back to
@@ -1338,9 +1339,6 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     } else if (total <= 4096 && !handover) {
         hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
-#ifndef ESAC_ALWAYS_RESET
-        if (!exact) reset_lists();
-#endif
         if (total <= ESAC_FIRST_WIDE_MAX) {
             hipLaunchKernelGGL(k_sample_first<32>, dim3((a.N + 1) / 2, a.frames), dim3(64), 0, s, b);
             b.first_try += 32;

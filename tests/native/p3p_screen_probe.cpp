@@ -229,3 +229,47 @@ extern "C" void probe_first_accept(const float* coords, int H, int W, int sub, f
         tries_out[i] = found;
     }
 }
+
+// one sample under the microscope (scripts/dev/screen_adversarial.py: replaying a false reject): both routes' roots and,
+// per root, the fp64 candidate's 4th-point error next to the screen's
+extern "C" void probe_one(const float* pts /*4x3*/, const float* px /*4x2*/, float f, float cx, float cy) {
+    const Cam cam{(double)f, (double)f, (double)cx, (double)cy};
+    float Pf[4][3], muf[4], mvf[4];
+    V3 Pt[4];
+    double mu[4], mv[4];
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 3; k++) Pf[j][k] = pts[3 * j + k];
+        Pt[j] = V3{(double)Pf[j][0], (double)Pf[j][1], (double)Pf[j][2]};
+        muf[j] = px[2 * j]; mvf[j] = px[2 * j + 1];
+        mu[j] = muf[j]; mv[j] = mvf[j];
+    }
+    P3PSetup E;
+    const bool oke = p3p_setup(Pt, mu, mv, cam, E);
+    printf("exact route: setup %d n=%d roots %.17g %.17g %.17g %.17g  a=%g b=%g p=%g q=%g r=%g\n", (int)oke, E.n, E.x[0], E.x[1], E.x[2], E.x[3], E.a, E.b, E.p, E.q, E.r);
+    ScreenScene sc;
+    const bool scok = screen_scene(Pf, sc);
+    const float mu3[3] = {(float)E.mu[0], (float)E.mu[1], (float)E.mu[2]}, mv3[3] = {(float)E.mv[0], (float)E.mv[1], (float)E.mv[2]},
+                mk3[3] = {(float)E.mk[0], (float)E.mk[1], (float)E.mk[2]};
+    for (int i = 0; oke && i < E.n; i++) {
+        double R[9], T[3], rp = -1, X, Y, Z;
+        const bool val = p3p_candidate(E, E.x[i], Pt, mu[3], mv[3], cam, R, T, rp);
+        const bool len = p3p_candidate_lengths(E, E.x[i], X, Y, Z);
+        const float es = (scok && len) ? screen_candidate(sc, mu3, mv3, mk3, (float)X, (float)Y, (float)Z, muf[3], mvf[3], f, cx, cy, ESAC_SCREEN_CONGRUENCE) : -2.f;
+        printf("   root %d x=%.17g  fp64 candidate valid=%d 4th-point err %.6f | lengths %d X=%.9g Y=%.9g Z=%.9g screen err %.6f\n", i, E.x[i], (int)val,
+               val ? sqrt(rp) : -1.0, (int)len, X, Y, Z, es);
+    }
+    ScreenSetup S;
+    const bool oks = screen_setup(Pt, mu, mv, cam, S);
+    printf("fast copy : setup %d n=%d roots %.17g %.17g %.17g %.17g  dx01=%g dx23=%g\n", (int)oks, S.n, S.x[0], S.x[1], S.x[2], S.x[3], (double)S.dx01, (double)S.dx23);
+    for (int i = 0; oks && i < S.n; i++) {
+        double X = 0, Y = 0, Z = 0;
+        const int ok = screen_lengths(S, S.x[i], i < 2 ? S.dx01 : S.dx23, X, Y, Z);
+        const float es = (scok && ok == 1) ? screen_candidate(sc, mu3, mv3, mk3, (float)X, (float)Y, (float)Z, muf[3], mvf[3], f, cx, cy, ESAC_SCREEN_CONGRUENCE) : -2.f;
+        printf("   root %d x=%.17g  lengths %d X=%.9g Y=%.9g Z=%.9g screen err %.6f\n", i, S.x[i], ok, X, Y, Z, es);
+    }
+    printf("screen on the fast copy: %g ; on the exact roots: %g\n", oks ? p3p_screen_roots(S, Pf, muf[3], mvf[3], f, cx, cy) : -1.f,
+           oke ? p3p_screen_roots(E, Pf, muf[3], mvf[3], f, cx, cy) : -1.f);
+    double Rp[9], Tp[3], reproj2 = 0;
+    const bool solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2);
+    printf("p3p_4pt: solved %d 4th-point err %.6f accept64 %d\n", (int)solved, sqrt(reproj2), (int)(solved && accept64(Rp, Tp, Pf, mu, mv, cam, 10.0)));
+}

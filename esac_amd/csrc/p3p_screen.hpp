@@ -456,8 +456,6 @@ struct ScreenScene {
     V3f P0, e1, e2, e3;
     float c1, c2, c3;  // 4th point in the triad
     float l1, l2, l3;  // squared side lengths |P1-P0|^2, |P2-P0|^2, |P2-P1|^2
-    float h1, h2, h3;  // 0.5 / side length: (squared-length mismatch) * h = length mismatch in metres
-    float lever;       // 1 + |P3-P0| / shortest side: how far a disagreement at the base points carries to the 4th point
 };
 // false: coincident or (near-)collinear base points -- the caller reports "maybe"
 ESAC_HD bool screen_scene(const float (&Pf)[4][3], ScreenScene& sc) {
@@ -475,8 +473,6 @@ ESAC_HD bool screen_scene(const float (&Pf)[4][3], ScreenScene& sc) {
     sc.e2 = crossf(sc.e3, sc.e1);
     const V3f w = P3 - P0;
     sc.c1 = dotf(w, sc.e1); sc.c2 = dotf(w, sc.e2); sc.c3 = dotf(w, sc.e3);
-    sc.h1 = 0.5f * scr_rsqf(sc.l1); sc.h2 = 0.5f * scr_rsqf(sc.l2); sc.h3 = 0.5f * scr_rsqf(sc.l3);
-    sc.lever = 1.0f + scr_sqrtf(dotf(w, w)) * scr_rsqf(fminf(sc.l1, fminf(sc.l2, sc.l3)));
     return true;
 }
 // one candidate: depths X, Y, Z of the base points along their unit bearings (mu, mv, mk) -> reprojection error of the 4th
@@ -491,6 +487,7 @@ ESAC_HD float screen_candidate(const ScreenScene& sc, const float (&mu)[3], cons
     const float m1 = dotf(qe1, qe1), m2 = dotf(qe2, qe2), m3s = dotf(qe3, qe3);
     if (!(fabsf(m1 - sc.l1) <= congruence * sc.l1) || !(fabsf(m2 - sc.l2) <= congruence * sc.l2) || !(fabsf(m3s - sc.l3) <= congruence * sc.l3))
         return ESAC_SCREEN_MAYBE;
+    const float dm = fmaxf(fmaxf(fabsf(m1 - sc.l1), fabsf(m2 - sc.l2)), fabsf(m3s - sc.l3));  // largest mismatch of a squared side, see below
     const V3f f1 = scr_rsqf(m1) * qe1;
     V3f f3 = crossf(f1, qe2);
     const float m3 = dotf(f3, f3);
@@ -503,12 +500,15 @@ ESAC_HD float screen_candidate(const ScreenScene& sc, const float (&mu)[3], cons
     if (!(fabsf(Zc) > 1e-3f * (fabsf(Xc) + fabsf(Yc) + 1e-6f))) return ESAC_SCREEN_MAYBE;  // 4th point next to the camera plane
     // The camera-frame triangle is never exactly the scene triangle (the depths carry the rounding of the roots), and the
     // fp64 route's least-squares alignment and the triads above settle that mismatch -- dl metres of side length --
-    // differently: their 4th points differ by ~lever * dl, which is f * lever * dl / |Zc| pixels.  Harmless at metres of
+    // differently: their 4th points differ by ~lever * (side mismatch) =: dl metres, which is f * dl / |Zc| pixels.  Harmless at metres of
     // depth; with the 4th point millimetres from the camera centre it is the whole margin (found by the 3.6e10-try host
     // campaign of round 3: a sample whose 4th cell repeats a base point, camera 3.5 mm from it, 14.0 px here against
     // 9.98 px in the fp64 route).  Half a pixel of it is allowed.
-    const float dl = fmaxf(fmaxf(fabsf(m1 - sc.l1) * sc.h1, fabsf(m2 - sc.l2) * sc.h2), fabsf(m3s - sc.l3) * sc.h3);
-    if (!(2.0f * f * sc.lever * dl <= 0.5f * fabsf(Zc))) {
+    // (dm of a squared side length is dm / (2 * side) metres of side; the lever is 1 + |P3 - P0| / side; both with the
+    // shortest side, formed here from what is live anyway: no register held across the candidates)
+    const float is = scr_rsqf(fminf(sc.l1, fminf(sc.l2, sc.l3)));
+    const float dl = dm * 0.5f * is * (1.0f + scr_sqrtf(sc.c1 * sc.c1 + sc.c2 * sc.c2 + sc.c3 * sc.c3) * is);
+    if (!(2.0f * f * dl <= 0.5f * fabsf(Zc))) {
         ESAC_SCREEN_STAT(9);
         return ESAC_SCREEN_MAYBE;
     }

@@ -273,3 +273,26 @@ extern "C" void probe_one(const float* pts /*4x3*/, const float* px /*4x2*/, flo
     const bool solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2);
     printf("p3p_4pt: solved %d 4th-point err %.6f accept64 %d\n", (int)solved, sqrt(reproj2), (int)(solved && accept64(Rp, Tp, Pf, mu, mv, cam, 10.0)));
 }
+
+// the same as numbers: out[0] screen on the private fast copy, out[1] screen on the exact route's roots (ESAC_SCREEN_MAYBE = -1),
+// out[2] 4th-point error of the fp64 route's pose, out[3] 1 if the fp64 route accepts the try at tau
+extern "C" void probe_one_values(const float* pts, const float* px, float f, float cx, float cy, float tau, double* out) {
+    const Cam cam{(double)f, (double)f, (double)cx, (double)cy};
+    float Pf[4][3], muf[4], mvf[4];
+    V3 Pt[4];
+    double mu[4], mv[4];
+    for (int j = 0; j < 4; j++) {
+        for (int k = 0; k < 3; k++) Pf[j][k] = pts[3 * j + k];
+        Pt[j] = V3{(double)Pf[j][0], (double)Pf[j][1], (double)Pf[j][2]};
+        muf[j] = px[2 * j]; mvf[j] = px[2 * j + 1];
+        mu[j] = muf[j]; mv[j] = mvf[j];
+    }
+    P3PSetup E;
+    ScreenSetup S;
+    out[0] = screen_setup(Pt, mu, mv, cam, S) ? (double)p3p_screen_roots(S, Pf, muf[3], mvf[3], f, cx, cy) : INFINITY;
+    out[1] = p3p_setup(Pt, mu, mv, cam, E) ? (double)p3p_screen_roots(E, Pf, muf[3], mvf[3], f, cx, cy) : INFINITY;
+    double Rp[9], Tp[3], reproj2 = 0;
+    const bool solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2);
+    out[2] = solved ? sqrt(reproj2) : -1.0;
+    out[3] = solved && accept64(Rp, Tp, Pf, mu, mv, cam, (double)tau) ? 1.0 : 0.0;
+}

@@ -362,6 +362,31 @@ def test_fp32_screen_never_rejects_an_accepted_try():
             assert out[5] / tries < 0.01, out[5] / tries              # "maybe" fraction at the kernel's margin
 
 
+def test_screen_defers_when_the_fourth_point_sits_at_the_camera_centre():
+    """The one false reject a 3.6e10-try host campaign found (scripts/dev/screen_adversarial.py, map "plane
+    warped, x and y quantised"): the 4th cell repeats a base point's scene coordinates 8 px away in the image, the solution
+    puts the camera centre 3.5 mm from it, and the alignment-free evaluation of the screen (14.0 px) and the fp64 route's
+    least-squares alignment (9.98 px: accepted) settle the triangle's residual mismatch differently.  The screen must say
+    "maybe" there -- on its private copy of the roots and on the exact route's own."""
+    import ctypes as C
+    from tests.native import build as nb
+    lib = C.CDLL(nb.build_screen_probe())
+    pts = np.array([[1.0, -0.0, 2.0], [0.0, 0.25, 2.0], [1.75, 0.5, 2.0], [1.75, 0.5, 2.0]], np.float32)
+    px = np.array([[476, 188], [340, 388], [612, 412], [612, 420]], np.float32)
+    out = np.zeros(4)
+    lib.probe_one_values(pts.ctypes.data_as(C.c_void_p), px.ctypes.data_as(C.c_void_p), C.c_float(525.0), C.c_float(320.0),
+                         C.c_float(240.0), C.c_float(10.0), out.ctypes.data_as(C.c_void_p))
+    assert out[3] == 1.0 and 9.9 < out[2] < 10.0, out   # the fp64 route accepts, barely
+    assert out[0] == -1.0 and out[1] == -1.0, out       # ESAC_SCREEN_MAYBE on both sets of roots
+    # the same triangle seen from a metre away is none of the guard's business
+    px2 = np.array([[476, 188], [340, 388], [612, 412], [100, 80]], np.float32)
+    pts2 = pts.copy()
+    pts2[3] = [-1.5, -1.0, 2.5]
+    lib.probe_one_values(pts2.ctypes.data_as(C.c_void_p), px2.ctypes.data_as(C.c_void_p), C.c_float(525.0), C.c_float(320.0),
+                         C.c_float(240.0), C.c_float(10.0), out.ctypes.data_as(C.c_void_p))
+    assert out[0] > 13.0 and out[3] == 0.0, out         # a plain rejection, decided by the screen itself
+
+
 def test_fast_quartic_agrees_with_the_exact_route_or_says_maybe():
     """quartic_roots_fast (the sampling screen's copy of the Ferrari solve: contracted arithmetic, fp32-seeded Newton cubic
     root) next to quartic_real_roots (the route the decision uses) on quartics BUILT to be hard: a root pair closing from 1e-1

@@ -2,7 +2,8 @@
 """Adversarial maps for the sampling screen (host build of esac_amd/csrc/p3p_screen.hpp vs the fp64 route,
 tests/native/p3p_screen_probe.cpp mode 3): planar / fronto-parallel / warped / quantised / mis-calibrated maps on which
 four random cells are near-degenerate P3P configurations (double roots of the quartic, collinear or coincident samples) or
-sit next to the tau boundary.  python scripts/dev/screen_adversarial.py [tries per map, default 1e7]"""
+sit next to the tau boundary.  python scripts/dev/screen_adversarial.py [tries per map, default 1e7] [mode, default 3] [quantised]
+(`quantised`: the second family, quantised_maps())"""
 import ctypes as C
 import os
 import sys
@@ -70,6 +71,26 @@ def adversarial_maps(H=60, W=80, sub=8, focal=525.0, ppx=320.0, ppy=240.0):
     return maps
 
 
+def quantised_maps():
+    """A second family (round 3, after the campaign's one find came from a map with repeated scene points): predictions with
+    coordinates rounded to a grid or constant over blocks of cells -- 4th cells that repeat a base point's coordinates."""
+    maps = {}
+    room = S.make_frame(3)["coords"][0]
+    for q in (0.01, 0.05, 0.25):
+        maps["room quantised %.2f m" % q] = (np.round(room / q) * q).astype(np.float32)
+    for b in (2, 4):
+        blk = room[:, ::b, ::b]
+        maps["room piecewise constant %dx%d" % (b, b)] = np.repeat(np.repeat(blk, b, axis=1), b, axis=2)[:, :60, :80].copy()
+    clean = S.make_frame(5, noise=0.0, outlier_frac=0.0)["coords"][0]
+    maps["clean room quantised 0.05 m"] = (np.round(clean / 0.05) * 0.05).astype(np.float32)
+    blk = clean[:, ::2, ::2]
+    maps["clean room piecewise constant 2x2"] = np.repeat(np.repeat(blk, 2, axis=1), 2, axis=2)[:, :60, :80].copy()
+    am = adversarial_maps()
+    maps["sphere warped quantised 0.125"] = (np.round(am["sphere warped"] * 8) / 8).astype(np.float32)
+    maps["plane warped 2x0.5 quantised xyz 0.25"] = (np.round(am["plane warped 2x0.5"] * 4) / 4).astype(np.float32)
+    return maps
+
+
 def run(lib, coords, n, seed, sub=8, focal=525.0, ppx=320.0, ppy=240.0, tau=10.0, margins=(0.5, 1.0, 2.0, 3.0), mode=3):
     m = np.asarray(margins, np.float32)
     out = np.zeros(40)
@@ -85,8 +106,9 @@ if __name__ == "__main__":
     mode = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     lib = C.CDLL(nb.build_screen_probe())
     tot = rej = 0
-    for k, (name, coords) in enumerate(adversarial_maps().items()):
-        out = run(lib, coords, n, 500 + k, mode=mode)
+    family = quantised_maps() if len(sys.argv) > 3 and sys.argv[3] == "quantised" else adversarial_maps()
+    for k, (name, coords) in enumerate(family.items()):
+        out = run(lib, coords, n, (900 if family is not None and len(sys.argv) > 3 else 500) + k, mode=mode)
         t, acc = out[0], out[1]
         tot += acc
         rej += out[15]

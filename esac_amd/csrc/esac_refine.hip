@@ -116,7 +116,7 @@ constexpr int ERR_UNROLL = ESAC_ERR_UNROLL;    // points per lane in flight in t
 constexpr int LM_NP = ESAC_LM_NP;              // correspondences per lane in flight in an LM pass
 
 // Section cycle counters (clock64 = shader clock), enabled with -DESAC_PROFILE_CYCLES; index:
-// 0 total, 1 argmax, 2 error image + compaction, 3 unused, 4 rodrigues+chain, 5 point loop, 6 block_sum,
+// 0 total, 1 argmax, 2 error image + compaction, 3 pose2trans + result record, 4 rodrigues+chain, 5 point loop, 6 block_sum,
 // 7 transform, 8 solve, 9 number of passes
 #ifdef ESAC_PROFILE_CYCLES
 #define CYC_DECL long long cyc_t0_
@@ -750,6 +750,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         return;
     }
     // ---- pose2trans (esac_util.h:537-548) and the result record
+    CYC_BEGIN();
     if (threadIdx.x == 0 && writer) {
         double R[9];
         rodrigues_vec2mat<false>(pose, R, nullptr);
@@ -790,6 +791,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
             *reinterpret_cast<volatile double*>(a.result_pin + 32) = a.epoch;
         }
 #ifdef ESAC_PROFILE_CYCLES
+        CYC_END(3);
         g_cyc[0] = clock64() - cyc_start;
         for (int k = 0; k < 16; k++) a.cycles[k] = g_cyc[k];
 #endif

@@ -28,6 +28,8 @@ BUF_INLIER_MAP, BUF_INLIER_COUNTS, BUF_WINNER_ERRS, BUF_EXACT_FLAGS, BUF_CYCLES 
 BUF_BWD_PROBS, BUF_BWD_LOSSES, BUF_BWD_REF_HYPS, BUF_BWD_SCORE_GRADS, BUF_BWD_SLOTS, BUF_BWD_SLOT_INFO, BUF_BWD_DLOSS = \
     10, 11, 12, 13, 14, 15, 16
 BUF_BWD_PATH1, BUF_BWD_PATH2 = 17, 18
+BUF_REFINE_INFO = 19
+REFINE_TEAM_MAX, REFINE_TEAM_DEFAULT = 8, 8
 MAX_REF_STEPS = 100
 BWD_MAX_SLOTS = 1000
 
@@ -37,11 +39,12 @@ ABI_SYMBOLS = [
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
     "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug", "esac_hip_check",
     "esac_hip_pick_record", "esac_hip_time_stages", "esac_hip_shard_balanced", "esac_hip_set_wait",
+    "esac_hip_set_refine_team",
 ]
-ABI_VERSION = 3
+ABI_VERSION = 4
 FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS, FLAG_EXACT_SAMPLING, FLAG_SCORES_BY_INDEX = 1, 2, 4, 8, 16, 32
 WAIT_SPIN, WAIT_YIELD, WAIT_BLOCK = 0, 1, 2
-DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL = 1, 2
+DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL, DEBUG_TEAM_SPREAD = 1, 2, 4
 
 
 class Params(C.Structure):
@@ -100,6 +103,7 @@ def load_library():
         lib.esac_hip_time_stages.argtypes = [vp, vp, vp, pp, vp, i32, vp]
         lib.esac_hip_shard_balanced.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
         lib.esac_hip_set_wait.argtypes = [vp, i32]
+        lib.esac_hip_set_refine_team.argtypes = [vp, i32]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
                 getattr(lib, name).restype = i32
@@ -127,6 +131,9 @@ class Engine:
         self.ctx = C.c_void_p()
         _check(self.lib.esac_hip_create(C.byref(self.ctx), self.device.index), self.lib)
         self._shape = None
+        # the raw hipStream_t of torch's current stream: a private torch symbol (no Stream object on the per-call path)
+        # with the public route as the fallback, resolved once
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
     def _call(self, fn, *args):
         """One C-ABI call with this engine's device current (the library calls hipSetDevice itself; the context
@@ -147,8 +154,10 @@ class Engine:
 
     # -- helpers
     def _stream(self):
-        # the raw hipStream_t of torch's current stream on this device (no Stream object: this sits on the per-call path)
-        return torch._C._cuda_getCurrentRawStream(self.device.index)
+        # the raw hipStream_t of torch's current stream on this device
+        if self._raw_stream is not None:
+            return self._raw_stream(self.device.index)
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     def make_params(self, E, H, W, N, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
                     inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0,
@@ -269,7 +278,7 @@ class Engine:
             BUF_SCORES: ((N,), np.float64), BUF_RESULT: ((RES_DOUBLES,), np.float64),
             BUF_INLIER_MAP: ((H, W), np.uint8), BUF_INLIER_COUNTS: ((MAX_REF_STEPS + 1,), np.int32),
             BUF_WINNER_ERRS: ((H, W), np.float32), BUF_EXACT_FLAGS: ((N,), np.uint8),
-            BUF_CYCLES: ((32,), np.int64),
+            BUF_CYCLES: ((32,), np.int64), BUF_REFINE_INFO: ((8,), np.int32),
             BUF_BWD_PROBS: ((N,), np.float64), BUF_BWD_LOSSES: ((N,), np.float64), BUF_BWD_REF_HYPS: ((N, 6), np.float64),
             BUF_BWD_SCORE_GRADS: ((N,), np.float64), BUF_BWD_SLOTS: ((N,), np.int32),
             BUF_BWD_SLOT_INFO: ((min(N, BWD_MAX_SLOTS), 4), np.int32), BUF_BWD_DLOSS: ((min(N, BWD_MAX_SLOTS), 6), np.float64),
@@ -322,8 +331,21 @@ class Engine:
         """Waits for the device; raises if the most recent (asynchronous) call met an out-of-range hypAssignment."""
         _check(self.lib.esac_hip_check(self.ctx), self.lib)
 
-    def set_debug(self, keep_error_image=False, coop_stall=False):
-        _check(self.lib.esac_hip_set_debug(self.ctx, (DEBUG_ERROR_IMAGE if keep_error_image else 0) | (DEBUG_COOP_STALL if coop_stall else 0)), self.lib)
+    def set_debug(self, keep_error_image=False, coop_stall=False, team_spread=False):
+        _check(self.lib.esac_hip_set_debug(self.ctx, (DEBUG_ERROR_IMAGE if keep_error_image else 0) | (DEBUG_COOP_STALL if coop_stall else 0) |
+                                           (DEBUG_TEAM_SPREAD if team_spread else 0)), self.lib)
+
+    def set_refine_team(self, members=REFINE_TEAM_DEFAULT):
+        """Workgroups that share the winner's refinement on a small single-frame grid (0 / 1: one workgroup;
+        esac_hip_set_refine_team)."""
+        _check(self.lib.esac_hip_set_refine_team(self.ctx, int(members)), self.lib)
+
+    def refine_info(self):
+        """How the most recent winner refinement ran (ESAC_BUF_REFINE_INFO)."""
+        v = self.read(BUF_REFINE_INFO)
+        return {"mode": ("one_workgroup", "cooperating", "team")[int(v[0])] if 0 <= int(v[0]) <= 2 else int(v[0]),
+                "workgroups": int(v[1]), "xcd_census": "%08x" % (int(v[2]) & 0xffffffff), "same_xcd": bool(v[3]),
+                "exchanges": int(v[4]), "timed_out": bool(v[5]), "team_fallbacks": int(v[6])}
 
     def set_timing(self, on, period=1):
         """Per-phase events on every `period`-th forward call (the next call is the first sampled one)."""

@@ -109,12 +109,12 @@ __device__ __forceinline__ double swap16_pairsum(double a, double b) {
     return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
-// Sum up to 28 doubles per thread over a workgroup of B threads; every thread receives all totals.
-// s_part: 28*(B/64) doubles, s_tot: 28 doubles.  Deterministic (fixed combination order).
-template <int NV, int B>
-__device__ __forceinline__ void block_sum28(double (&v)[NV], double* s_part, double* s_tot) {
-    static_assert(NV <= 28, "block_sum28 handles at most 28 values");
-    constexpr int NW = B / 64;
+// Stage 1 of the workgroup sum of up to 28 doubles per thread: every wavefront leaves ITS 28 totals in
+// s_part[wave * 28 ...] (ends with a workgroup barrier).  Stage 2 (workgroup_total28): thread t < 28 adds the wavefronts'
+// totals of value t in wavefront order.
+template <int NV>
+__device__ __forceinline__ void wave_totals28_to_lds(const double (&v)[NV], double* s_part) {
+    static_assert(NV <= 28, "at most 28 values");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double w[14], u[7];
 #pragma unroll
@@ -140,12 +140,24 @@ __device__ __forceinline__ void block_sum28(double (&v)[NV], double* s_part, dou
         for (int q = 0; q < 7; q++) s_part[wave * 28 + 4 * q + sub] = u[q];
     }
     barrier_lds();
+}
+template <int B>
+__device__ __forceinline__ double workgroup_total28(const double* s_part) {  // meaningful in threads < 28
+    double t = 0;
     if (threadIdx.x < 28) {
-        double t = 0;
 #pragma unroll
-        for (int k = 0; k < NW; k++) t += s_part[k * 28 + threadIdx.x];
-        s_tot[threadIdx.x] = t;
+        for (int k = 0; k < B / 64; k++) t += s_part[k * 28 + threadIdx.x];
     }
+    return t;
+}
+
+// Sum up to 28 doubles per thread over a workgroup of B threads; every thread receives all totals.
+// s_part: 28*(B/64) doubles, s_tot: 28 doubles.  Deterministic (fixed combination order).
+template <int NV, int B>
+__device__ __forceinline__ void block_sum28(double (&v)[NV], double* s_part, double* s_tot) {
+    wave_totals28_to_lds<NV>(v, s_part);
+    const double t = workgroup_total28<B>(s_part);
+    if (threadIdx.x < 28) s_tot[threadIdx.x] = t;
     barrier_lds();
 #pragma unroll
     for (int k = 0; k < NV; k++) v[k] = s_tot[k];

@@ -8,6 +8,7 @@
 #include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/esac_hip.h"
@@ -23,7 +24,7 @@ static_assert(ESAC_RES_SCORE == ESAC_RES_SCORE_K && ESAC_RES_HYP == ESAC_RES_HYP
                   ESAC_RES_CONTENDERS == ESAC_RES_CONTENDERS_K && ESAC_RES_LM_ITERS == ESAC_RES_LM_ITERS_K &&
                   ESAC_MAX_REF_STEPS == ESAC_MAX_REF_STEPS_K && ESAC_BWD_MAX_SLOTS == ESAC_BWD_SLOTS_K &&
                   ESAC_FLAG_EXACT_SCORES == ESAC_FLAG_EXACT_SCORES_K && ESAC_FLAG_EXACT_SAMPLING == ESAC_FLAG_EXACT_SAMPLING_K &&
-                  ESAC_FLAG_SCORES_BY_INDEX == ESAC_FLAG_SCORES_BY_INDEX_K,
+                  ESAC_FLAG_SCORES_BY_INDEX == ESAC_FLAG_SCORES_BY_INDEX_K && ESAC_REFINE_TEAM_MAX == ESAC_REFINE_TEAM_MAX_K,
               "result layout drifted between include/esac_hip.h and esac_kernels.hpp");
 
 static thread_local char g_err[512] = "";
@@ -75,6 +76,10 @@ struct esac_hip_ctx {
     int wait_mode = ESAC_WAIT_SPIN;
     int coop_max = 0;         // cooperative refinement workgroups this device holds at once (refine_coop_capacity)
     bool coop_stall = false;  // ESAC_DEBUG_COOP_STALL
+    int team = ESAC_REFINE_TEAM_DEFAULT;  // members of the refinement team on small grids (esac_hip_set_refine_team; 0: one workgroup)
+    bool team_spread = false;             // ESAC_DEBUG_TEAM_SPREAD: the members are consecutive workgroups (one per XCD)
+    unsigned long long refine_tag = 0;    // tag of the most recent shared (cooperative / team) refinement launch, 0: none yet
+    long long team_fallbacks = 0;         // blocking calls whose team timed out and were refined again by one workgroup
     BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
     int bN = 0, bP = 0, bcap = 0;
     bool b_lists = false;
@@ -98,7 +103,7 @@ static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.hyps_R,      c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.samp_count, c->ws.samp_pending, c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.sel_partials, c->ws.sel_arrived, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
-                    c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials, c->ws.bucket_fill};
+                    c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.refine_info, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials, c->ws.bucket_fill};
     c->tN = c->tChunks = 0;
     c->tPart = 0;
     for (void* p : ptrs)
@@ -123,6 +128,10 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
     memset(c->h_pin, 0, (size_t)ESAC_PIN_DOUBLES * ESAC_MAX_BATCH * sizeof(double));
     HIP_OK(hipHostGetDevicePointer((void**)&c->d_pin, c->h_pin, 0));
     c->coop_max = refine_coop_capacity();  // CUs x resident workgroups of the cooperative refinement kernel on THIS device
+    if (const char* e = getenv("ESAC_REFINE_TEAM")) {  // start value of esac_hip_set_refine_team (measurement scripts)
+        const int g = atoi(e);
+        c->team = g < 2 ? 0 : (g > ESAC_REFINE_TEAM_MAX ? ESAC_REFINE_TEAM_MAX : g);
+    }
     *out = c;
     return 0;
 }
@@ -177,6 +186,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.status, (size_t)1);
     rc |= alloc(&c->ws.coop_partials, (size_t)2 * ESAC_REFINE_COOP_MAX * 32);
     rc |= alloc(&c->ws.coop_counter, (size_t)2);
+    rc |= alloc(&c->ws.refine_info, (size_t)8);
     rc |= alloc(&c->ws.sample_xy, (size_t)nN * 8);
     rc |= alloc(&c->ws.tries, (size_t)nN);
     rc |= alloc(&c->ws.samp_resume, (size_t)nN);
@@ -210,7 +220,9 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
         return rc;
     }
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
-    HIP_OK(hipMemset(c->ws.coop_counter, 0, 2 * sizeof(unsigned long long)));  // [1] is read by esac_hip_check
+    HIP_OK(hipMemset(c->ws.coop_counter, 0, 2 * sizeof(unsigned long long)));  // [1]: tag of the last failed shared refinement (esac_hip_check)
+    HIP_OK(hipMemset(c->ws.coop_partials, 0, (size_t)2 * ESAC_REFINE_COOP_MAX * 32 * sizeof(double)));  // (also the team's granules)
+    HIP_OK(hipMemset(c->ws.refine_info, 0, 8 * sizeof(int)));
     HIP_OK(hipMemset(c->ws.samp_count, 0, (4 + 2 * 1024) * sizeof(int)));       // the screened chain leaves them at zero (esac_kernels.hip)
     HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
     HIP_OK(hipMemcpy(c->ws.status, &old_status, sizeof(old_status), hipMemcpyHostToDevice));
@@ -340,6 +352,8 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     a.expert_base = p->expert_base;
     a.coop_max = c->coop_max;
     a.coop_extra = c->coop_stall ? 1 : 0;
+    a.team = c->team;
+    a.team_stride = c->team_spread ? 1 : 8;
     a.samp_cap = (int)(((long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP) > 0x7fffffffLL ? 0x7fffffff : (long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP);
     a.flags = p->flags;
     c->epoch += 1.0;  // every call gets its own epoch: result hand-off word and the tag of the status word
@@ -408,7 +422,7 @@ extern "C" int esac_hip_select(esac_hip_ctx* c, const float* d_sc, const int64_t
     });
 }
 extern "C" int esac_hip_refine(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    return run_stage(c, d_sc, d_assign, p, stream, "k_refine", [](esac_hip_ctx*, const KArgs& a, hipStream_t s) { launch_refine(a, s); });
+    return run_stage(c, d_sc, d_assign, p, stream, "k_refine", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) { cc->refine_tag = launch_refine(a, s); });
 }
 extern "C" int esac_hip_score_exact(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
     return run_stage(c, d_sc, d_assign, p, stream, "k_rescore(all)", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) {
@@ -454,7 +468,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     else       launch_select_rescore(a, s);
     if ((rc = check_launch(exact ? "k_stats_exact" : "k_select_rescore"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
-    launch_refine(a, s);
+    c->refine_tag = launch_refine(a, s);
     if ((rc = check_launch("k_refine"))) return rc;
     if (tm) {
         HIP_OK(hipEventRecord(c->ev[4], s));
@@ -467,33 +481,47 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     if (h_result_out) {
         // the refinement kernel stores the record and then the epoch word into pinned host memory
         // (one ESAC_PIN_DOUBLES slot per frame: record, epoch word, status word)
-        const double want = c->epoch;
-        auto all_landed = [&]() {
-            for (int b = 0; b < B; b++)
-                if (*(volatile double*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES + 32) != want) return false;
-            return true;
-        };
-        bool landed = false;
-        if (c->wait_mode == ESAC_WAIT_BLOCK) {
-            HIP_OK(hipStreamSynchronize(s));
-            landed = all_landed();
-        } else {
-            const bool yield = c->wait_mode == ESAC_WAIT_YIELD;
-            for (long spins = 0; spins < 200000000L; spins++) {
-                if (all_landed()) {
-                    landed = true;
-                    break;
-                }
-                if (yield) sched_yield();
-                if ((spins & (yield ? 63 : 1023)) == (yield ? 63 : 1023) && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernels are done (or failed)
-                    landed = all_landed();
-                    break;
+        auto wait_record = [&](double want) -> int {
+            auto all_landed = [&]() {
+                for (int b = 0; b < B; b++)
+                    if (*(volatile double*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES + 32) != want) return false;
+                return true;
+            };
+            bool landed = false;
+            if (c->wait_mode == ESAC_WAIT_BLOCK) {
+                HIP_OK(hipStreamSynchronize(s));
+                landed = all_landed();
+            } else {
+                const bool yield = c->wait_mode == ESAC_WAIT_YIELD;
+                for (long spins = 0; spins < 200000000L; spins++) {
+                    if (all_landed()) {
+                        landed = true;
+                        break;
+                    }
+                    if (yield) sched_yield();
+                    if ((spins & (yield ? 63 : 1023)) == (yield ? 63 : 1023) && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernels are done (or failed)
+                        landed = all_landed();
+                        break;
+                    }
                 }
             }
-        }
-        if (!landed) {
-            HIP_OK(hipStreamSynchronize(s));
-            if (!all_landed()) return fail(-9, "esac_hip_forward: the refinement kernel did not deliver a result record");
+            if (!landed) {
+                HIP_OK(hipStreamSynchronize(s));
+                if (!all_landed()) return fail(-9, "esac_hip_forward: the refinement kernel did not deliver a result record");
+            }
+            return 0;
+        };
+        if ((rc = wait_record(c->epoch))) return rc;
+        if (B == 1 && c->h_pin[33] == 3.0 && refine_team_members(a) > 0 && refine_coop_slice(a) == 0) {
+            // the team's members did not all become resident in time (a shared or partitioned GPU): the same refinement in
+            // one workgroup -- the hypotheses, scores and selection of this call are still in the workspace
+            c->team_fallbacks++;
+            c->epoch += 1.0;
+            a.epoch = c->epoch;
+            a.team = 0;
+            c->refine_tag = launch_refine(a, s);
+            if ((rc = check_launch("k_refine (one workgroup, after a team time-out)"))) return rc;
+            if ((rc = wait_record(c->epoch))) return rc;
         }
         __sync_synchronize();
         bool bad_assign = false;
@@ -531,7 +559,7 @@ extern "C" int esac_hip_time_stages(esac_hip_ctx* c, const float* d_sc, const in
             case 0: launch_sample(a, s); break;
             case 1: if (exact) launch_rescore_all(a, s); else launch_score(a, s); break;
             case 2: if (exact) launch_stats_exact(a, s); else launch_select_rescore(a, s); break;
-            default: launch_refine(a, s); break;
+            default: c->refine_tag = launch_refine(a, s); break;
         }
     };
     for (int k = 0; k < 4; k++) stage(k);
@@ -771,8 +799,8 @@ extern "C" int esac_hip_check(esac_hip_ctx* c) {
     unsigned long long st = 0, coop[2] = {0, 0};
     HIP_OK(hipMemcpy(&st, c->ws.status, sizeof(st), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(coop, c->ws.coop_counter, sizeof(coop), hipMemcpyDeviceToHost));
-    if (coop[1] != 0)  // (zeroed by every cooperative launch: this is the most recent one)
-        return fail(-12, "the cooperating refinement workgroups of the most recent large-grid call could not synchronise (not all of them became resident)");
+    if (c->refine_tag != 0 && coop[1] == c->refine_tag)  // the failure word carries the tag of the launch that failed: only the most recent one counts
+        return fail(-12, "the cooperating refinement workgroups of the most recent call could not synchronise (not all of them became resident)");
     if (st != 0 && (double)st == c->sample_epoch) return fail(-10, "hypAssignment held a value outside [0,E) in the most recent sampling call");
     return 0;
 }
@@ -828,6 +856,17 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
             src = c->ws.errs; want = P * sizeof(float); break;
         case ESAC_BUF_EXACT_FLAGS: src = c->ws.exact_flag; want = N; break;
         case ESAC_BUF_CYCLES: src = c->ws.cycles; want = 32 * sizeof(long long); break;
+        case ESAC_BUF_REFINE_INFO: {
+            if (bytes != 8 * sizeof(int32_t)) return fail(-7, "esac_hip_read: the refinement info holds 32 bytes, caller asked for %zu", bytes);
+            if (!c->ws.refine_info) return fail(-6, "esac_hip_read: buffer %d is empty (no call has run yet)", which);
+            HIP_OK(hipDeviceSynchronize());
+            int32_t info[8];
+            HIP_OK(hipMemcpy(info, c->ws.refine_info, sizeof(info), hipMemcpyDeviceToHost));
+            info[6] = (int32_t)c->team_fallbacks;
+            info[7] = 0;
+            memcpy(h_dst, info, sizeof(info));
+            return 0;
+        }
         case ESAC_BUF_BWD_PROBS: src = c->bws.probs; want = N * sizeof(double); break;
         case ESAC_BUF_BWD_LOSSES: src = c->bws.losses; want = N * sizeof(double); break;
         case ESAC_BUF_BWD_REF_HYPS: src = c->bws.ref_hyps; want = N * 6 * sizeof(double); break;
@@ -870,10 +909,18 @@ extern "C" int esac_hip_write_hyps(esac_hip_ctx* c, const double* h_hyps, int N)
     return 0;
 }
 
+extern "C" int esac_hip_set_refine_team(esac_hip_ctx* c, int members) {
+    if (!c) return fail(-1, "null context");
+    if (members < 0 || members > ESAC_REFINE_TEAM_MAX) return fail(-4, "esac_hip_set_refine_team: %d members (0..%d)", members, ESAC_REFINE_TEAM_MAX);
+    c->team = members < 2 ? 0 : members;
+    return 0;
+}
+
 extern "C" int esac_hip_set_debug(esac_hip_ctx* c, int flags) {
     if (!c) return fail(-1, "null context");
     c->keep_errs = (flags & ESAC_DEBUG_ERROR_IMAGE) != 0;
     c->coop_stall = (flags & ESAC_DEBUG_COOP_STALL) != 0;
+    c->team_spread = (flags & ESAC_DEBUG_TEAM_SPREAD) != 0;
     return 0;
 }
 

@@ -15,6 +15,8 @@ constexpr int ESAC_REFINE_LDS_CAP = 8192;  // correspondences the refinement ker
 constexpr int ESAC_REFINE_THREADS = 256;   // 4 wavefronts = one per SIMD of the one CU a refinement occupies
 constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the error pass
 constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refinement (one per CU: all must be resident)
+constexpr int ESAC_REFINE_TEAM_MAX_K = 8;    // ... on a grid that fits one workgroup's LDS list: a team on one XCD (esac_refine.hip)
+constexpr int ESAC_REFINE_TEAM_MIN_CELLS = 1024;  // smaller grids are refined by one workgroup (a pass is shorter than an exchange)
 constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result record [32] + epoch word + status word
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
 constexpr int ESAC_FLAG_EXACT_SAMPLING_K = 16, ESAC_FLAG_SCORES_BY_INDEX_K = 32;  // = ESAC_FLAG_* (checked in esac_capi.hip)
@@ -109,6 +111,10 @@ struct KArgs {
     int coop_slice;
     int coop_max;                       // workgroups of the cooperative kernel the device holds at once (refine_coop_capacity)
     int coop_extra;                     // ESAC_DEBUG_COOP_STALL: workgroups the barrier waits for beyond those launched (0 normally)
+    unsigned long long coop_tag;        // launch number << 20: tags the exchange granules and the failure word of THIS refinement launch
+    int team;                           // members of a refinement team on small grids (0: one workgroup refines; esac_hip_set_refine_team)
+    int team_stride;                    // the team's members are the workgroups blockIdx.x % team_stride == 0 (8: one XCD; 1: debug, spread)
+    int* refine_info;                   // [8] mode, members, XCD census (4 bits per XCD), same-XCD flag, exchanges, failed
     // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
     int* order;           // [N] hypothesis at sorted position pos (sorted by expert)
     float* rt_sorted;     // [N,12] rt32 rows in sorted order
@@ -144,7 +150,8 @@ void launch_shard_balanced(const int64_t* assign, int N, int E, int world, int r
                            int64_t* assign_out, int32_t* info_out, hipStream_t s);
 int refine_coop_capacity();              // resident workgroups of the cooperative refinement kernel on the current device
 int refine_coop_slice(const KArgs& a);  // cells per cooperating refinement workgroup, 0: one workgroup refines
-void launch_refine(const KArgs& a, hipStream_t s);
+int refine_team_members(const KArgs& a);  // members of the team that refines a small grid, 0: one workgroup refines
+unsigned long long launch_refine(const KArgs& a, hipStream_t s);  // returns the tag of a shared (cooperative / team) launch, 0 otherwise
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);
 void launch_bwd_select(const KArgs& a, hipStream_t s);

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 
 #include "device_common.hpp"
 #include "esac_kernels.hpp"
@@ -110,10 +111,7 @@ __device__ __forceinline__ void lm_solve6_pinv(const double (&U21)[21], const do
 constexpr int REFINE_B = ESAC_REFINE_THREADS;  // 4 wavefronts = one per SIMD of the one CU this kernel occupies
 constexpr int LDS_CAP = ESAC_REFINE_LDS_CAP;   // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
 constexpr int ERR_UNROLL = ESAC_ERR_UNROLL;    // points per lane in flight in the exact error pass
-#ifndef ESAC_LM_NP
-#define ESAC_LM_NP 2
-#endif
-constexpr int LM_NP = ESAC_LM_NP;              // correspondences per lane in flight in an LM pass
+constexpr int LM_NP = 2;              // correspondences per lane in flight in an LM pass
 
 // Section cycle counters (clock64 = shader clock), enabled with -DESAC_PROFILE_CYCLES; index:
 // 0 total, 1 argmax, 2 error image + compaction, 3 pose2trans + result record, 4 rodrigues+chain, 5 point loop, 6 block_sum,
@@ -152,34 +150,58 @@ __device__ __forceinline__ double pow10_int(int k) {
     return k < 0 ? 1.0 / r : r;
 }
 
-// ---- cooperating workgroups (large grids) --------------------------------------------------------------------------------
-// At 60x80 a refinement is one workgroup: its ~35 reduction points carry ~3.5 us of work each, less than a round through
-// global memory costs.  At 480x640 a pass over the grid is ~700 us of one CU's time and the same round (~4 us) is noise:
-// G workgroups then share the refinement.  Workgroup g owns the cells [g * slice, (g+1) * slice) -- its part of every
-// error pass and, in its own LDS, the correspondences found there -- and every reduction (inlier count, the 24 moments of
-// an LM pass) becomes: block sum -> partial[g] in global memory -> barrier -> every workgroup adds the G partials in the
-// same fixed order.  All workgroups then hold bitwise identical sums, take the same LM / stopping decisions and carry
-// the same pose: nothing is ever broadcast.  The barrier is one monotonic counter: the partial sums are stored with
-// device-scope (sc1, write-through) stores and drained, one lane arrives with a device-scope atomic and polls it with
-// s_sleep, the sums are read back with device-scope loads -- the "sc1 payload, drained, then the flag" hand-off of
-// MI355X_MICROARCH.md ("Workgroup dispatch ... inter-workgroup visibility"), which needs no release / acquire fence
-// (-DESAC_COOP_FENCES builds the fence form); partial sums are double-buffered by phase parity, so one barrier per
-// reduction suffices.  All G workgroups must be resident (G <= 256 one-per-CU workgroups); the spin is bounded and a
-// timeout marks the call as failed instead of hanging it.
+// ---- cooperating workgroups ------------------------------------------------------------------------------------------------
+// One refinement can be shared by G workgroups: workgroup g owns a slice of the cells -- its part of every error pass and,
+// in its own LDS, the correspondences found there -- and every reduction (inlier count, the 24 moments of an LM pass)
+// becomes: workgroup sum -> exchange -> every workgroup adds the G contributions in the same fixed order.  All workgroups
+// then hold bitwise identical sums, take the same LM / stopping decisions and carry the same pose: nothing is ever
+// broadcast.  Two exchanges exist:
+//
+// REFINE_COOP (grids beyond the LDS list, 480x640: a pass is ~700 us of one CU, up to 256 workgroups anywhere on the chip):
+// partial[g] by device-scope (sc1, write-through) stores, drained; one lane arrives at a monotonic counter and polls it
+// with s_sleep; the partials are read back with device-scope loads (~3 us a round, noise against the pass).
+//
+// REFINE_TEAM (round 4; the 60x80 grid of the headline call, where a pass is 2-6 us and that barrier costs more than it
+// saves): up to 8 workgroups exchange TAGGED GRANULES in ONE hop.  A granule is 16 bytes {double v, u64 tag},
+// tag = (launch epoch << 20 | exchange number) ^ bits(v), written by one 16-byte sc1 store; every workgroup polls all
+// G x NV granules with L1-bypassing 16-byte loads (thread t -> value t >> 3 of member t & 7) until the tag fits the value,
+// then three DPP stages add the members' contributions.  No counter, no flag, no fence; a torn or stale granule fails the
+// tag test and is simply polled again.  Buffers alternate by exchange parity (a member can be at most one exchange ahead
+// of the slowest).  Measured (scripts/dev/xcd_exchange.hip, profiles/r04_xcd_exchange.txt): 0.75 us per exchange for 8
+// workgroups on one XCD, 1.4 us across 8 XCDs.  The launcher therefore starts 8 G workgroups and keeps those with
+// blockIdx.x % 8 == 0 -- observed placement: block b runs on XCD b % 8, so the members share an L2 -- but NOTHING depends
+// on that placement except speed: sc1 stores are valid hand-offs between any two CUs.  Every member reads its XCC_ID and
+// the first exchange carries a census of them into the refinement's info words.
+// Both exchanges spin with a bound; a time-out (a member never became resident: shared or partitioned GPU) marks the
+// launch as failed, every member winds down, and the host re-runs the refinement in one workgroup (blocking calls) or
+// reports -12 (esac_hip_check).
+enum : int { REFINE_SOLO = 0, REFINE_COOP = 1, REFINE_TEAM = 2 };
+constexpr int TEAM_MAX = ESAC_REFINE_TEAM_MAX_K;  // members of a team (the poll layout gives every value 8 lanes)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct Coop {
     int G, g;                      // number of cooperating workgroups, this one's index (G == 1: no cooperation)
-    double* partials;              // [2][G][32]
-    unsigned long long* counter;   // monotonic arrival counter, zeroed by the launcher; COOP_POISON is added on a time-out
-    unsigned long long* failed;    // set when a barrier timed out (what the host reads)
-    unsigned long long arrivals;   // barriers passed so far (same in every thread of every workgroup)
-    int expect;                    // workgroups a barrier waits for (= G; ESAC_DEBUG_COOP_STALL: G + 1, never reached)
-    long spin_limit;               // polls before a barrier gives up
-    int* s_dead;                   // LDS flag: a barrier of this launch timed out somewhere
-    bool dead;                     // ... as every thread of the workgroup saw it after its last barrier (workgroup-uniform)
+    double* partials;              // REFINE_COOP: [2][G][32]
+    unsigned long long* counter;   // REFINE_COOP: monotonic arrival counter, zeroed by the launcher; COOP_POISON is or-ed in on a time-out
+    unsigned long long* failed;    // the launch tag of the most recent launch in which an exchange timed out (what the host reads)
+    unsigned long long arrivals;   // exchanges passed so far (same in every thread of every workgroup)
+    int expect;                    // workgroups an exchange waits for (= G; ESAC_DEBUG_COOP_STALL: G + 1, never reached)
+    long spin_limit;               // polls before an exchange gives up
+    int* s_dead;                   // LDS flag: an exchange of this launch timed out somewhere
+    bool dead;                     // ... as every thread of the workgroup saw it after its last exchange (workgroup-uniform)
+    u32x4* gran;                   // REFINE_TEAM: [2][TEAM_MAX][32] granules
+    unsigned long long tag;        // this launch's tag: (launch number << 20); the low 20 bits count a team's exchanges
 };
-// A workgroup that gives up at a barrier adds this to the counter: every waiter (now and at every later barrier) sees its
-// target reached at once and reads the failure out of the same value -- nobody spins a second time.
+// A workgroup that gives up at the counter barrier sets this bit: every waiter (now and at every later barrier) sees its
+// target reached at once and reads the failure out of the same value -- nobody spins a second time.  (An OR: several
+// workgroups timing out together cannot wrap the counter.)
 constexpr unsigned long long COOP_POISON = 1ull << 62;
+
+__device__ __forceinline__ void coop_mark_failed(Coop& co) {
+    __hip_atomic_store(co.failed, co.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *co.s_dead = 1;
+}
 
 // One lane: arrive at the barrier and wait for the others.  On a time-out (a workgroup of this launch never became
 // resident: the GPU is shared, partitioned, or smaller than the launcher assumed) the counter is poisoned so that every
@@ -193,16 +215,15 @@ __device__ __forceinline__ void coop_arrive_and_wait(Coop& co) {
     while ((seen = __hip_atomic_load(co.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > co.spin_limit) {
-            __hip_atomic_store(co.failed, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            seen = __hip_atomic_fetch_add(co.counter, COOP_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + COOP_POISON;
+            seen = __hip_atomic_fetch_or(co.counter, COOP_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | COOP_POISON;
             break;
         }
     }
-    if (seen >= COOP_POISON) *co.s_dead = 1;
+    if (seen & COOP_POISON) coop_mark_failed(co);
 }
 
 // v[0..NV) <- sum over the G workgroups of their v (every thread of a workgroup enters with the same v, leaves with the
-// same total; s_tot: >= 28 doubles of LDS scratch).  No-op for G == 1.
+// same total; s_tot: >= 28 doubles of LDS scratch).  REFINE_COOP only.
 template <int NV>
 __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double* s_tot, double* s_part) {
     static_assert(NV <= 28, "partials hold 32 doubles per workgroup");
@@ -216,7 +237,6 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
         for (int k = 0; k < NV; k++) s_tot[k] = v[k];
     }
     __syncthreads();
-#ifndef ESAC_COOP_FENCES
     // publish with device-scope (write-through, sc1) stores, drained before the arrival; read with device-scope loads: no
     // release / acquire fence (each ~1.7 us: an L2 write-back / an L1 invalidate) on either side of the barrier
     if (threadIdx.x < NV) {
@@ -225,19 +245,6 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
     }
     if (threadIdx.x == 0) coop_arrive_and_wait(co);
     __syncthreads();
-#define COOP_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#else
-    if (threadIdx.x < NV) buf[(size_t)co.g * 32 + threadIdx.x] = s_tot[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        coop_arrive_and_wait(co);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-#define COOP_LOAD(p) (*(p))
-#endif
     co.dead = *co.s_dead != 0;  // written before the barrier above by lane 0, read by everyone: workgroup-uniform
     // gather: 8 groups of 32 lanes, group j adds the partials of workgroups j, j+8, j+16, ... (loads independent of each
     // other), then value k adds its 8 group sums -- one fixed order for every workgroup: bitwise identical totals
@@ -245,7 +252,7 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
         const int k = threadIdx.x & 31, j = threadIdx.x >> 5;
         double t = 0;
         if (k < NV)
-            for (int w = j; w < co.G; w += 8) t += COOP_LOAD(buf + (size_t)w * 32 + k);
+            for (int w = j; w < co.G; w += 8) t += __hip_atomic_load(buf + (size_t)w * 32 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_part[j * 32 + k] = t;
     }
     __syncthreads();
@@ -262,6 +269,69 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
     co.arrivals += 1ull;
 }
 
+// ---- REFINE_TEAM: the tagged-granule exchange
+__device__ __forceinline__ u32x4 gran_load(const u32x4* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gran_store(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
+// thread t < NV publishes `own` = this member's total of value t for the exchange that team_collect() then completes
+template <int NV>
+__device__ __forceinline__ void team_publish(double own, const Coop& co) {
+    static_assert(NV <= 32, "32 granules per member");
+    if (co.dead) return;
+    if (threadIdx.x < NV) {
+        const unsigned long long want = co.tag | (co.arrivals + 1ull);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(own), tg = want ^ bits;
+        u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
+        gran_store(buf + co.g * 32 + threadIdx.x, u32x4{(unsigned)bits, (unsigned)(bits >> 32), (unsigned)tg, (unsigned)(tg >> 32)});
+    }
+}
+// v[k] <- sum over the members of their value k, members added in one fixed (pairwise) order: bitwise identical in every
+// member.  REFINE_B = 256 threads: thread t polls value t >> 3 of member t & 7.  s_tot: >= 32 doubles nobody else touches
+// until the next workgroup barrier.
+template <int NV>
+__device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot) {
+    static_assert(NV <= 32 && REFINE_B == 32 * TEAM_MAX && TEAM_MAX == 8, "poll layout: 8 lanes per value");
+    if (co.dead) return;
+    const unsigned long long want = co.tag | (co.arrivals + 1ull);
+    const u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
+    const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
+    double val = 0.0;
+    bool timed_out = false;
+    if (j < co.expect && k < NV) {
+        const u32x4* p = buf + j * 32 + k;
+        long spins = 0;
+        for (;;) {
+            const u32x4 g = gran_load(p);
+            const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.y << 32);
+            const unsigned long long tg = (unsigned long long)g.z | ((unsigned long long)g.w << 32);
+            if ((tg ^ bits) == want) {
+                val = __longlong_as_double((long long)bits);
+                break;
+            }
+            ++spins;
+            // another member gave up (its failure word carries this launch's tag): no point in waiting out the limit
+            if (spins > co.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag)) {
+                timed_out = true;
+                break;
+            }
+        }
+    }
+    if (timed_out) coop_mark_failed(co);
+    val += dpp_move<0xB1>(val);   // members (0,1) (2,3) (4,5) (6,7)
+    val += dpp_move<0x4E>(val);   // quads
+    val += dpp_move<0x141>(val);  // all eight
+    if (j == 0 && k < NV) s_tot[k] = val;
+    barrier_lds();
+    co.dead = *co.s_dead != 0;
+#pragma unroll
+    for (int kk = 0; kk < NV; kk++) v[kk] = s_tot[kk];
+    co.arrivals += 1ull;
+}
+
 // Fused pass over the whole grid at `pose`:
 //   a.errs[i]  = min(reprojection error, maxReproj)                (getReproErrs, esac_util.h:292-360);
 //                reference-exact near tau, fp32-accurate (~1e-3 px) elsewhere -- see the screening below;
@@ -271,18 +341,23 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
 // Returns the inlier count (same value in every thread).
 // Cooperative form: this workgroup handles the cells [cell0, cell0 + Pn) of the P-cell grid (cell0 a multiple of the
 // trip size); the returned count is the total over all workgroups.
-template <int B, bool VEC, typename ListPtr>
+// MODE == REFINE_TEAM: the slice is a few hundred cells -- ONE group of 4 cells per lane and trip, the groups dealt to the
+// wavefronts in turn (group q -> wavefront q % 4, lane q / 4) so that all four carry the same share of the inliers.
+template <int B, bool VEC, int MODE, typename ListPtr>
 __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __restrict__ mx, int P, const double pose[6],
                                                const Cam& cam, ListPtr list, int& n_wave, uint8_t* __restrict__ map_out,
                                                int* s_wcnt, long long* g_cyc, int cell0 = 0, int Pn = -1, Coop* co = nullptr,
                                                double* s_tot = nullptr, double* s_part = nullptr) {
     if (Pn < 0) Pn = P;
     CYC_DECL;
+    constexpr bool TEAM = MODE == REFINE_TEAM;
+    static_assert(!TEAM || VEC, "a team's slices are made of 4-cell groups");
     // VEC: every lane owns G groups of 4 CONSECUTIVE cells per trip (W % 4 == 0: a group never straddles a
     // row, planes are 16-byte aligned) -> float4 loads, one float4 + one packed-byte store per group.
     // Otherwise: U cells per lane strided by B, scalar accesses.
-    constexpr int G = VEC ? ERR_UNROLL / 4 : ERR_UNROLL;  // load groups per lane per trip
-    constexpr int L = VEC ? 4 : 1;                        // cells per group
+    constexpr int UNROLL = TEAM ? 4 : ERR_UNROLL;
+    constexpr int G = VEC ? UNROLL / 4 : UNROLL;  // load groups per lane per trip
+    constexpr int L = VEC ? 4 : 1;                // cells per group
     constexpr int U = G * L, NW = B / 64;
     static_assert(ERR_UNROLL % 4 == 0, "ERR_UNROLL must be a multiple of 4");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -319,8 +394,12 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
         CYC_BEGIN();
 #pragma unroll
         for (int g = 0; g < G; g++) {  // all loads first: one memory latency for the U cells
-            const int i = start + (g * B + (int)threadIdx.x) * L;
+            const int i = TEAM ? start + (lane * NW + wave) * L : start + (g * B + (int)threadIdx.x) * L;
             cell[g] = i;
+            if (TEAM) {
+                row = i / a.W;
+                col = i - row * a.W;
+            }
             const int ic = full ? i : (i < cell_end ? i : cell_end - L);
             if (VEC) {
                 const float4 vx = *reinterpret_cast<const float4*>(mx + ic);
@@ -341,11 +420,13 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
                 pxf[g * L + l] = (float)cell_pxi(a, col + l);
                 pyf[g * L + l] = (float)cell_pyi(a, row);
             }
-            col += stepC;
-            row += stepR;
-            if (col >= a.W) {
-                col -= a.W;
-                row++;
+            if (!TEAM) {
+                col += stepC;
+                row += stepR;
+                if (col >= a.W) {
+                    col -= a.W;
+                    row++;
+                }
             }
         }
         CYC_END(10);
@@ -357,21 +438,6 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
         // packed FMA issues in 6.5 cycles against 5.5 for a plain one (scripts/dev/valu_rate.hip) -- 1.7x on the
         // arithmetic of this pass; component by component the same operations in the same order as the plain form.
         bool need[U];
-#ifdef ESAC_ERR_SCALAR  // A/B switch (scripts/dev/variants.sh): the plain form
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const float xc = fmaf(Rf[0], X[u], fmaf(Rf[1], Y[u], fmaf(Rf[2], Z[u], tf[0])));
-            const float yc = fmaf(Rf[3], X[u], fmaf(Rf[4], Y[u], fmaf(Rf[5], Z[u], tf[1])));
-            const float zc = fmaf(Rf[6], X[u], fmaf(Rf[7], Y[u], fmaf(Rf[8], Z[u], tf[2])));
-            const float iz = (zc != 0.0f) ? __builtin_amdgcn_rcpf(zc) : 1.0f;
-            const float du = pxf[u] - fmaf(a.focal, xc * iz, a.ppx);
-            const float dv = pyf[u] - fmaf(a.focal, yc * iz, a.ppy);
-            errv[u] = __builtin_amdgcn_sqrtf(fmaf(du, du, dv * dv));
-            const float aiz = fabsf(iz), axy = fabsf(xc) + fabsf(yc);
-            const float guard = fmaf(kf * aiz * (axy + fabsf(zc) + tmag2), fmaf(axy, aiz, 1.0f), kpix);
-            need[u] = !(fabsf(errv[u] - a.tau) > guard);
-        }
-#else
 #pragma unroll
         for (int u = 0; u < U; u += 2) {
             typedef float f2 __attribute__((ext_vector_type(2)));
@@ -394,7 +460,6 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
             need[u] = !(fabsf(errv[u] - a.tau) > guard.x);
             need[u + 1] = !(fabsf(errv[u + 1] - a.tau) > guard.y);
         }
-#endif
         CYC_END(11);
         CYC_BEGIN();
         // Second screen, per sub-step and only where some lane asked for it (wave-uniform branches): the error in
@@ -467,9 +532,14 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
 #pragma unroll
     for (int w = 0; w < NW; w++) base += s_wcnt[w];
     n_wave = wcount < region ? wcount : region;
-    if (co && co->G > 1) {  // total over the cooperating workgroups (exact in double: counts < 2^28)
+    if (MODE != REFINE_SOLO && co->G > 1) {  // total over the cooperating workgroups (exact in double: counts < 2^28)
         double cnt[1] = {(double)base};
-        coop_allreduce<1>(cnt, *co, s_tot, s_part);
+        if (TEAM) {
+            team_publish<1>(cnt[0], *co);
+            team_collect<1>(cnt, *co, s_tot);
+        } else {
+            coop_allreduce<1>(cnt, *co, s_tot, s_part);
+        }
         base = co->dead ? 0 : (int)cnt[0];  // dead: "no inliers" ends the refinement loop at once
     }
     CYC_END(14);
@@ -482,7 +552,7 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
 struct PxMap {
     int sub, offx, offy;
 };
-template <int B, typename ListPtr>
+template <int B, int MODE, typename ListPtr>
 __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double param[6], const Cam& cam, const PxMap& pm, double U21[21],
                                           double g6[6], double* s_part, double* s_tot, long long* g_cyc, Coop* co = nullptr) {
     CYC_DECL;
@@ -527,8 +597,15 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
     }
     CYC_END(5);
     CYC_BEGIN();
-    block_sum28<LM_NMOM, B>(mom, s_part, s_tot);
-    if (co) coop_allreduce<LM_NMOM>(mom, *co, s_tot, s_part);
+    if (MODE == REFINE_TEAM) {
+        // wavefront totals -> LDS -> this member's totals (threads < 24) -> granules -> every member adds all members'
+        wave_totals28_to_lds<LM_NMOM>(mom, s_part);
+        team_publish<LM_NMOM>(workgroup_total28<B>(s_part), *co);
+        team_collect<LM_NMOM>(mom, *co, s_tot);
+    } else {
+        block_sum28<LM_NMOM, B>(mom, s_part, s_tot);
+        if (MODE == REFINE_COOP) coop_allreduce<LM_NMOM>(mom, *co, s_tot, s_part);
+    }
     CYC_END(6);
     CYC_BEGIN();
     double acc[LM_NACC];
@@ -543,7 +620,7 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
 // lambda = 10^k from k = -3, k++ while a step made the error worse (<= 16), k-- after an accepted step.
 // Written as ONE loop around ONE lm_pass call site (the kernel must stay inside the instruction cache:
 // with the pass inlined at several sites the code grew to 170 KB and every phase ran from cold code).
-template <int B, typename ListPtr>
+template <int B, int MODE, typename ListPtr>
 __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], const Cam& cam, const PxMap& pm, double* s_part,
                                         double* s_tot, long long* g_cyc, Coop* co = nullptr) {
     CYC_DECL;
@@ -557,7 +634,7 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
     bool have_base = false;
     for (;;) {
         // residual norm and (speculatively) the normal equations at `param`
-        const double err_norm = sqrt(lm_pass<B>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc, co));
+        const double err_norm = sqrt(lm_pass<B, MODE>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc, co));
         if (co && co->dead) break;  // a barrier timed out: the sums are garbage, the call reports -12
         bool accept;
         if (!have_base) {
@@ -605,15 +682,19 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
 // VEC: 16-byte accesses in the error pass (W % 4 == 0 and a 16-byte aligned coordinate tensor).
 // SLOTS: training path -- workgroup b refines the hypothesis of selection slot b (esac.cpp:328-347) and leaves
 // its refined pose and inlier maps in the BwdArgs buffers instead of picking the winner and writing the record.
-// COOP: gridDim.x workgroups share one refinement (see struct Coop): workgroup g owns the cells [g * coop_slice, ...), its
-// correspondences live in its own LDS list (GLOBAL_LIST must be false: a slice never exceeds LDS_CAP cells), workgroup 0
-// writes the outputs.
-template <int B, bool GLOBAL_LIST, bool VEC, bool SLOTS, bool COOP = false>
+// MODE: REFINE_SOLO one workgroup per refinement; REFINE_COOP / REFINE_TEAM several workgroups share one (see struct
+// Coop): workgroup g owns a slice of the cells, its correspondences live in its own LDS list (GLOBAL_LIST must be false: a
+// slice never exceeds LDS_CAP cells), workgroup 0 writes the outputs.  REFINE_COOP: gridDim.x workgroups, slices of
+// a.coop_slice cells.  REFINE_TEAM: the members are the workgroups blockIdx.x % a.team_stride == 0, equal slices of 4-cell
+// groups.
+template <int B, bool GLOBAL_LIST, bool VEC, bool SLOTS, int MODE = REFINE_SOLO>
 __global__ __launch_bounds__(B) void k_refine(KArgs a) {
-    static_assert(!COOP || (!GLOBAL_LIST && !SLOTS), "cooperating workgroups keep their slices' lists in LDS; winner refinement only");
+    constexpr bool SHARED = MODE != REFINE_SOLO;
+    static_assert(!SHARED || (!GLOBAL_LIST && !SLOTS), "cooperating workgroups keep their slices' lists in LDS; winner refinement only");
+    if (MODE == REFINE_TEAM && (blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight: placement only
     __shared__ Corr s_list[GLOBAL_LIST ? 1 : LDS_CAP];
-    __shared__ double s_part[COOP ? 256 : 28 * (B / 64)];  // block reductions; the cooperative gather uses 8 x 32
-    __shared__ double s_tot[28];
+    __shared__ double s_part[MODE == REFINE_COOP ? 256 : 28 * (B / 64)];  // block reductions; the REFINE_COOP gather uses 8 x 32
+    __shared__ double s_tot[32];
     __shared__ double s_best[B / 64];
     __shared__ int s_besti[B / 64];
     __shared__ int s_bestg[B / 64];
@@ -624,7 +705,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const Cam cam = make_cam(a);
     const PxMap pm{a.sub, a.sub / 2 - a.shift_x, a.sub / 2 - a.shift_y};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    long long g_cyc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long g_cyc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)g_cyc;
     CYC_DECL;
 #ifdef ESAC_PROFILE_CYCLES
@@ -633,20 +714,33 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     CYC_BEGIN();
     if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
     __shared__ int s_coop_dead;
-    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &s_coop_dead, false};
-    if (COOP) {
-        co.G = (int)gridDim.x;
-        co.g = (int)blockIdx.x;
+    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &s_coop_dead, false, nullptr, 0ull};
+    int cell0 = 0, Pn = P;  // this workgroup's cells: [cell0, cell0 + Pn)
+    if (SHARED) {
+        co.G = MODE == REFINE_TEAM ? (int)gridDim.x / a.team_stride : (int)gridDim.x;
+        co.g = MODE == REFINE_TEAM ? (int)blockIdx.x / a.team_stride : (int)blockIdx.x;
         co.partials = a.coop_partials;
+        co.gran = reinterpret_cast<u32x4*>(a.coop_partials);
         co.counter = a.coop_counter;
         co.failed = a.coop_counter + 1;
+        co.tag = a.coop_tag;
         co.expect = co.G + a.coop_extra;
-        co.spin_limit = a.coop_extra ? (1L << 12) : (1L << 25);  // ~seconds normally; the stall test gives up after ~0.1 ms
+        co.spin_limit = a.coop_extra ? (1L << 12) : (MODE == REFINE_TEAM ? (1L << 22) : (1L << 25));  // ~seconds normally; the stall test gives up after ~1 ms
         if (threadIdx.x == 0) s_coop_dead = 0;  // (ordered before its first use by the __syncthreads of the argmax below)
+        if (MODE == REFINE_TEAM) {
+            const int groups = P >> 2, q0 = (int)((long long)groups * co.g / co.G), q1 = (int)((long long)groups * (co.g + 1) / co.G);
+            cell0 = q0 << 2;
+            Pn = (q1 - q0) << 2;
+            // first exchange, in flight while the winner is looked up: a census of the XCDs the members run on (16^XCC_ID each)
+            int xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            team_publish<1>((double)(1ull << (4 * (xcc & 7))), co);
+        } else {
+            cell0 = co.g * a.coop_slice;
+            Pn = P - cell0 < a.coop_slice ? P - cell0 : a.coop_slice;
+        }
     }
-    const bool writer = !COOP || co.g == 0;          // the workgroup that owns the outputs
-    const int cell0 = COOP ? co.g * a.coop_slice : 0;  // this workgroup's cells: [cell0, cell0 + Pn)
-    const int Pn = COOP ? (P - cell0 < a.coop_slice ? P - cell0 : a.coop_slice) : P;
+    const bool writer = !SHARED || co.g == 0;  // the workgroup that owns the outputs
 
     // ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties
     //      (esac_util.h:512-529; softmax is monotone, so the argmax of the scores is the argmax of the probabilities)
@@ -705,6 +799,8 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     if (!SLOTS && writer)
         for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;
     __syncthreads();
+    double census[1] = {0.0};
+    if (MODE == REFINE_TEAM) team_collect<1>(census, co, s_tot);
     CYC_END(1);
 
     // ---- refineHyp (esac_util.h:378-454): one error-pass site, one re-fit site
@@ -722,15 +818,15 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         // this step's inlier set and its compacted correspondence list
         CYC_BEGIN();
         __syncthreads();  // every lane is done reading the list before it is rebuilt
-        const int n_inl = error_pass_impl<B, VEC>(a, mx, P, pose, cam, list, n_wave, maps + (size_t)cur * P, s_wcnt, g_cyc, cell0, Pn,
-                                                  COOP ? &co : nullptr, s_tot, s_part);
+        const int n_inl = error_pass_impl<B, VEC, MODE>(a, mx, P, pose, cam, list, n_wave, maps + (size_t)cur * P, s_wcnt, g_cyc, cell0, Pn,
+                                                        SHARED ? &co : nullptr, s_tot, s_part);
         __syncthreads();
         CYC_END(2);
         if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
         if (!SLOTS && writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
         if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
         best_inliers = (unsigned)n_inl;
-        lm_total += lm_refit<B>(my_list, n_wave, pose, cam, pm, s_part, s_tot, g_cyc, COOP ? &co : nullptr);
+        lm_total += lm_refit<B, MODE>(my_list, n_wave, pose, cam, pm, s_part, s_tot, g_cyc, SHARED ? &co : nullptr);
         accepted++;
         last_inliers = n_inl;
         map_buf = cur;  // inlierMap = this step's set (esac_util.h:440)
@@ -772,7 +868,18 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
         r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
         // a barrier between the cooperating workgroups timed out: the record is not to be trusted
-        const bool coop_failed = COOP && (co.dead || __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull);
+        const bool coop_failed = SHARED && (co.dead || __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag);
+        if (a.refine_info) {
+            const unsigned long long cz = (unsigned long long)census[0];
+            int same = 0;
+            for (int x = 0; x < 8; x++) same |= ((cz >> (4 * x)) & 15ull) == (unsigned long long)co.G;
+            a.refine_info[0] = MODE;
+            a.refine_info[1] = co.G;
+            a.refine_info[2] = (int)(unsigned)cz;  // hex digit x = members on XCD x
+            a.refine_info[3] = same;
+            a.refine_info[4] = (int)co.arrivals;
+            a.refine_info[5] = coop_failed ? 1 : 0;
+        }
         r[ESAC_RES_EXPERT_K] = (double)(e + a.expert_base);
         if (a.result_user) {
 #pragma unroll
@@ -793,13 +900,14 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
 #ifdef ESAC_PROFILE_CYCLES
         CYC_END(3);
         g_cyc[0] = clock64() - cyc_start;
-        for (int k = 0; k < 16; k++) a.cycles[k] = g_cyc[k];
+        for (int k = 0; k < 24; k++) a.cycles[k] = g_cyc[k];
 #endif
     }
 }
 
 // Slice of cells per cooperating workgroup (0: the refinement stays in one workgroup): grids beyond the LDS list whose
-// rows vectorise, single frames; 4096 cells (two trips of the error pass) unless that needs more than 256 workgroups.
+// rows vectorise, single frames; 8192 cells (four trips of the error pass: 2 trips measured 478 us, 1 trip 604, 4 trips 437
+// at 480x640) unless that needs more than 256 workgroups.
 int refine_coop_slice(const KArgs& a) {
     const int P = a.H * a.W;
     const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
@@ -808,12 +916,20 @@ int refine_coop_slice(const KArgs& a) {
     const int gmax = a.coop_max < ESAC_REFINE_COOP_MAX ? a.coop_max : ESAC_REFINE_COOP_MAX;
     if (P <= LDS_CAP || !vec || a.frames != 1 || !a.coop_partials || gmax < 2) return 0;
     constexpr int trip = REFINE_B * ERR_UNROLL;
-#ifndef ESAC_COOP_TRIPS
-#define ESAC_COOP_TRIPS 4  // 8192 cells per workgroup (= LDS_CAP): 2 trips measured 478 us, 1 trip 604, 4 trips 437 at 480x640
-#endif
-    int slice = ESAC_COOP_TRIPS * trip;
+    int slice = 4 * trip;
     if ((P + slice - 1) / slice > gmax) slice = ((P + gmax - 1) / gmax + trip - 1) / trip * trip;
     return slice <= LDS_CAP ? slice : 0;  // 0: the grid needs more resident workgroups than the device has -> one workgroup, global list
+}
+
+// Members of the team that refines a single frame on a grid that fits one LDS list (0: one workgroup).  All of the
+// 8 x members workgroups the launch consists of must be resident together.
+int refine_team_members(const KArgs& a) {
+    const int P = a.H * a.W;
+    const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
+    int G = a.team < TEAM_MAX ? a.team : TEAM_MAX;
+    if (G < 2 || P > LDS_CAP || P < ESAC_REFINE_TEAM_MIN_CELLS || !vec || a.frames != 1 || !a.coop_partials) return 0;
+    if (a.coop_max < G * (a.team_stride > 0 ? a.team_stride : 8)) return 0;
+    return G;
 }
 
 // Workgroups of the cooperative refinement kernel the current device can hold at once: CUs x workgroups per CU (1: the
@@ -822,12 +938,19 @@ int refine_coop_capacity() {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_refine<REFINE_B, false, true, false, true>, REFINE_B, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_refine<REFINE_B, false, true, false, REFINE_COOP>, REFINE_B, 0) != hipSuccess) return 0;
     const long long cap = (long long)cus * per_cu;
     return cap > ESAC_REFINE_COOP_MAX ? ESAC_REFINE_COOP_MAX : (int)cap;
 }
 
-void launch_refine(const KArgs& a, hipStream_t s) {
+// Every shared launch gets its own tag (process-wide launch number << 20): what its exchange granules and its failure word
+// are stamped with, so that nothing has to be cleared between launches.
+static unsigned long long next_refine_tag() {
+    static std::atomic<unsigned long long> seq{0};
+    return (seq.fetch_add(1) + 1ull) << 20;
+}
+
+unsigned long long launch_refine(const KArgs& a, hipStream_t s) {
     constexpr int B = REFINE_B;
     const bool global_list = a.H * a.W > LDS_CAP;
     // 16-byte accesses: W % 4 == 0 keeps every row, plane (P % 4 == 0) and expert map 16-byte aligned
@@ -836,10 +959,19 @@ void launch_refine(const KArgs& a, hipStream_t s) {
     if (slice > 0) {
         KArgs b = a;
         b.coop_slice = slice;
+        b.coop_tag = next_refine_tag();
         const int G = (a.H * a.W + slice - 1) / slice;
-        (void)hipMemsetAsync(a.coop_counter, 0, 2 * sizeof(unsigned long long), s);
-        hipLaunchKernelGGL((k_refine<B, false, true, false, true>), dim3(G), dim3(B), 0, s, b);
-        return;
+        (void)hipMemsetAsync(a.coop_counter, 0, sizeof(unsigned long long), s);
+        hipLaunchKernelGGL((k_refine<B, false, true, false, REFINE_COOP>), dim3(G), dim3(B), 0, s, b);
+        return b.coop_tag;
+    }
+    const int team = refine_team_members(a);
+    if (team > 0) {
+        KArgs b = a;
+        if (b.team_stride <= 0) b.team_stride = 8;
+        b.coop_tag = next_refine_tag();
+        hipLaunchKernelGGL((k_refine<B, false, true, false, REFINE_TEAM>), dim3(team * b.team_stride), dim3(B), 0, s, b);
+        return b.coop_tag;
     }
     if (global_list) {
         if (vec) hipLaunchKernelGGL((k_refine<B, true, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
@@ -848,6 +980,7 @@ void launch_refine(const KArgs& a, hipStream_t s) {
         if (vec) hipLaunchKernelGGL((k_refine<B, false, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
         else     hipLaunchKernelGGL((k_refine<B, false, false, false>), dim3(1, a.frames), dim3(B), 0, s, a);
     }
+    return 0ull;
 }
 
 // One workgroup per selection slot; slots beyond n_sel (known only on the device) return at once.

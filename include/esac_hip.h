@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESAC_HIP_ABI_VERSION 3
+#define ESAC_HIP_ABI_VERSION 4
 
 /* reference compile-time constants (esac.cpp:44-45) */
 #define ESAC_MAX_SAMPLING_TRIES 1000000
@@ -137,7 +137,13 @@ enum {
                                       inliers of the last accepted step, accepted steps, LM iterations        */
     ESAC_BUF_BWD_DLOSS = 16,       /* double[min(N,ESAC_BWD_MAX_SLOTS),6] d loss / d refined pose per slot    */
     ESAC_BUF_BWD_PATH1 = 17,       /* double[k,3,H,W] gradient slabs of the first k slots, path I (unweighted)  */
-    ESAC_BUF_BWD_PATH2 = 18        /* double[k,3,H,W] the same for path II; k = bytes / (3*H*W*8) <= #slots     */
+    ESAC_BUF_BWD_PATH2 = 18,       /* double[k,3,H,W] the same for path II; k = bytes / (3*H*W*8) <= #slots     */
+    ESAC_BUF_REFINE_INFO = 19      /* int32[8] how the most recent winner refinement ran (refineHyp, esac_util.h:378-454):
+                                      [0] 0 one workgroup, 1 cooperating workgroups (grids beyond one LDS list), 2 a team on
+                                      one XCD (small grids); [1] workgroups sharing it; [2] XCD census of a team: hex digit x =
+                                      members that ran on XCD x; [3] 1 when all members shared one XCD; [4] exchanges between
+                                      them; [5] 1 when an exchange timed out; [6] blocking calls on this context so far whose
+                                      team timed out and were refined again by one workgroup; [7] 0                          */
 };
 
 /* Hypotheses that take part in the training expectation: selection probability >= PROB_THRESH = 0.001
@@ -250,9 +256,10 @@ int esac_hip_score_exact(esac_hip_ctx* ctx, const float* d_scene_coords, const i
                          const esac_hip_params* p, void* stream);
 
 /* Waits for the device; -10 when the most recent SAMPLING launch on this context (esac_hip_forward / _batch / _sample /
- * _backward) met a hypAssignment value outside [0,E), -12 when the cooperating workgroups of its most recent large-grid
- * refinement could not synchronise (blocking calls report both themselves; asynchronous ones -- no host result pointer --
- * cannot: their device record then lacks ESAC_RES_VALID), else 0.
+ * _backward) met a hypAssignment value outside [0,E), -12 when the workgroups sharing its most recent winner refinement
+ * could not synchronise (blocking calls report the former themselves and, when a small-grid team timed out, run the
+ * refinement again in one workgroup; asynchronous ones -- no host result pointer -- cannot: their device record then
+ * lacks ESAC_RES_VALID), else 0.
  * Out-of-range values never cause an out-of-bounds read: such hypotheses are evaluated against expert 0. */
 int esac_hip_check(esac_hip_ctx* ctx);
 
@@ -286,7 +293,19 @@ int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
  * more than was launched, with a short spin limit -- exercises the "not all workgroups became resident" failure path
  * (status -12) without having to occupy the GPU. */
 #define ESAC_DEBUG_COOP_STALL 2
+/* ESAC_DEBUG_TEAM_SPREAD (tests only): the members of a refinement team are launched as CONSECUTIVE workgroups, which the
+ * hardware places on different XCDs -- the placement the team's exchange must survive (it is correct at any placement,
+ * only slower across XCDs); ESAC_BUF_REFINE_INFO[3] then reads 0. */
+#define ESAC_DEBUG_TEAM_SPREAD 4
 int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
+
+/* The winner's refinement (refineHyp, esac_util.h:378-454) on a single frame whose grid fits one workgroup's LDS list
+ * (1024 <= H*W <= 8192 cells, W % 4 == 0) is shared by a TEAM of `members` workgroups on one XCD (2..ESAC_REFINE_TEAM_MAX;
+ * default ESAC_REFINE_TEAM_DEFAULT), each owning a slice of the cells; 0 or 1: one workgroup refines, as on every other shape.
+ * Results do not depend on the setting beyond the rounding of the LM sums (every discrete output is identical). */
+#define ESAC_REFINE_TEAM_MAX 8
+#define ESAC_REFINE_TEAM_DEFAULT 8
+int esac_hip_set_refine_team(esac_hip_ctx* ctx, int members);
 
 /* How a blocking call waits for its result record (written by the last kernel into pinned host memory):
  * ESAC_WAIT_SPIN (default) polls the epoch word -- lowest latency, one host core busy for the ~0.2 ms of the call;

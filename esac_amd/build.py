@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libesac_hip.so")
-SOURCES = ["esac_kernels.hip", "esac_score_tiled.hip", "esac_refine.hip", "esac_backward.hip", "esac_capi.hip"]
+SOURCES = ["esac_kernels.hip", "esac_score_tiled.hip", "esac_refine.hip", "esac_refine_team.hip", "esac_backward.hip", "esac_capi.hip"]
 # every header under csrc/ (a new one must not be forgotten here: a stale library would be tested against new headers)
 HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join("..", "..", "include", "esac_hip.h")]
 # -ffp-contract=off: the fp64 "exact" kernels follow IEEE op-by-op like the CPU
@@ -57,5 +57,16 @@ def build_hip(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_variant(out_path, extra_flags=()):
+    """The same sources with extra compiler flags into another file (measurement scripts: ESAC_HIP_LIB=<out_path>)."""
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out_path]
+    subprocess.check_call(cmd)
+    return out_path
+
+
 if __name__ == "__main__":
-    print(build_hip(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 1:  # python esac_amd/build.py <out.so> [-DFLAG ...]
+        print(build_variant(sys.argv[1], sys.argv[2:]))
+    else:
+        print(build_hip(force=True, verbose=True))

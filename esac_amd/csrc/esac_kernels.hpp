@@ -152,6 +152,8 @@ int refine_coop_capacity();              // resident workgroups of the cooperati
 int refine_coop_slice(const KArgs& a);  // cells per cooperating refinement workgroup, 0: one workgroup refines
 int refine_team_members(const KArgs& a);  // members of the team that refines a small grid, 0: one workgroup refines
 unsigned long long launch_refine(const KArgs& a, hipStream_t s);  // returns the tag of a shared (cooperative / team) launch, 0 otherwise
+unsigned long long launch_refine_team(const KArgs& a, hipStream_t s);  // esac_refine_team.hip; requires refine_team_members(a) > 0
+unsigned long long next_refine_tag();
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);
 void launch_bwd_select(const KArgs& a, hipStream_t s);

@@ -25,183 +25,9 @@
 #include <stdlib.h>
 #include <atomic>
 
-#include "device_common.hpp"
-#include "esac_kernels.hpp"
-#include "bwd_math.hpp"
-#include "lm_math.hpp"
-#include "pose_math.hpp"
+#include "refine_common.hpp"
 
 namespace esac {
-
-// The rare branch of an LM step: the damped normal matrix is singular to rounding (lm_solve6 returned false), so the
-// step is pinv(A) * g with eigenvalues below 2 eps sum|w| dropped -- cv::solve(DECOMP_SVD) inside CvLevMarq, the
-// route the CPU library always takes (bwd_math.hpp:pinv_sym6_jacobi is the same algorithm, unrolled into registers).
-// Here it must cost the common path nothing: ONE lane runs rolled loops over matrices in LDS (run-time indices, a few
-// hundred bytes of code, no extra registers), the others wait.  Every lane reaches this together (the LM state is
-// replicated), so the barriers are uniform.  `lds`: >= 84 doubles of scratch nobody else touches meanwhile.
-__device__ __forceinline__ void lm_solve6_pinv(const double (&U21)[21], const double (&g)[6], double lambda, double (&dx)[6], double* lds) {
-    double* A = lds;        // [6][6]
-    double* V = lds + 36;   // [6][6]
-    double* out = lds + 72; // [6]
-    double* gs = lds + 78;  // [6]
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-            for (int j = i; j < 6; j++) {
-                const double v = (i == j) ? U21[k] * (1. + lambda) : U21[k];
-                A[i * 6 + j] = v;
-                A[j * 6 + i] = v;
-                k++;
-            }
-#pragma unroll
-        for (int i = 0; i < 6; i++) gs[i] = g[i];
-        for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
-        for (int sweep = 0; sweep < 60; sweep++) {
-            double off = 0;
-            for (int i = 0; i < 6; i++)
-                for (int j = i + 1; j < 6; j++) off += A[i * 6 + j] * A[i * 6 + j];
-            if (off == 0) break;
-            for (int p = 0; p < 6; p++)
-                for (int q = p + 1; q < 6; q++) {
-                    const double apq = A[p * 6 + q];
-                    const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2 * apq);
-                    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                    if (!(fabs(theta) <= 1.7976931348623157e308)) t = 0;
-                    if (apq == 0) t = 0;
-                    const double c = 1 / sqrt(t * t + 1), sn = t * c;
-                    for (int m = 0; m < 6; m++) {
-                        const double akp = A[m * 6 + p], akq = A[m * 6 + q];
-                        A[m * 6 + p] = c * akp - sn * akq;
-                        A[m * 6 + q] = sn * akp + c * akq;
-                    }
-                    for (int m = 0; m < 6; m++) {
-                        const double apk = A[p * 6 + m], aqk = A[q * 6 + m];
-                        A[p * 6 + m] = c * apk - sn * aqk;
-                        A[q * 6 + m] = sn * apk + c * aqk;
-                    }
-                    for (int m = 0; m < 6; m++) {
-                        const double vkp = V[m * 6 + p], vkq = V[m * 6 + q];
-                        V[m * 6 + p] = c * vkp - sn * vkq;
-                        V[m * 6 + q] = sn * vkp + c * vkq;
-                    }
-                }
-        }
-        double thresh = 0;
-        for (int i = 0; i < 6; i++) thresh += fabs(A[i * 7]);
-        thresh *= 2 * 2.220446049250313e-16;
-        for (int i = 0; i < 6; i++) out[i] = 0;
-        for (int m = 0; m < 6; m++) {
-            const double w = A[m * 7];
-            if (!(fabs(w) > thresh)) continue;
-            double proj = 0;
-            for (int j = 0; j < 6; j++) proj += V[j * 6 + m] * gs[j];
-            proj /= w;
-            for (int i = 0; i < 6; i++) out[i] += V[i * 6 + m] * proj;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 6; i++) dx[i] = out[i];
-    __syncthreads();
-}
-
-constexpr int REFINE_B = ESAC_REFINE_THREADS;  // 4 wavefronts = one per SIMD of the one CU this kernel occupies
-constexpr int LDS_CAP = ESAC_REFINE_LDS_CAP;   // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
-constexpr int ERR_UNROLL = ESAC_ERR_UNROLL;    // points per lane in flight in the exact error pass
-constexpr int LM_NP = 2;              // correspondences per lane in flight in an LM pass
-
-// Section cycle counters (clock64 = shader clock), enabled with -DESAC_PROFILE_CYCLES; index:
-// 0 total, 1 argmax, 2 error image + compaction, 3 pose2trans + result record, 4 rodrigues+chain, 5 point loop, 6 block_sum,
-// 7 transform, 8 solve, 9 number of passes
-#ifdef ESAC_PROFILE_CYCLES
-#define CYC_DECL long long cyc_t0_
-#define CYC_BEGIN() cyc_t0_ = clock64()
-#define CYC_END(idx) g_cyc[idx] += clock64() - cyc_t0_
-#define CYC_ADD(idx, v) g_cyc[idx] += (v)
-#else
-#define CYC_DECL
-#define CYC_BEGIN()
-#define CYC_END(idx)
-#define CYC_ADD(idx, v)
-#endif
-
-struct __attribute__((aligned(16))) Corr {
-    float x, y, z;
-    uint32_t row_col;  // grid cell of the correspondence: row << 16 | col (H, W <= 65535, checked by the C ABI); its pixel
-                       // position is col * sub + sub / 2 - shift_x (createSampling, esac_util.h:64-66), any magnitude
-};
-
-__device__ __forceinline__ int cell_pxi(const KArgs& a, int col) { return col * a.sub + a.sub / 2 - a.shift_x; }
-__device__ __forceinline__ int cell_pyi(const KArgs& a, int row) { return row * a.sub + a.sub / 2 - a.shift_y; }
-
-// 10^k, |k| <= 31, by binary exponentiation (the CPU library evaluates exp(k*log(10)))
-__device__ __forceinline__ double pow10_int(int k) {
-    double r = 1.0;
-    const int n = k < 0 ? -k : k;
-    double b = 10.0;
-#pragma unroll
-    for (int bit = 0; bit < 5; bit++) {
-        if (n & (1 << bit)) r *= b;
-        b *= b;
-    }
-    return k < 0 ? 1.0 / r : r;
-}
-
-// ---- cooperating workgroups ------------------------------------------------------------------------------------------------
-// One refinement can be shared by G workgroups: workgroup g owns a slice of the cells -- its part of every error pass and,
-// in its own LDS, the correspondences found there -- and every reduction (inlier count, the 24 moments of an LM pass)
-// becomes: workgroup sum -> exchange -> every workgroup adds the G contributions in the same fixed order.  All workgroups
-// then hold bitwise identical sums, take the same LM / stopping decisions and carry the same pose: nothing is ever
-// broadcast.  Two exchanges exist:
-//
-// REFINE_COOP (grids beyond the LDS list, 480x640: a pass is ~700 us of one CU, up to 256 workgroups anywhere on the chip):
-// partial[g] by device-scope (sc1, write-through) stores, drained; one lane arrives at a monotonic counter and polls it
-// with s_sleep; the partials are read back with device-scope loads (~3 us a round, noise against the pass).
-//
-// REFINE_TEAM (round 4; the 60x80 grid of the headline call, where a pass is 2-6 us and that barrier costs more than it
-// saves): up to 8 workgroups exchange TAGGED GRANULES in ONE hop.  A granule is 16 bytes {double v, u64 tag},
-// tag = (launch epoch << 20 | exchange number) ^ bits(v), written by one 16-byte sc1 store; every workgroup polls all
-// G x NV granules with L1-bypassing 16-byte loads (thread t -> value t >> 3 of member t & 7) until the tag fits the value,
-// then three DPP stages add the members' contributions.  No counter, no flag, no fence; a torn or stale granule fails the
-// tag test and is simply polled again.  Buffers alternate by exchange parity (a member can be at most one exchange ahead
-// of the slowest).  Measured (scripts/dev/xcd_exchange.hip, profiles/r04_xcd_exchange.txt): 0.75 us per exchange for 8
-// workgroups on one XCD, 1.4 us across 8 XCDs.  The launcher therefore starts 8 G workgroups and keeps those with
-// blockIdx.x % 8 == 0 -- observed placement: block b runs on XCD b % 8, so the members share an L2 -- but NOTHING depends
-// on that placement except speed: sc1 stores are valid hand-offs between any two CUs.  Every member reads its XCC_ID and
-// the first exchange carries a census of them into the refinement's info words.
-// Both exchanges spin with a bound; a time-out (a member never became resident: shared or partitioned GPU) marks the
-// launch as failed, every member winds down, and the host re-runs the refinement in one workgroup (blocking calls) or
-// reports -12 (esac_hip_check).
-enum : int { REFINE_SOLO = 0, REFINE_COOP = 1, REFINE_TEAM = 2 };
-constexpr int TEAM_MAX = ESAC_REFINE_TEAM_MAX_K;  // members of a team (the poll layout gives every value 8 lanes)
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-struct Coop {
-    int G, g;                      // number of cooperating workgroups, this one's index (G == 1: no cooperation)
-    double* partials;              // REFINE_COOP: [2][G][32]
-    unsigned long long* counter;   // REFINE_COOP: monotonic arrival counter, zeroed by the launcher; COOP_POISON is or-ed in on a time-out
-    unsigned long long* failed;    // the launch tag of the most recent launch in which an exchange timed out (what the host reads)
-    unsigned long long arrivals;   // exchanges passed so far (same in every thread of every workgroup)
-    int expect;                    // workgroups an exchange waits for (= G; ESAC_DEBUG_COOP_STALL: G + 1, never reached)
-    long spin_limit;               // polls before an exchange gives up
-    int* s_dead;                   // LDS flag: an exchange of this launch timed out somewhere
-    bool dead;                     // ... as every thread of the workgroup saw it after its last exchange (workgroup-uniform)
-    u32x4* gran;                   // REFINE_TEAM: [2][TEAM_MAX][32] granules
-    unsigned long long tag;        // this launch's tag: (launch number << 20); the low 20 bits count a team's exchanges
-};
-// A workgroup that gives up at the counter barrier sets this bit: every waiter (now and at every later barrier) sees its
-// target reached at once and reads the failure out of the same value -- nobody spins a second time.  (An OR: several
-// workgroups timing out together cannot wrap the counter.)
-constexpr unsigned long long COOP_POISON = 1ull << 62;
-
-__device__ __forceinline__ void coop_mark_failed(Coop& co) {
-    __hip_atomic_store(co.failed, co.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *co.s_dead = 1;
-}
 
 // One lane: arrive at the barrier and wait for the others.  On a time-out (a workgroup of this launch never became
 // resident: the GPU is shared, partitioned, or smaller than the launcher assumed) the counter is poisoned so that every
@@ -269,69 +95,6 @@ __device__ __forceinline__ void coop_allreduce(double (&v)[NV], Coop& co, double
     co.arrivals += 1ull;
 }
 
-// ---- REFINE_TEAM: the tagged-granule exchange
-__device__ __forceinline__ u32x4 gran_load(const u32x4* p) {
-    u32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void gran_store(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-
-// thread t < NV publishes `own` = this member's total of value t for the exchange that team_collect() then completes
-template <int NV>
-__device__ __forceinline__ void team_publish(double own, const Coop& co) {
-    static_assert(NV <= 32, "32 granules per member");
-    if (co.dead) return;
-    if (threadIdx.x < NV) {
-        const unsigned long long want = co.tag | (co.arrivals + 1ull);
-        const unsigned long long bits = (unsigned long long)__double_as_longlong(own), tg = want ^ bits;
-        u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
-        gran_store(buf + co.g * 32 + threadIdx.x, u32x4{(unsigned)bits, (unsigned)(bits >> 32), (unsigned)tg, (unsigned)(tg >> 32)});
-    }
-}
-// v[k] <- sum over the members of their value k, members added in one fixed (pairwise) order: bitwise identical in every
-// member.  REFINE_B = 256 threads: thread t polls value t >> 3 of member t & 7.  s_tot: >= 32 doubles nobody else touches
-// until the next workgroup barrier.
-template <int NV>
-__device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot) {
-    static_assert(NV <= 32 && REFINE_B == 32 * TEAM_MAX && TEAM_MAX == 8, "poll layout: 8 lanes per value");
-    if (co.dead) return;
-    const unsigned long long want = co.tag | (co.arrivals + 1ull);
-    const u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
-    const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
-    double val = 0.0;
-    bool timed_out = false;
-    if (j < co.expect && k < NV) {
-        const u32x4* p = buf + j * 32 + k;
-        long spins = 0;
-        for (;;) {
-            const u32x4 g = gran_load(p);
-            const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.y << 32);
-            const unsigned long long tg = (unsigned long long)g.z | ((unsigned long long)g.w << 32);
-            if ((tg ^ bits) == want) {
-                val = __longlong_as_double((long long)bits);
-                break;
-            }
-            ++spins;
-            // another member gave up (its failure word carries this launch's tag): no point in waiting out the limit
-            if (spins > co.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag)) {
-                timed_out = true;
-                break;
-            }
-        }
-    }
-    if (timed_out) coop_mark_failed(co);
-    val += dpp_move<0xB1>(val);   // members (0,1) (2,3) (4,5) (6,7)
-    val += dpp_move<0x4E>(val);   // quads
-    val += dpp_move<0x141>(val);  // all eight
-    if (j == 0 && k < NV) s_tot[k] = val;
-    barrier_lds();
-    co.dead = *co.s_dead != 0;
-#pragma unroll
-    for (int kk = 0; kk < NV; kk++) v[kk] = s_tot[kk];
-    co.arrivals += 1ull;
-}
-
 // Fused pass over the whole grid at `pose`:
 //   a.errs[i]  = min(reprojection error, maxReproj)                (getReproErrs, esac_util.h:292-360);
 //                reference-exact near tau, fp32-accurate (~1e-3 px) elsewhere -- see the screening below;
@@ -341,8 +104,6 @@ __device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* 
 // Returns the inlier count (same value in every thread).
 // Cooperative form: this workgroup handles the cells [cell0, cell0 + Pn) of the P-cell grid (cell0 a multiple of the
 // trip size); the returned count is the total over all workgroups.
-// MODE == REFINE_TEAM: the slice is a few hundred cells -- ONE group of 4 cells per lane and trip, the groups dealt to the
-// wavefronts in turn (group q -> wavefront q % 4, lane q / 4) so that all four carry the same share of the inliers.
 template <int B, bool VEC, int MODE, typename ListPtr>
 __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __restrict__ mx, int P, const double pose[6],
                                                const Cam& cam, ListPtr list, int& n_wave, uint8_t* __restrict__ map_out,
@@ -350,13 +111,10 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
                                                double* s_tot = nullptr, double* s_part = nullptr) {
     if (Pn < 0) Pn = P;
     CYC_DECL;
-    constexpr bool TEAM = MODE == REFINE_TEAM;
-    static_assert(!TEAM || VEC, "a team's slices are made of 4-cell groups");
     // VEC: every lane owns G groups of 4 CONSECUTIVE cells per trip (W % 4 == 0: a group never straddles a
     // row, planes are 16-byte aligned) -> float4 loads, one float4 + one packed-byte store per group.
     // Otherwise: U cells per lane strided by B, scalar accesses.
-    constexpr int UNROLL = TEAM ? 4 : ERR_UNROLL;
-    constexpr int G = VEC ? UNROLL / 4 : UNROLL;  // load groups per lane per trip
+    constexpr int G = VEC ? ERR_UNROLL / 4 : ERR_UNROLL;  // load groups per lane per trip
     constexpr int L = VEC ? 4 : 1;                // cells per group
     constexpr int U = G * L, NW = B / 64;
     static_assert(ERR_UNROLL % 4 == 0, "ERR_UNROLL must be a multiple of 4");
@@ -394,12 +152,8 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
         CYC_BEGIN();
 #pragma unroll
         for (int g = 0; g < G; g++) {  // all loads first: one memory latency for the U cells
-            const int i = TEAM ? start + (lane * NW + wave) * L : start + (g * B + (int)threadIdx.x) * L;
+            const int i = start + (g * B + (int)threadIdx.x) * L;
             cell[g] = i;
-            if (TEAM) {
-                row = i / a.W;
-                col = i - row * a.W;
-            }
             const int ic = full ? i : (i < cell_end ? i : cell_end - L);
             if (VEC) {
                 const float4 vx = *reinterpret_cast<const float4*>(mx + ic);
@@ -420,13 +174,11 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
                 pxf[g * L + l] = (float)cell_pxi(a, col + l);
                 pyf[g * L + l] = (float)cell_pyi(a, row);
             }
-            if (!TEAM) {
-                col += stepC;
-                row += stepR;
-                if (col >= a.W) {
-                    col -= a.W;
-                    row++;
-                }
+            col += stepC;
+            row += stepR;
+            if (col >= a.W) {
+                col -= a.W;
+                row++;
             }
         }
         CYC_END(10);
@@ -534,12 +286,7 @@ __device__ __forceinline__ int error_pass_impl(const KArgs& a, const float* __re
     n_wave = wcount < region ? wcount : region;
     if (MODE != REFINE_SOLO && co->G > 1) {  // total over the cooperating workgroups (exact in double: counts < 2^28)
         double cnt[1] = {(double)base};
-        if (TEAM) {
-            team_publish<1>(cnt[0], *co);
-            team_collect<1>(cnt, *co, s_tot);
-        } else {
-            coop_allreduce<1>(cnt, *co, s_tot, s_part);
-        }
+        coop_allreduce<1>(cnt, *co, s_tot, s_part);
         base = co->dead ? 0 : (int)cnt[0];  // dead: "no inliers" ends the refinement loop at once
     }
     CYC_END(14);
@@ -597,20 +344,16 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
     }
     CYC_END(5);
     CYC_BEGIN();
-    if (MODE == REFINE_TEAM) {
-        // wavefront totals -> LDS -> this member's totals (threads < 24) -> granules -> every member adds all members'
-        wave_totals28_to_lds<LM_NMOM>(mom, s_part);
-        team_publish<LM_NMOM>(workgroup_total28<B>(s_part), *co);
-        team_collect<LM_NMOM>(mom, *co, s_tot);
-    } else {
-        block_sum28<LM_NMOM, B>(mom, s_part, s_tot);
-        if (MODE == REFINE_COOP) coop_allreduce<LM_NMOM>(mom, *co, s_tot, s_part);
-    }
+    block_sum28<LM_NMOM, B>(mom, s_part, s_tot);
+    if (MODE == REFINE_COOP) coop_allreduce<LM_NMOM>(mom, *co, s_tot, s_part);
     CYC_END(6);
     CYC_BEGIN();
+    CYC_PIN(mom, LM_NMOM);
     double acc[LM_NACC];
     lm_moments_to_acc(mom, cam.fx, acc);
     lm_transform(acc, ch, U21, g6);
+    CYC_PIN(U21, 21);
+    CYC_PIN(g6, 6);
     CYC_END(7);
     CYC_ADD(9, 1);
     return acc[26];
@@ -636,6 +379,8 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
         // residual norm and (speculatively) the normal equations at `param`
         const double err_norm = sqrt(lm_pass<B, MODE>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc, co));
         if (co && co->dead) break;  // a barrier timed out: the sums are garbage, the call reports -12
+        CYC_BEGIN();
+        CYC_PIN(g6t, 6);
         bool accept;
         if (!have_base) {
             have_base = true;  // iters == 0: prevErrNorm = |err(initial pose)|
@@ -665,10 +410,14 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
                 prev[k] = param[k];
             }
         }
+        CYC_PIN(g6, 6);
+        CYC_PIN(prev, 6);
+        CYC_END(16);
         // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
         double dx[6];
         CYC_BEGIN();
         if (!lm_solve6(U21, g6, pow10_int(lambda_lg10), dx)) lm_solve6_pinv(U21, g6, pow10_int(lambda_lg10), dx, s_part);
+        CYC_PIN(dx, 6);
         CYC_END(8);
 #pragma unroll
         for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
@@ -682,16 +431,15 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
 // VEC: 16-byte accesses in the error pass (W % 4 == 0 and a 16-byte aligned coordinate tensor).
 // SLOTS: training path -- workgroup b refines the hypothesis of selection slot b (esac.cpp:328-347) and leaves
 // its refined pose and inlier maps in the BwdArgs buffers instead of picking the winner and writing the record.
-// MODE: REFINE_SOLO one workgroup per refinement; REFINE_COOP / REFINE_TEAM several workgroups share one (see struct
-// Coop): workgroup g owns a slice of the cells, its correspondences live in its own LDS list (GLOBAL_LIST must be false: a
-// slice never exceeds LDS_CAP cells), workgroup 0 writes the outputs.  REFINE_COOP: gridDim.x workgroups, slices of
-// a.coop_slice cells.  REFINE_TEAM: the members are the workgroups blockIdx.x % a.team_stride == 0, equal slices of 4-cell
-// groups.
+// MODE: REFINE_SOLO one workgroup per refinement; REFINE_COOP: gridDim.x workgroups share one (refine_common.hpp, struct
+// Coop): workgroup g owns a.coop_slice cells, its correspondences live in its own LDS list (GLOBAL_LIST must be false: a
+// slice never exceeds LDS_CAP cells), workgroup 0 writes the outputs.  (REFINE_TEAM, the shared refinement of the small
+// grids, is a kernel of its own: esac_refine_team.hip.)
 template <int B, bool GLOBAL_LIST, bool VEC, bool SLOTS, int MODE = REFINE_SOLO>
 __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     constexpr bool SHARED = MODE != REFINE_SOLO;
     static_assert(!SHARED || (!GLOBAL_LIST && !SLOTS), "cooperating workgroups keep their slices' lists in LDS; winner refinement only");
-    if (MODE == REFINE_TEAM && (blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight: placement only
+    static_assert(MODE == REFINE_SOLO || MODE == REFINE_COOP, "esac_refine_team.hip holds the team kernel");
     __shared__ Corr s_list[GLOBAL_LIST ? 1 : LDS_CAP];
     __shared__ double s_part[MODE == REFINE_COOP ? 256 : 28 * (B / 64)];  // block reductions; the REFINE_COOP gather uses 8 x 32
     __shared__ double s_tot[32];
@@ -717,78 +465,16 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &s_coop_dead, false, nullptr, 0ull};
     int cell0 = 0, Pn = P;  // this workgroup's cells: [cell0, cell0 + Pn)
     if (SHARED) {
-        co.G = MODE == REFINE_TEAM ? (int)gridDim.x / a.team_stride : (int)gridDim.x;
-        co.g = MODE == REFINE_TEAM ? (int)blockIdx.x / a.team_stride : (int)blockIdx.x;
-        co.partials = a.coop_partials;
-        co.gran = reinterpret_cast<u32x4*>(a.coop_partials);
-        co.counter = a.coop_counter;
-        co.failed = a.coop_counter + 1;
-        co.tag = a.coop_tag;
-        co.expect = co.G + a.coop_extra;
-        co.spin_limit = a.coop_extra ? (1L << 12) : (MODE == REFINE_TEAM ? (1L << 22) : (1L << 25));  // ~seconds normally; the stall test gives up after ~1 ms
-        if (threadIdx.x == 0) s_coop_dead = 0;  // (ordered before its first use by the __syncthreads of the argmax below)
-        if (MODE == REFINE_TEAM) {
-            const int groups = P >> 2, q0 = (int)((long long)groups * co.g / co.G), q1 = (int)((long long)groups * (co.g + 1) / co.G);
-            cell0 = q0 << 2;
-            Pn = (q1 - q0) << 2;
-            // first exchange, in flight while the winner is looked up: a census of the XCDs the members run on (16^XCC_ID each)
-            int xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            team_publish<1>((double)(1ull << (4 * (xcc & 7))), co);
-        } else {
-            cell0 = co.g * a.coop_slice;
-            Pn = P - cell0 < a.coop_slice ? P - cell0 : a.coop_slice;
-        }
+        coop_init(co, a, (int)gridDim.x, (int)blockIdx.x, 1L << 25);
+        cell0 = co.g * a.coop_slice;
+        Pn = P - cell0 < a.coop_slice ? P - cell0 : a.coop_slice;
     }
     const bool writer = !SHARED || co.g == 0;  // the workgroup that owns the outputs
 
     // ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties
-    //      (esac_util.h:512-529; softmax is monotone, so the argmax of the scores is the argmax of the probabilities)
     const int nc = SLOTS ? 0 : a.n_contenders[0];
-    double bs = -INFINITY;
-    int bi = 0x7fffffff, bg = 0x7fffffff;
-    for (int h = threadIdx.x; h < (SLOTS ? 0 : a.N); h += B) {
-        if (!a.exact_flag[h]) continue;  // contenders = the hypotheses that were re-scored exactly
-        const int g = global_hyp(a, h);
-        const double s = a.scores[h];
-        if (s > bs || (s == bs && g < bg)) {
-            bs = s;
-            bi = h;
-            bg = g;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double os = __shfl_xor(bs, o);
-        const int oi = __shfl_xor(bi, o);
-        const int og = __shfl_xor(bg, o);
-        if (os > bs || (os == bs && og < bg)) {
-            bs = os;
-            bi = oi;
-            bg = og;
-        }
-    }
-    if (lane == 0) {
-        s_best[wave] = bs;
-        s_besti[wave] = bi;
-        s_bestg[wave] = bg;
-    }
-    __syncthreads();
-    bs = s_best[0];
-    bi = s_besti[0];
-    bg = s_bestg[0];
-#pragma unroll
-    for (int w = 1; w < B / 64; w++) {
-        const double os = s_best[w];
-        const int oi = s_besti[w];
-        const int og = s_bestg[w];
-        if (os > bs || (os == bs && og < bg)) {
-            bs = os;
-            bi = oi;
-            bg = og;
-        }
-    }
-    const int win = SLOTS ? a.bwd.sel[blockIdx.x] : (bi == 0x7fffffff) ? 0 : bi;
+    const int picked = SLOTS ? 0 : refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
+    const int win = SLOTS ? a.bwd.sel[blockIdx.x] : picked;
     const double win_score = a.scores[win];
     const int e = expert_of(a, win);
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
@@ -799,8 +485,6 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     if (!SLOTS && writer)
         for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;
     __syncthreads();
-    double census[1] = {0.0};
-    if (MODE == REFINE_TEAM) team_collect<1>(census, co, s_tot);
     CYC_END(1);
 
     // ---- refineHyp (esac_util.h:378-454): one error-pass site, one re-fit site
@@ -848,55 +532,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     // ---- pose2trans (esac_util.h:537-548) and the result record
     CYC_BEGIN();
     if (threadIdx.x == 0 && writer) {
-        double R[9];
-        rodrigues_vec2mat<false>(pose, R, nullptr);
-        double T[16];
-        pose_to_inverse_transform(R, pose + 3, T);
-        double* r = a.result;
-        r[ESAC_RES_SCORE_K] = win_score;
-        r[ESAC_RES_HYP_K] = (double)global_hyp(a, win);
-#pragma unroll
-        for (int k = 0; k < 6; k++) r[ESAC_RES_RVEC_K + k] = pose[k];
-#pragma unroll
-        for (int k = 0; k < 16; k++) r[ESAC_RES_POSE_K + k] = (double)(float)T[k];
-        r[ESAC_RES_REF_STEPS_K] = (double)accepted;
-        r[ESAC_RES_INLIERS_K] = (double)last_inliers;
-        const double smax = a.stats[0], ssum = a.stats[1];
-        r[ESAC_RES_PROB_K] = exp(win_score - smax) / ssum;
-        r[ESAC_RES_ENTROPY_K] = a.stats[2];
-        r[ESAC_RES_CONTENDERS_K] = (double)nc;
-        r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
-        r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
-        // a barrier between the cooperating workgroups timed out: the record is not to be trusted
-        const bool coop_failed = SHARED && (co.dead || __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag);
-        if (a.refine_info) {
-            const unsigned long long cz = (unsigned long long)census[0];
-            int same = 0;
-            for (int x = 0; x < 8; x++) same |= ((cz >> (4 * x)) & 15ull) == (unsigned long long)co.G;
-            a.refine_info[0] = MODE;
-            a.refine_info[1] = co.G;
-            a.refine_info[2] = (int)(unsigned)cz;  // hex digit x = members on XCD x
-            a.refine_info[3] = same;
-            a.refine_info[4] = (int)co.arrivals;
-            a.refine_info[5] = coop_failed ? 1 : 0;
-        }
-        r[ESAC_RES_EXPERT_K] = (double)(e + a.expert_base);
-        if (a.result_user) {
-#pragma unroll
-            for (int k = 0; k < 31; k++) a.result_user[k] = r[k];
-            // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" from a record; never set on a failed one
-            a.result_user[31] = coop_failed ? 0.0 : 1.0;
-        }
-        if (a.result_pin) {
-            // straight into pinned host memory: the host polls the epoch word instead of waiting for a
-            // copy kernel + stream-completion signal (saves ~15-20 us of the blocking call's latency)
-#pragma unroll
-            for (int k = 0; k < 32; k++) a.result_pin[k] = r[k];
-            a.result_pin[33] = (a.status[0] == (unsigned long long)a.sample_epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment seen by k_sample
-            if (coop_failed) a.result_pin[33] = 3.0;
-            __threadfence_system();
-            *reinterpret_cast<volatile double*>(a.result_pin + 32) = a.epoch;
-        }
+        refine_write_record(a, pose, win, win_score, e, nc, accepted, last_inliers, lm_total, map_buf, MODE, co, 0ull);
 #ifdef ESAC_PROFILE_CYCLES
         CYC_END(3);
         g_cyc[0] = clock64() - cyc_start;
@@ -921,17 +557,6 @@ int refine_coop_slice(const KArgs& a) {
     return slice <= LDS_CAP ? slice : 0;  // 0: the grid needs more resident workgroups than the device has -> one workgroup, global list
 }
 
-// Members of the team that refines a single frame on a grid that fits one LDS list (0: one workgroup).  All of the
-// 8 x members workgroups the launch consists of must be resident together.
-int refine_team_members(const KArgs& a) {
-    const int P = a.H * a.W;
-    const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
-    int G = a.team < TEAM_MAX ? a.team : TEAM_MAX;
-    if (G < 2 || P > LDS_CAP || P < ESAC_REFINE_TEAM_MIN_CELLS || !vec || a.frames != 1 || !a.coop_partials) return 0;
-    if (a.coop_max < G * (a.team_stride > 0 ? a.team_stride : 8)) return 0;
-    return G;
-}
-
 // Workgroups of the cooperative refinement kernel the current device can hold at once: CUs x workgroups per CU (1: the
 // kernel's 128 KiB correspondence list fills a CU's LDS).  0 when the occupancy query fails.
 int refine_coop_capacity() {
@@ -945,7 +570,7 @@ int refine_coop_capacity() {
 
 // Every shared launch gets its own tag (process-wide launch number << 20): what its exchange granules and its failure word
 // are stamped with, so that nothing has to be cleared between launches.
-static unsigned long long next_refine_tag() {
+unsigned long long next_refine_tag() {
     static std::atomic<unsigned long long> seq{0};
     return (seq.fetch_add(1) + 1ull) << 20;
 }
@@ -965,14 +590,7 @@ unsigned long long launch_refine(const KArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_refine<B, false, true, false, REFINE_COOP>), dim3(G), dim3(B), 0, s, b);
         return b.coop_tag;
     }
-    const int team = refine_team_members(a);
-    if (team > 0) {
-        KArgs b = a;
-        if (b.team_stride <= 0) b.team_stride = 8;
-        b.coop_tag = next_refine_tag();
-        hipLaunchKernelGGL((k_refine<B, false, true, false, REFINE_TEAM>), dim3(team * b.team_stride), dim3(B), 0, s, b);
-        return b.coop_tag;
-    }
+    if (refine_team_members(a) > 0) return launch_refine_team(a, s);
     if (global_list) {
         if (vec) hipLaunchKernelGGL((k_refine<B, true, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
         else     hipLaunchKernelGGL((k_refine<B, true, false, false>), dim3(1, a.frames), dim3(B), 0, s, a);

@@ -1,0 +1,370 @@
+// esac_refine_team.hip -- draw(argmax) + refineHyp + pose2trans of ONE frame on a grid of a few thousand cells, shared by a
+// TEAM of up to 8 workgroups on one XCD (round 4).
+//
+// Reference: refineHyp esac_util.h:378-454 (the loop), cv::solvePnP(SOLVEPNP_ITERATIVE, useExtrinsicGuess) reached from
+// esac_util.h:426-436 (the re-fit: CvLevMarq, 6 parameters, max_iter 20, eps FLT_EPSILON), draw esac_util.h:505-530,
+// pose2trans esac_util.h:537-548.  esac_refine.hip holds the same refinement for one workgroup (and for cooperating
+// workgroups on grids beyond one LDS list); this file is the latency shape of the headline call: a 60x80 grid, where one
+// workgroup spends 150 us on ~33 dependent passes of 2-6 us each.
+//
+// What is different here:
+//   * CELLS LIVE IN REGISTERS.  Member g of G owns the cells [g P / G, (g+1) P / G); with G = 8 that is <= 1024 cells, at
+//     most 4 per lane (600 at 60x80: 3 per lane), loaded once.  No correspondence list, no compaction, no LDS but the
+//     reduction scratch: an inlier set is a bit mask per lane.
+//   * ONE KIND OF PASS at a pose: the fp64 projection chain of every owned cell (lm_math.hpp: the LM chain, contraction and
+//     Newton reciprocal allowed), from it (a) the squared residual over the set the running re-fit works on, (b) `err < tau`
+//     for EVERY cell -- decided by the fp64 error against tau +- a band that covers what the reference's float rounding
+//     can do, the bit-exact project_exact_err sequence for what is left (practically never) -- i.e. the NEXT inlier set,
+//     its count and its squared residual, (c) the 24 moments of the normal equations over the running set or over the
+//     next one.  27 sums per pass.
+//   * FUSED ROUNDS.  The reference evaluates the error image at a pose, then starts the re-fit with a pass at the SAME
+//     pose; and it ends a re-fit with a pass at the pose whose error image it evaluates next.  Whether an LM trial, if
+//     accepted, ends the re-fit (iteration 20, or relative step < FLT_EPSILON) is known BEFORE the trial is evaluated
+//     (it depends on the step, not on the residual), so such a trial is evaluated as a full pass with the moments over
+//     the next set: accepted -- the common case -- it IS the next step's error image and first LM pass.  Rejected, the
+//     re-fit goes on with a larger lambda from the normal equations it already holds; nothing was overwritten (the sets
+//     are register masks).  ~24 rounds per frame instead of ~33, same accepted points, same decisions.
+//   * ONE HOP PER ROUND between the members: refine_common.hpp, tagged granules.  The chain-rule matrices of the pose are
+//     computed while the exchange is in flight.
+// All members carry the same pose and take the same decisions from bitwise identical sums; member 0 writes the outputs,
+// every member writes its cells of the inlier map once, at the end.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "refine_common.hpp"
+
+namespace esac {
+
+constexpr int TEAM_CPL_MAX = 4;   // cells per lane a member can hold: slices of up to 1024 cells
+constexpr int TEAM_NSUM = 27;     // 24 moments | residual^2 over the running set | residual^2 over the next set | size of the next set
+constexpr int TEAM_LDS_PAD = 96 * 1024;  // LDS nobody touches: one member per CU (two would share its SIMDs)
+
+template <int CPL>
+struct TeamCells {
+    double X[CPL], Y[CPL], Z[CPL], px[CPL], py[CPL];  // scene point and pixel position (float inputs, exact in double)
+    int cell[CPL];                                     // grid cell, -1: none (ragged end of the slice)
+};
+
+// the decision band of `err < tau` on the fp64 squared error (see error_pass_impl in esac_refine.hip, second screen): the
+// reference rounds the projection to float before taking the difference, so its error differs from the fp64 value by
+// at most ~sqrt(2)/2 ulp of the pixel coordinate (+1e-6); 3.5x of head-room on that.
+struct TauBand {
+    double lo2, hi2;   // e2 < lo2: inlier for certain; e2 > hi2: outlier for certain
+    float tau, tau_below, max_reproj;
+    bool all_in;       // maxReproj < tau: every clamped error is below tau (esac_util.h:358 then :404)
+};
+__device__ __forceinline__ TauBand make_band(const KArgs& a) {
+    const double band2 = 2.4e-7 * ((double)(a.W > a.H ? a.W : a.H) * a.sub + abs(a.shift_x) + abs(a.shift_y) + (double)a.tau) + 2e-6;
+    const double tlo = (double)a.tau - band2, thi = (double)a.tau + band2;
+    return TauBand{tlo > 0 ? tlo * tlo : -1.0, thi * thi, a.tau, nextafterf(a.tau, -INFINITY), a.max_reproj, a.max_reproj < a.tau};
+}
+
+// One pass at `param` (see the header).  in: run_set = the set the re-fit works on, use_next = moments over the next set
+// instead.  out: next_set, sums (totals over the team, identical in every thread of every member), ch = chain-rule
+// matrices at param.
+template <int CPL>
+__device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& cl, const double (&param)[6], const Cam& cam, const TauBand& band,
+                                          unsigned run_set, bool use_next, unsigned& next_set, double (&sums)[TEAM_NSUM], LmChain& ch,
+                                          Coop& co, double* s_part, double* s_tot, long long* g_cyc) {
+    CYC_DECL;
+    CYC_BEGIN();
+    double R[9];
+    LmTrig tg;
+    lm_pose_rotation(param, R, tg);
+    CYC_END(4);
+    CYC_BEGIN();
+    bool on[CPL];
+#pragma unroll
+    for (int p = 0; p < CPL; p++) on[p] = cl.cell[p] >= 0;
+    LmTerms<CPL> q;  // x, y, 1/z, residual of every owned cell (all zero for a missing one)
+    lm_point_terms<CPL>(R, param + 3, cam, cl.X, cl.Y, cl.Z, cl.px, cl.py, on, q);
+    // (b) the next inlier set
+    unsigned nset = 0;
+    double e2[CPL];
+    bool undecided[CPL];
+    bool any_undecided = false;
+#pragma unroll
+    for (int p = 0; p < CPL; p++) {
+        e2[p] = __builtin_fma(q.ex[p], q.ex[p], q.ey[p] * q.ey[p]);
+        const bool in2 = e2[p] < band.lo2, out2 = e2[p] > band.hi2;  // NaN: neither
+        undecided[p] = on[p] && !band.all_in && !(in2 || out2);
+        any_undecided |= undecided[p];
+        if (on[p] && (in2 || band.all_in)) nset |= 1u << p;
+    }
+    if (__any(any_undecided)) {  // the reference's own sequence, op by op (rodrigues as cv::Rodrigues, contraction off)
+        double Rx[9];
+        rodrigues_vec2mat<false>(param, Rx, nullptr);
+#pragma unroll
+        for (int p = 0; p < CPL; p++) {
+            if (!__any(undecided[p])) continue;
+            float err = project_exact_err(Rx, param + 3, cam, (float)cl.X[p], (float)cl.Y[p], (float)cl.Z[p], (float)cl.px[p], (float)cl.py[p]);
+            err = err < band.max_reproj ? err : band.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+            if (undecided[p] && err < band.tau) nset |= 1u << p;
+        }
+    }
+    next_set = nset;
+    if (a.errs && use_next) {  // debug option (esac_hip_set_debug): the error image of the pose; nothing downstream reads it
+#pragma unroll
+        for (int p = 0; p < CPL; p++) {
+            if (!on[p]) continue;
+            float err = (float)sqrt(e2[p]);
+            if (!band.all_in) err = (nset >> p) & 1u ? fminf(err, band.tau_below) : fmaxf(err, band.tau);  // the fp32 value on the decided side
+            if (undecided[p]) {
+                double Rx[9];
+                rodrigues_vec2mat<false>(param, Rx, nullptr);
+                err = project_exact_err(Rx, param + 3, cam, (float)cl.X[p], (float)cl.Y[p], (float)cl.Z[p], (float)cl.px[p], (float)cl.py[p]);
+            }
+            a.errs[cl.cell[p]] = err < band.max_reproj ? err : band.max_reproj;
+        }
+    }
+    // (a), (c): 0/1 weights the optimiser cannot see through (one basic block, no chain sunk under a branch)
+#pragma unroll
+    for (int k = 0; k < TEAM_NSUM; k++) sums[k] = 0;
+    LmTerms<CPL> m;
+#pragma unroll
+    for (int p = 0; p < CPL; p++) {
+        double w_run = (run_set >> p) & 1u ? 1.0 : 0.0, w_next = (nset >> p) & 1u ? 1.0 : 0.0;
+        asm volatile("" : "+v"(w_run), "+v"(w_next));
+        const double w = use_next ? w_next : w_run;
+        m.x[p] = q.x[p] * w;
+        m.y[p] = q.y[p] * w;
+        m.iz[p] = q.iz[p] * w;
+        m.ex[p] = q.ex[p] * w;
+        m.ey[p] = q.ey[p] * w;
+        m.w[p] = w;
+        sums[24] = __builtin_fma(w_run, e2[p], sums[24]);
+        sums[25] = __builtin_fma(w_next, e2[p], sums[25]);
+        sums[26] += w_next;
+    }
+    lm_accumulate_moments<CPL>(m, sums);
+    CYC_END(5);
+    CYC_BEGIN();
+    // wavefront totals -> LDS -> this member's totals (threads < 27) -> granules -> every member adds all members'
+    wave_totals28_to_lds<TEAM_NSUM>(sums, s_part);
+    team_publish<TEAM_NSUM>(workgroup_total28<REFINE_B>(s_part), co);
+    lm_pose_chain_rest(tg, param + 3, ch);  // while the exchange is in flight
+    team_collect<TEAM_NSUM>(sums, co, s_tot);
+    CYC_END(6);
+    CYC_ADD(9, 1);
+}
+
+// normal equations in (rvec, tvec) space from the moments of a pass at the pose `ch` belongs to
+__device__ __forceinline__ void team_normal_equations(const double (&sums)[TEAM_NSUM], const Cam& cam, const LmChain& ch, double (&U21)[21],
+                                                      double (&g6)[6], long long* g_cyc) {
+    CYC_DECL;
+    CYC_BEGIN();
+    double acc[LM_NACC];
+    lm_moments_to_acc(sums, cam.fx, acc);
+    lm_transform(acc, ch, U21, g6);
+    CYC_PIN(U21, 21);
+    CYC_PIN(g6, 6);
+    CYC_END(7);
+}
+
+// step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
+__device__ __forceinline__ void team_step(const double (&U21)[21], const double (&g6)[6], int lambda_lg10, const double (&prev)[6], double (&param)[6],
+                                          double* s_part, long long* g_cyc) {
+    CYC_DECL;
+    CYC_BEGIN();
+    double dx[6];
+    if (!lm_solve6(U21, g6, pow10_int(lambda_lg10), dx)) lm_solve6_pinv(U21, g6, pow10_int(lambda_lg10), dx, s_part);
+#pragma unroll
+    for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
+    CYC_PIN(param, 6);
+    CYC_END(8);
+}
+
+template <int CPL>
+__global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
+    constexpr int B = REFINE_B;
+    if ((blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
+    __shared__ double s_part[28 * (B / 64) > 84 ? 28 * (B / 64) : 84];  // block reductions; scratch of the pseudo-inverse step
+    __shared__ double s_tot[32];
+    __shared__ double s_best[B / 64];
+    __shared__ int s_besti[B / 64];
+    __shared__ int s_bestg[B / 64];
+    __shared__ int s_coop_dead;
+    __shared__ char s_pad[TEAM_LDS_PAD];
+    if (a.team_stride < 0) s_pad[threadIdx.x] = 1;  // (never: keeps the allocation)
+    const int P = a.H * a.W;
+    const Cam cam = make_cam(a);
+    long long g_cyc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)g_cyc;
+    CYC_DECL;
+#ifdef ESAC_PROFILE_CYCLES
+    const long long cyc_start = clock64();
+#endif
+    CYC_BEGIN();
+    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &s_coop_dead, false, nullptr, 0ull};
+    coop_init(co, a, (int)gridDim.x / a.team_stride, (int)blockIdx.x / a.team_stride, 1L << 22);
+    co.expect = co.G;
+    if (a.coop_extra && co.g == co.G - 1) return;  // ESAC_DEBUG_COOP_STALL: the last member never shows up
+    // first exchange, in flight while the winner is looked up: a census of the XCDs the members run on (16^XCC_ID each)
+    {
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        team_publish<1>((double)(1ull << (4 * (xcc & 7))), co);
+    }
+    const bool writer = co.g == 0;
+    if (writer)
+        for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;  // (drained by the barrier of the winner pick)
+    const int cell0 = (int)((long long)P * co.g / co.G), cell1 = (int)((long long)P * (co.g + 1) / co.G);
+
+    const int nc = a.n_contenders[0];
+    const int win = refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
+    const double win_score = a.scores[win];
+    const int e = expert_of(a, win);
+    const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
+    double pose[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
+    // this lane's cells
+    TeamCells<CPL> cl;
+#pragma unroll
+    for (int p = 0; p < CPL; p++) {
+        const int i = cell0 + p * B + (int)threadIdx.x;
+        const bool have = i < cell1;
+        const int ic = have ? i : cell0;
+        cl.cell[p] = have ? i : -1;
+        const int row = ic / a.W, col = ic - row * a.W;
+        cl.X[p] = have ? (double)mx[ic] : 0.0;
+        cl.Y[p] = have ? (double)mx[P + ic] : 0.0;
+        cl.Z[p] = have ? (double)mx[2 * P + ic] : 0.0;
+        cl.px[p] = (double)(float)cell_pxi(a, col);  // Point2f of the integer pixel centre (esac_util.h:64-66, :180)
+        cl.py[p] = (double)(float)cell_pyi(a, row);
+    }
+    double census[1] = {0.0};
+    team_collect<1>(census, co, s_tot);
+    CYC_END(1);
+
+    // ---- refineHyp (esac_util.h:378-454) around ONE pass site
+    const TauBand band = make_band(a);
+    double sums[TEAM_NSUM];
+    LmChain ch;
+    unsigned run_set = 0, next_set = 0, acc_set = 0;  // sets as bit masks over this lane's cells: the running re-fit's, the one the last
+                                                      // full pass found, the last ACCEPTED step's (inlierMap, esac_util.h:440)
+    double param[6], prev[6], U21[21], g6[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) param[k] = prev[k] = pose[k];
+    int accepted = 0, last_inliers = 0, lm_total = 0, rstep = 0;
+    unsigned best_inliers = 4;
+    // LM state: lambda = 10^lambda_lg10, iterations of the running re-fit, |err| at `prev`
+    int lambda_lg10 = -3, iters = 0;
+    double prev_err_norm = 0;
+    bool in_refit = false;  // false: the next pass is the error image at `pose` (= param) with the first LM pass of its set
+    for (;;) {
+        // Does this trial, if accepted, end the re-fit?  (CvLevMarq: ++iters >= max_iter, or the relative step
+        // cvNorm(param, prevParam, CV_RELATIVE_L2) < eps)  -- a function of the step alone.
+        bool ends_refit = true;
+        if (in_refit) {
+            double dn = 0, pn = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                dn += (param[k] - prev[k]) * (param[k] - prev[k]);
+                pn += prev[k] * prev[k];
+            }
+            const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
+            ends_refit = iters + 1 >= 20 || rel < (double)FLT_EPSILON;
+        }
+        team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, ch, co, s_part, s_tot, g_cyc);
+        if (co.dead) break;  // an exchange timed out: the sums are garbage, the call reports it
+        CYC_BEGIN();
+        if (in_refit) {
+            const double err_norm = sqrt(sums[24]);
+            if (err_norm > prev_err_norm && ++lambda_lg10 <= 16) {  // state CHECK_ERR failed: retry from `prev` with a larger lambda
+                CYC_END(16);
+                team_step(U21, g6, lambda_lg10, prev, param, s_part, g_cyc);
+                continue;
+            }
+            lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
+            ++iters;
+            if (!ends_refit) {  // state CALC_J at the accepted point
+                prev_err_norm = err_norm;
+#pragma unroll
+                for (int k = 0; k < 6; k++) prev[k] = param[k];
+                CYC_END(16);
+                team_normal_equations(sums, cam, ch, U21, g6, g_cyc);
+                team_step(U21, g6, lambda_lg10, prev, param, s_part, g_cyc);
+                continue;
+            }
+            // the re-fit is done: its last trial is the refined pose, and this pass was its error image
+            lm_total += iters;
+            accepted++;
+            last_inliers = (int)best_inliers;
+            acc_set = run_set;
+            in_refit = false;
+            rstep++;
+        }
+        // error image at `param` (reproErrs, esac.cpp:169 / esac_util.h:445-452): next_set, its size, its normal equations
+        if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
+        const int n_inl = (int)sums[26];
+        if (writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
+        if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
+        best_inliers = (unsigned)n_inl;
+        // the re-fit over next_set starts from `param`: this pass already was its first one (iters == 0: prevErrNorm = |err(initial pose)|)
+        run_set = next_set;
+        in_refit = true;
+        lambda_lg10 = -3;
+        iters = 0;
+        prev_err_norm = sqrt(sums[25]);
+#pragma unroll
+        for (int k = 0; k < 6; k++) prev[k] = param[k];
+        CYC_END(16);
+        team_normal_equations(sums, cam, ch, U21, g6, g_cyc);
+        team_step(U21, g6, lambda_lg10, prev, param, s_part, g_cyc);
+    }
+    // the refined pose: the last accepted re-fit's (esac_util.h:439); a pass that ended the loop was evaluated AT it
+    // (or at the initial pose when no re-fit was accepted)
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose[k] = in_refit ? prev[k] : param[k];  // in_refit here only after a time-out
+
+    // inlierMap of the last accepted step (esac_util.h:440), every member its cells; buffer 0 (result[31] names it)
+    if (accepted > 0) {
+#pragma unroll
+        for (int p = 0; p < CPL; p++)
+            if (cl.cell[p] >= 0) a.inlier_map[cl.cell[p]] = (uint8_t)((acc_set >> p) & 1u);
+    }
+    CYC_BEGIN();
+    if (threadIdx.x == 0 && writer) {
+        refine_write_record(a, pose, win, win_score, e, nc, accepted, last_inliers, lm_total, accepted > 0 ? 0 : -1, REFINE_TEAM, co,
+                            (unsigned long long)census[0]);
+#ifdef ESAC_PROFILE_CYCLES
+        CYC_END(3);
+        g_cyc[0] = clock64() - cyc_start;
+        for (int k = 0; k < 24; k++) a.cycles[k] = g_cyc[k];
+#endif
+    }
+}
+
+// Members of the team that refines a single frame (0: one workgroup refines): grids of 1024 .. 8192 cells, as many members
+// as were asked for but at least so many that a member's slice fits its lanes' registers (1024 cells); the device must
+// hold the whole launch at once.
+int refine_team_members(const KArgs& a) {
+    const int P = a.H * a.W;
+    int G = a.team < TEAM_MAX ? a.team : TEAM_MAX;
+    if (G < 2 || P > TEAM_MAX * TEAM_CPL_MAX * REFINE_B || P < ESAC_REFINE_TEAM_MIN_CELLS || a.frames != 1 || !a.coop_partials) return 0;
+    const int need = (P + TEAM_CPL_MAX * REFINE_B - 1) / (TEAM_CPL_MAX * REFINE_B);
+    if (G < need) G = need;
+    if (a.coop_max < G * (a.team_stride > 0 ? a.team_stride : 8)) return 0;
+    return G;
+}
+
+unsigned long long launch_refine_team(const KArgs& a, hipStream_t s) {
+    const int G = refine_team_members(a);
+    KArgs b = a;
+    if (b.team_stride <= 0) b.team_stride = 8;
+    b.coop_tag = next_refine_tag();
+    const int P = a.H * a.W;
+    const int slice = (P + G - 1) / G;  // the largest member slice: floor((g+1) P / G) - floor(g P / G) <= ceil(P / G)
+    const int cpl = (slice + REFINE_B - 1) / REFINE_B;
+    const dim3 grid(G * b.team_stride), block(REFINE_B);
+    switch (cpl) {
+        case 1: hipLaunchKernelGGL((k_refine_team<1>), grid, block, 0, s, b); break;
+        case 2: hipLaunchKernelGGL((k_refine_team<2>), grid, block, 0, s, b); break;
+        case 3: hipLaunchKernelGGL((k_refine_team<3>), grid, block, 0, s, b); break;
+        default: hipLaunchKernelGGL((k_refine_team<4>), grid, block, 0, s, b); break;
+    }
+    return b.coop_tag;
+}
+
+}  // namespace esac

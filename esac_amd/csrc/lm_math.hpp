@@ -239,52 +239,83 @@ ESAC_HD void lm_chain(const double R[9], const double dRdr[27], const double t[3
 // LEFT Jacobian of SO(3),   J_l(r) = (s/th) I + (1 - s/th) n n^T + ((1-c)/th) [n]x,   n = r/th
 // (same matrices as lm_chain(rodrigues_vec2mat<true>) to rounding, ~40 flops instead of ~400 on the per-pass
 // dependent chain every lane walks before it can touch its first correspondence).
-ESAC_HD void lm_pose_chain(const double param[6], double R[9], LmChain& ch) {
+// In two halves: the rotation (what a pass needs before its first correspondence) and the chain-rule matrices (what
+// only the transform AFTER the pass's reduction needs -- a team computes them while its exchange is in flight).
+struct LmTrig {
+    double nx, ny, nz, theta, itheta, s, c1;  // unit axis, angle, 1/angle, sin, 1 - cos
+    bool identity;                             // theta < DBL_EPSILON
+};
+
+ESAC_HD void lm_pose_rotation(const double param[6], double R[9], LmTrig& tg) {
+#pragma clang fp contract(fast)
+    double rx = param[0], ry = param[1], rz = param[2];
+    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    tg.theta = theta;
+    tg.identity = theta < DBL_EPSILON;
+    if (tg.identity) {
+        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+        tg.nx = tg.ny = tg.nz = 0;
+        tg.itheta = 0;
+        tg.s = 0;
+        tg.c1 = 0;
+        return;
+    }
+    double c, s;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos(theta, &s, &c);  // one argument reduction for both (this chain is serial in every lane)
+#else
+    c = cos(theta);
+    s = sin(theta);
+#endif
+    const double c1 = 1. - c;
+    const double itheta = 1. / theta;
+    rx *= itheta; ry *= itheta; rz *= itheta;
+    const double xx = rx * rx, xy = rx * ry, xz = rx * rz, yy = ry * ry, yz = ry * rz, zz = rz * rz;
+    R[0] = c + c1 * xx;      R[1] = c1 * xy - s * rz; R[2] = c1 * xz + s * ry;
+    R[3] = c1 * xy + s * rz; R[4] = c + c1 * yy;      R[5] = c1 * yz - s * rx;
+    R[6] = c1 * xz - s * ry; R[7] = c1 * yz + s * rx; R[8] = c + c1 * zz;
+    tg.nx = rx; tg.ny = ry; tg.nz = rz;
+    tg.itheta = itheta;
+    tg.s = s;
+    tg.c1 = c1;
+}
+
+ESAC_HD void lm_pose_chain_rest(const LmTrig& tg, const double t[3], LmChain& ch) {
 #pragma clang fp contract(fast)
     double (&Mw)[3][3] = ch.Mw;
     double (&K)[3][3] = ch.K;
-    double rx = param[0], ry = param[1], rz = param[2];
-    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
-    if (theta < DBL_EPSILON) {
-        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+    if (tg.identity) {
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) Mw[i][j] = (i == j) ? 1.0 : 0.0;
     } else {
-        double c, s;
-#if defined(__HIP_DEVICE_COMPILE__)
-        sincos(theta, &s, &c);  // one argument reduction for both (this chain is serial in every lane)
-#else
-        c = cos(theta);
-        s = sin(theta);
-#endif
-        const double c1 = 1. - c;
-        const double itheta = 1. / theta;
-        rx *= itheta; ry *= itheta; rz *= itheta;
+        const double rx = tg.nx, ry = tg.ny, rz = tg.nz, theta = tg.theta;
         const double xx = rx * rx, xy = rx * ry, xz = rx * rz, yy = ry * ry, yz = ry * rz, zz = rz * rz;
-        R[0] = c + c1 * xx;      R[1] = c1 * xy - s * rz; R[2] = c1 * xz + s * ry;
-        R[3] = c1 * xy + s * rz; R[4] = c + c1 * yy;      R[5] = c1 * yz - s * rx;
-        R[6] = c1 * xz - s * ry; R[7] = c1 * yz + s * rx; R[8] = c + c1 * zz;
         // s/th, (1-c)/th, 1 - s/th; below 1e-2 rad the differences cancel (error ~1e-16/th), their series are exact
         // to rounding there (next term th^8/9! < 1e-21)
         const bool tiny = theta < 1e-2;
         const double t2 = theta * theta;
         const double sb_ser = t2 * (1. / 6. - t2 * (1. / 120. - t2 * (1. / 5040.)));
-        const double sa = tiny ? 1. - sb_ser : s * itheta;
-        const double ca = tiny ? theta * (0.5 - t2 * (1. / 24. - t2 * (1. / 720. - t2 * (1. / 40320.)))) : c1 * itheta;
+        const double sa = tiny ? 1. - sb_ser : tg.s * tg.itheta;
+        const double ca = tiny ? theta * (0.5 - t2 * (1. / 24. - t2 * (1. / 720. - t2 * (1. / 40320.)))) : tg.c1 * tg.itheta;
         const double sb = tiny ? sb_ser : 1. - sa;
         Mw[0][0] = sa + sb * xx;      Mw[0][1] = sb * xy - ca * rz; Mw[0][2] = sb * xz + ca * ry;
         Mw[1][0] = sb * xy + ca * rz; Mw[1][1] = sa + sb * yy;      Mw[1][2] = sb * yz - ca * rx;
         Mw[2][0] = sb * xz - ca * ry; Mw[2][1] = sb * yz + ca * rx; Mw[2][2] = sa + sb * zz;
     }
-    const double* t = param + 3;
 #pragma unroll
     for (int j = 0; j < 3; j++) {  // K[:,j] = t x Mw[:,j]
         K[0][j] = t[1] * Mw[2][j] - t[2] * Mw[1][j];
         K[1][j] = t[2] * Mw[0][j] - t[0] * Mw[2][j];
         K[2][j] = t[0] * Mw[1][j] - t[1] * Mw[0][j];
     }
+}
+
+ESAC_HD void lm_pose_chain(const double param[6], double R[9], LmChain& ch) {
+    LmTrig tg;
+    lm_pose_rotation(param, R, tg);
+    lm_pose_chain_rest(tg, param + 3, ch);
 }
 
 ESAC_HD void lm_transform(const double acc[LM_NACC], const LmChain& ch, double U21[21], double g6[6]);

@@ -1,0 +1,381 @@
+// refine_common.hpp -- what the two refinement translation units share (esac_refine.hip: one workgroup per refinement /
+// cooperating workgroups on grids beyond one LDS list; esac_refine_team.hip: a team of workgroups on one XCD for the
+// small grids): the rare pseudo-inverse LM step, cycle-counter macros, the exchange between workgroups that share one
+// refinement, winner pick and result record.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_common.hpp"
+#include "esac_kernels.hpp"
+#include "bwd_math.hpp"
+#include "lm_math.hpp"
+#include "pose_math.hpp"
+
+namespace esac {
+
+// The rare branch of an LM step: the damped normal matrix is singular to rounding (lm_solve6 returned false), so the
+// step is pinv(A) * g with eigenvalues below 2 eps sum|w| dropped -- cv::solve(DECOMP_SVD) inside CvLevMarq, the
+// route the CPU library always takes (bwd_math.hpp:pinv_sym6_jacobi is the same algorithm, unrolled into registers).
+// Here it must cost the common path nothing: ONE lane runs rolled loops over matrices in LDS (run-time indices, a few
+// hundred bytes of code, no extra registers), the others wait.  Every lane reaches this together (the LM state is
+// replicated), so the barriers are uniform.  `lds`: >= 84 doubles of scratch nobody else touches meanwhile.
+__device__ __forceinline__ void lm_solve6_pinv(const double (&U21)[21], const double (&g)[6], double lambda, double (&dx)[6], double* lds) {
+    double* A = lds;        // [6][6]
+    double* V = lds + 36;   // [6][6]
+    double* out = lds + 72; // [6]
+    double* gs = lds + 78;  // [6]
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) {
+                const double v = (i == j) ? U21[k] * (1. + lambda) : U21[k];
+                A[i * 6 + j] = v;
+                A[j * 6 + i] = v;
+                k++;
+            }
+#pragma unroll
+        for (int i = 0; i < 6; i++) gs[i] = g[i];
+        for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 60; sweep++) {
+            double off = 0;
+            for (int i = 0; i < 6; i++)
+                for (int j = i + 1; j < 6; j++) off += A[i * 6 + j] * A[i * 6 + j];
+            if (off == 0) break;
+            for (int p = 0; p < 6; p++)
+                for (int q = p + 1; q < 6; q++) {
+                    const double apq = A[p * 6 + q];
+                    const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2 * apq);
+                    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                    if (!(fabs(theta) <= 1.7976931348623157e308)) t = 0;
+                    if (apq == 0) t = 0;
+                    const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                    for (int m = 0; m < 6; m++) {
+                        const double akp = A[m * 6 + p], akq = A[m * 6 + q];
+                        A[m * 6 + p] = c * akp - sn * akq;
+                        A[m * 6 + q] = sn * akp + c * akq;
+                    }
+                    for (int m = 0; m < 6; m++) {
+                        const double apk = A[p * 6 + m], aqk = A[q * 6 + m];
+                        A[p * 6 + m] = c * apk - sn * aqk;
+                        A[q * 6 + m] = sn * apk + c * aqk;
+                    }
+                    for (int m = 0; m < 6; m++) {
+                        const double vkp = V[m * 6 + p], vkq = V[m * 6 + q];
+                        V[m * 6 + p] = c * vkp - sn * vkq;
+                        V[m * 6 + q] = sn * vkp + c * vkq;
+                    }
+                }
+        }
+        double thresh = 0;
+        for (int i = 0; i < 6; i++) thresh += fabs(A[i * 7]);
+        thresh *= 2 * 2.220446049250313e-16;
+        for (int i = 0; i < 6; i++) out[i] = 0;
+        for (int m = 0; m < 6; m++) {
+            const double w = A[m * 7];
+            if (!(fabs(w) > thresh)) continue;
+            double proj = 0;
+            for (int j = 0; j < 6; j++) proj += V[j * 6 + m] * gs[j];
+            proj /= w;
+            for (int i = 0; i < 6; i++) out[i] += V[i * 6 + m] * proj;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 6; i++) dx[i] = out[i];
+    __syncthreads();
+}
+
+constexpr int REFINE_B = ESAC_REFINE_THREADS;  // 4 wavefronts = one per SIMD of the one CU this kernel occupies
+constexpr int LDS_CAP = ESAC_REFINE_LDS_CAP;   // correspondences staged in LDS (128 KiB of the CU's 160 KiB)
+constexpr int ERR_UNROLL = ESAC_ERR_UNROLL;    // points per lane in flight in the exact error pass
+constexpr int LM_NP = 2;              // correspondences per lane in flight in an LM pass
+
+// Section cycle counters (clock64 = shader clock), enabled with -DESAC_PROFILE_CYCLES; index:
+// 0 total, 1 argmax, 2 error image + compaction, 3 pose2trans + result record, 4 rodrigues+chain, 5 point loop, 6 block_sum,
+// 7 transform, 8 solve, 9 number of passes, 10-15 error-pass sub-sections, 16 LM accept / reject / termination logic
+#ifdef ESAC_PROFILE_CYCLES
+#define CYC_DECL long long cyc_t0_
+#define CYC_BEGIN() cyc_t0_ = clock64()
+#define CYC_END(idx) g_cyc[idx] += clock64() - cyc_t0_
+#define CYC_ADD(idx, v) g_cyc[idx] += (v)
+// register-only arithmetic may be scheduled across the clock reads: pinning a section's inputs after its first read and its
+// outputs before its second one keeps the section's work between them
+#define CYC_PIN(arr, n)                                                  \
+    do {                                                                 \
+        _Pragma("unroll") for (int pin_k = 0; pin_k < (n); pin_k++) asm volatile("" : "+v"((arr)[pin_k])); \
+    } while (0)
+#else
+#define CYC_DECL
+#define CYC_BEGIN()
+#define CYC_END(idx)
+#define CYC_ADD(idx, v)
+#define CYC_PIN(arr, n)
+#endif
+
+struct __attribute__((aligned(16))) Corr {
+    float x, y, z;
+    uint32_t row_col;  // grid cell of the correspondence: row << 16 | col (H, W <= 65535, checked by the C ABI); its pixel
+                       // position is col * sub + sub / 2 - shift_x (createSampling, esac_util.h:64-66), any magnitude
+};
+
+__device__ __forceinline__ int cell_pxi(const KArgs& a, int col) { return col * a.sub + a.sub / 2 - a.shift_x; }
+__device__ __forceinline__ int cell_pyi(const KArgs& a, int row) { return row * a.sub + a.sub / 2 - a.shift_y; }
+
+// 10^k, |k| <= 31, by binary exponentiation (the CPU library evaluates exp(k*log(10)))
+__device__ __forceinline__ double pow10_int(int k) {
+    double r = 1.0;
+    const int n = k < 0 ? -k : k;
+    double b = 10.0;
+#pragma unroll
+    for (int bit = 0; bit < 5; bit++) {
+        if (n & (1 << bit)) r *= b;
+        b *= b;
+    }
+    return k < 0 ? 1.0 / r : r;
+}
+
+// ---- cooperating workgroups ------------------------------------------------------------------------------------------------
+// One refinement can be shared by G workgroups: workgroup g owns a slice of the cells -- its part of every error pass and,
+// in its own LDS, the correspondences found there -- and every reduction (inlier count, the 24 moments of an LM pass)
+// becomes: workgroup sum -> exchange -> every workgroup adds the G contributions in the same fixed order.  All workgroups
+// then hold bitwise identical sums, take the same LM / stopping decisions and carry the same pose: nothing is ever
+// broadcast.  Two exchanges exist:
+//
+// REFINE_COOP (grids beyond the LDS list, 480x640: a pass is ~700 us of one CU, up to 256 workgroups anywhere on the chip):
+// partial[g] by device-scope (sc1, write-through) stores, drained; one lane arrives at a monotonic counter and polls it
+// with s_sleep; the partials are read back with device-scope loads (~3 us a round, noise against the pass).
+//
+// REFINE_TEAM (round 4; the 60x80 grid of the headline call, where a pass is 2-6 us and that barrier costs more than it
+// saves): up to 8 workgroups exchange TAGGED GRANULES in ONE hop.  A granule is 16 bytes {double v, u64 tag},
+// tag = (launch epoch << 20 | exchange number) ^ bits(v), written by one 16-byte sc1 store; every workgroup polls all
+// G x NV granules with L1-bypassing 16-byte loads (thread t -> value t >> 3 of member t & 7) until the tag fits the value,
+// then three DPP stages add the members' contributions.  No counter, no flag, no fence; a torn or stale granule fails the
+// tag test and is simply polled again.  Buffers alternate by exchange parity (a member can be at most one exchange ahead
+// of the slowest).  Measured (scripts/dev/xcd_exchange.hip, profiles/r04_xcd_exchange.txt): 0.75 us per exchange for 8
+// workgroups on one XCD, 1.4 us across 8 XCDs.  The launcher therefore starts 8 G workgroups and keeps those with
+// blockIdx.x % 8 == 0 -- observed placement: block b runs on XCD b % 8, so the members share an L2 -- but NOTHING depends
+// on that placement except speed: sc1 stores are valid hand-offs between any two CUs.  Every member reads its XCC_ID and
+// the first exchange carries a census of them into the refinement's info words.
+// Both exchanges spin with a bound; a time-out (a member never became resident: shared or partitioned GPU) marks the
+// launch as failed, every member winds down, and the host re-runs the refinement in one workgroup (blocking calls) or
+// reports -12 (esac_hip_check).
+enum : int { REFINE_SOLO = 0, REFINE_COOP = 1, REFINE_TEAM = 2 };
+constexpr int TEAM_MAX = ESAC_REFINE_TEAM_MAX_K;  // members of a team (the poll layout gives every value 8 lanes)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct Coop {
+    int G, g;                      // number of cooperating workgroups, this one's index (G == 1: no cooperation)
+    double* partials;              // REFINE_COOP: [2][G][32]
+    unsigned long long* counter;   // REFINE_COOP: monotonic arrival counter, zeroed by the launcher; COOP_POISON is or-ed in on a time-out
+    unsigned long long* failed;    // the launch tag of the most recent launch in which an exchange timed out (what the host reads)
+    unsigned long long arrivals;   // exchanges passed so far (same in every thread of every workgroup)
+    int expect;                    // workgroups an exchange waits for (= G; ESAC_DEBUG_COOP_STALL: G + 1, never reached)
+    long spin_limit;               // polls before an exchange gives up
+    int* s_dead;                   // LDS flag: an exchange of this launch timed out somewhere
+    bool dead;                     // ... as every thread of the workgroup saw it after its last exchange (workgroup-uniform)
+    u32x4* gran;                   // REFINE_TEAM: [2][TEAM_MAX][32] granules
+    unsigned long long tag;        // this launch's tag: (launch number << 20); the low 20 bits count a team's exchanges
+};
+// A workgroup that gives up at the counter barrier sets this bit: every waiter (now and at every later barrier) sees its
+// target reached at once and reads the failure out of the same value -- nobody spins a second time.  (An OR: several
+// workgroups timing out together cannot wrap the counter.)
+constexpr unsigned long long COOP_POISON = 1ull << 62;
+
+// Every thread of a workgroup that shares a refinement: its place among the G workgroups and the launch's exchange state.
+// (s_dead is ordered before its first use by the workgroup barrier of the winner pick.)
+__device__ __forceinline__ void coop_init(Coop& co, const KArgs& a, int G, int g, long spin_limit) {
+    co.G = G;
+    co.g = g;
+    co.partials = a.coop_partials;
+    co.gran = reinterpret_cast<u32x4*>(a.coop_partials);
+    co.counter = a.coop_counter;
+    co.failed = a.coop_counter + 1;
+    co.tag = a.coop_tag;
+    co.expect = G + a.coop_extra;
+    co.spin_limit = a.coop_extra ? (1L << 12) : spin_limit;  // ~seconds normally; the stall test gives up after ~1 ms
+    if (threadIdx.x == 0) *co.s_dead = 0;
+}
+
+__device__ __forceinline__ void coop_mark_failed(Coop& co) {
+    __hip_atomic_store(co.failed, co.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *co.s_dead = 1;
+}
+
+// ---- REFINE_TEAM: the tagged-granule exchange
+__device__ __forceinline__ u32x4 gran_load(const u32x4* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gran_store(u32x4* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
+// thread t < NV publishes `own` = this member's total of value t for the exchange that team_collect() then completes
+template <int NV>
+__device__ __forceinline__ void team_publish(double own, const Coop& co) {
+    static_assert(NV <= 32, "32 granules per member");
+    if (co.dead) return;
+    if (threadIdx.x < NV) {
+        const unsigned long long want = co.tag | (co.arrivals + 1ull);
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(own), tg = want ^ bits;
+        u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
+        gran_store(buf + co.g * 32 + threadIdx.x, u32x4{(unsigned)bits, (unsigned)(bits >> 32), (unsigned)tg, (unsigned)(tg >> 32)});
+    }
+}
+// v[k] <- sum over the members of their value k, members added in one fixed (pairwise) order: bitwise identical in every
+// member.  REFINE_B = 256 threads: thread t polls value t >> 3 of member t & 7.  s_tot: >= 32 doubles nobody else touches
+// until the next workgroup barrier.
+template <int NV>
+__device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot) {
+    static_assert(NV <= 32 && REFINE_B == 32 * TEAM_MAX && TEAM_MAX == 8, "poll layout: 8 lanes per value");
+    if (co.dead) return;
+    const unsigned long long want = co.tag | (co.arrivals + 1ull);
+    const u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
+    const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
+    double val = 0.0;
+    bool timed_out = false;
+    if (j < co.expect && k < NV) {
+        const u32x4* p = buf + j * 32 + k;
+        long spins = 0;
+        for (;;) {
+            const u32x4 g = gran_load(p);
+            const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.y << 32);
+            const unsigned long long tg = (unsigned long long)g.z | ((unsigned long long)g.w << 32);
+            if ((tg ^ bits) == want) {
+                val = __longlong_as_double((long long)bits);
+                break;
+            }
+            ++spins;
+            // another member gave up (its failure word carries this launch's tag): no point in waiting out the limit
+            if (spins > co.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag)) {
+                timed_out = true;
+                break;
+            }
+        }
+    }
+    if (timed_out) coop_mark_failed(co);
+    val += dpp_move<0xB1>(val);   // members (0,1) (2,3) (4,5) (6,7)
+    val += dpp_move<0x4E>(val);   // quads
+    val += dpp_move<0x141>(val);  // all eight
+    if (j == 0 && k < NV) s_tot[k] = val;
+    barrier_lds();
+    co.dead = *co.s_dead != 0;
+#pragma unroll
+    for (int kk = 0; kk < NV; kk++) v[kk] = s_tot[kk];
+    co.arrivals += 1ull;
+}
+
+
+
+// ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties
+//      (esac_util.h:512-529; softmax is monotone, so the argmax of the scores is the argmax of the probabilities).
+// Every thread returns the winner's (local) hypothesis index; contains a workgroup barrier.
+template <int B>
+__device__ __forceinline__ int refine_pick_winner(const KArgs& a, double* s_best, int* s_besti, int* s_bestg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double bs = -INFINITY;
+    int bi = 0x7fffffff, bg = 0x7fffffff;
+    for (int h = threadIdx.x; h < a.N; h += B) {
+        if (!a.exact_flag[h]) continue;  // contenders = the hypotheses that were re-scored exactly
+        const int g = global_hyp(a, h);
+        const double s = a.scores[h];
+        if (s > bs || (s == bs && g < bg)) {
+            bs = s;
+            bi = h;
+            bg = g;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(bs, o);
+        const int oi = __shfl_xor(bi, o);
+        const int og = __shfl_xor(bg, o);
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    if (lane == 0) {
+        s_best[wave] = bs;
+        s_besti[wave] = bi;
+        s_bestg[wave] = bg;
+    }
+    __syncthreads();
+    bs = s_best[0];
+    bi = s_besti[0];
+    bg = s_bestg[0];
+#pragma unroll
+    for (int w = 1; w < B / 64; w++) {
+        const double os = s_best[w];
+        const int oi = s_besti[w];
+        const int og = s_bestg[w];
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    return bi == 0x7fffffff ? 0 : bi;
+}
+
+// ---- pose2trans (esac_util.h:537-548) and the result record; ONE thread of the workgroup that owns the outputs.
+// census: XCD census of a team (hex digit x = members on XCD x), 0 otherwise.
+__device__ __forceinline__ void refine_write_record(const KArgs& a, const double (&pose)[6], int win, double win_score, int e, int nc, int accepted,
+                                                    int last_inliers, int lm_total, int map_buf, int mode, const Coop& co,
+                                                    unsigned long long census) {
+    double R[9];
+    rodrigues_vec2mat<false>(pose, R, nullptr);
+    double T[16];
+    pose_to_inverse_transform(R, pose + 3, T);
+    double* r = a.result;
+    r[ESAC_RES_SCORE_K] = win_score;
+    r[ESAC_RES_HYP_K] = (double)global_hyp(a, win);
+#pragma unroll
+    for (int k = 0; k < 6; k++) r[ESAC_RES_RVEC_K + k] = pose[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) r[ESAC_RES_POSE_K + k] = (double)(float)T[k];
+    r[ESAC_RES_REF_STEPS_K] = (double)accepted;
+    r[ESAC_RES_INLIERS_K] = (double)last_inliers;
+    const double smax = a.stats[0], ssum = a.stats[1];
+    r[ESAC_RES_PROB_K] = exp(win_score - smax) / ssum;
+    r[ESAC_RES_ENTROPY_K] = a.stats[2];
+    r[ESAC_RES_CONTENDERS_K] = (double)nc;
+    r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
+    r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
+    // an exchange between the workgroups sharing this refinement timed out: the record is not to be trusted
+    const bool coop_failed = mode != REFINE_SOLO && (co.dead || __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag);
+    if (a.refine_info) {
+        int same = 0;
+        for (int x = 0; x < 8; x++) same |= ((census >> (4 * x)) & 15ull) == (unsigned long long)co.G;
+        a.refine_info[0] = mode;
+        a.refine_info[1] = co.G;
+        a.refine_info[2] = (int)(unsigned)census;
+        a.refine_info[3] = mode == REFINE_TEAM ? same : 0;
+        a.refine_info[4] = (int)co.arrivals;
+        a.refine_info[5] = coop_failed ? 1 : 0;
+    }
+    r[ESAC_RES_EXPERT_K] = (double)(e + a.expert_base);
+    if (a.result_user) {
+#pragma unroll
+        for (int k = 0; k < 31; k++) a.result_user[k] = r[k];
+        // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" from a record; never set on a failed one
+        a.result_user[31] = coop_failed ? 0.0 : 1.0;
+    }
+    if (a.result_pin) {
+        // straight into pinned host memory: the host polls the epoch word instead of waiting for a
+        // copy kernel + stream-completion signal (saves ~15-20 us of the blocking call's latency)
+#pragma unroll
+        for (int k = 0; k < 32; k++) a.result_pin[k] = r[k];
+        a.result_pin[33] = (a.status[0] == (unsigned long long)a.sample_epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment seen by k_sample
+        if (coop_failed) a.result_pin[33] = 3.0;
+        __threadfence_system();
+        *reinterpret_cast<volatile double*>(a.result_pin + 32) = a.epoch;
+    }
+}
+
+}  // namespace esac

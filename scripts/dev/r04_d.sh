@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 4: the fused team refinement kernel -- its tests, the parity files, bench by team size, cycle sections
+export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r04d
+mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_semantics.py -m gpu -x -q -k "team or cooperative" > $O/pytest_team.log 2>&1
+tail -25 $O/pytest_team.log
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_edge.py -m gpu -q > $O/pytest.log 2>&1
+tail -8 $O/pytest.log
+for g in 0 5 8 0 8; do
+  ESAC_REFINE_TEAM=$g timeout 300 python bench.py --no-cpu-baseline --no-extras > $O/bench_team$g.json 2> $O/bench_team$g.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$O/bench_team$g.json").read().strip().splitlines()[-1])
+    print("team $g: ms %.4f value %.0f seed1305 %s" % (d["ms_per_step"], d["value"], d.get("value_seed1305")), {k["stage"]: round(k["avg_us"],1) for k in d.get("kernels",[])})
+except Exception as e:
+    print("team $g FAILED", e); print(open("$O/bench_team$g.err").read()[-2000:])
+PY
+done
+ESAC_REFINE_TEAM=8 bash scripts/dev/cyc.sh > $O/cyc_team8.txt 2>&1
+cat $O/cyc_team8.txt

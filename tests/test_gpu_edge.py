@@ -166,8 +166,18 @@ def test_sharding_independence_on_device(engine):
         np.testing.assert_array_equal(engine.read(api.BUF_SCORES)[both_fast], scores_all[idx][both_fast])
 
 
+def _same_record(batch_rec, single_rec, upto):
+    """A frame of a batch is refined by one workgroup, a single call by a team: every discrete field identical, the
+    refined pose equal to what the rounding of the LM sums -- their summation order differs -- becomes through the damped
+    normal equations (measured <= 6e-10; the bar against the oracle is 1e-6)."""
+    discrete = [api.RES_SCORE, api.RES_HYP, api.RES_EXPERT, api.RES_REF_STEPS, api.RES_INLIERS]
+    np.testing.assert_array_equal(batch_rec[discrete], single_rec[discrete])
+    np.testing.assert_allclose(batch_rec[:upto], single_rec[:upto], rtol=0, atol=1e-8)
+
+
 def test_batched_forward_equals_sequential_calls(engine):
-    """esac_hip_forward_batch: frame b == the b-th of B consecutive single calls, bit for bit."""
+    """esac_hip_forward_batch: frame b == the b-th of B consecutive single calls -- bit for bit when the single calls
+    refine in one workgroup like the frames of a batch do, to the rounding of the LM sums when a team refines them."""
     B, N = 12, 96
     frames = [S.make_frame(70 + b, E=2, true_expert=b % 2) for b in range(B)]
     assigns = np.stack([S.gating_assignment(f, N, mode="gating") for f in frames])
@@ -176,12 +186,21 @@ def test_batched_forward_equals_sequential_calls(engine):
     scores_b = torch.empty(B, N, dtype=torch.float64, device="cuda")
     p = engine.make_params(2, 60, 80, N, call=40)
     res_b = engine.forward_batch(coords, ha, p, scores_out=scores_b)
-    for b in range(B):
-        q = engine.make_params(2, 60, 80, N, call=40 + b)
-        s1 = torch.empty(N, dtype=torch.float64, device="cuda")
-        r1 = engine.forward_device(coords[b], ha[b], q, scores_out=s1)
-        np.testing.assert_array_equal(res_b[b][:31], r1[:31])
-        np.testing.assert_array_equal(scores_b[b].cpu().numpy(), s1.cpu().numpy())
+    try:
+        for team in (0, api.REFINE_TEAM_DEFAULT):
+            engine.set_refine_team(team)
+            for b in range(B):
+                q = engine.make_params(2, 60, 80, N, call=40 + b)
+                s1 = torch.empty(N, dtype=torch.float64, device="cuda")
+                r1 = engine.forward_device(coords[b], ha[b], q, scores_out=s1)
+                if team == 0:
+                    np.testing.assert_array_equal(res_b[b][:31], r1[:31])
+                else:
+                    _same_record(res_b[b], r1, 31)
+                    assert engine.refine_info()["mode"] == "team"
+                np.testing.assert_array_equal(scores_b[b].cpu().numpy(), s1.cpu().numpy())
+    finally:
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
     # module-level API, shared maps for every frame
     import esac
     esac.set_seed(1305, 40)
@@ -189,7 +208,7 @@ def test_batched_forward_equals_sequential_calls(engine):
     experts = esac.forward_batch(coords[0], ha[:3], poses, 0, 0, 525.0, 320.0, 240.0, 10.0, 100.0, 0.5, 100.0, 8)
     q = engine.make_params(2, 60, 80, N, call=41)
     r1 = engine.forward_device(coords[0], ha[1], q)
-    np.testing.assert_array_equal(poses[1].numpy().reshape(-1), r1[api.RES_POSE:api.RES_POSE + 16].astype(np.float32))
+    np.testing.assert_allclose(poses[1].numpy().reshape(-1), r1[api.RES_POSE:api.RES_POSE + 16].astype(np.float32), rtol=0, atol=1e-6)
     assert experts[1] == int(r1[api.RES_EXPERT]) and esac.get_rng_state() == (1305, 43)
 
 
@@ -262,7 +281,7 @@ def test_large_batch_equals_sequential_calls(engine):
     for b in range(0, B, 5):
         q = engine.make_params(2, 60, 80, N, call=500 + b)
         res_1 = engine.forward_device(coords[b], ha[b], q)
-        np.testing.assert_array_equal(res_b[b][:api.RES_PROB], res_1[:api.RES_PROB])
+        _same_record(res_b[b], res_1, api.RES_PROB)
         assert res_b[b][api.RES_LM_ITERS] == res_1[api.RES_LM_ITERS]
         np.testing.assert_allclose(res_b[b][api.RES_PROB:api.RES_ENTROPY + 1], res_1[api.RES_PROB:api.RES_ENTROPY + 1], rtol=1e-5)
 

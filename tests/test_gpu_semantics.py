@@ -464,3 +464,157 @@ def test_cooperative_refinement_reports_a_barrier_time_out(engine):
     again = engine.forward_device(sc, hat, p)
     np.testing.assert_array_equal(again, good)  # the context recovers
     engine.check()
+
+
+# ---------------------------------------------------------------- the refinement team (esac_refine_team.hip)
+def _team_run(engine, oracle, frame, ha, seed, call, **kw):
+    sc, hat = torch.from_numpy(frame["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    E, _, H, W = frame["coords"].shape
+    p = engine.make_params(E, H, W, len(ha), shift_x=frame["shift"][0], shift_y=frame["shift"][1], focal=frame["focal"],
+                           ppx=frame["ppx"], ppy=frame["ppy"], sub_sampling=frame["sub"], seed=seed, call=call, **kw)
+    rec = engine.forward_device(sc, hat, p).copy()
+    out = {"rec": rec, "counts": engine.read(api.BUF_INLIER_COUNTS), "map": engine.read(api.BUF_INLIER_MAP), "info": engine.refine_info()}
+    return out
+
+
+def _same_refinement(a, b):
+    """Two runs of one refinement that differ in how many workgroups shared it: every discrete output identical, the
+    pose equal to what the rounding of the LM sums (their summation order differs) becomes through the damped normal
+    equations: measured <= 6e-10, asserted 1e-8 (the bar against the oracle is 1e-6)."""
+    discrete = [api.RES_SCORE, api.RES_HYP, api.RES_EXPERT, api.RES_REF_STEPS, api.RES_INLIERS, api.RES_LM_ITERS]
+    np.testing.assert_array_equal(a["rec"][discrete], b["rec"][discrete])
+    np.testing.assert_array_equal(a["counts"], b["counts"])
+    np.testing.assert_array_equal(a["map"], b["map"])
+    np.testing.assert_allclose(a["rec"][:31], b["rec"][:31], rtol=0, atol=1e-8)
+
+
+def test_refinement_team_sizes_agree_with_one_workgroup_and_the_oracle(engine, oracle):
+    """esac_hip_set_refine_team: the winner's refinement of a single 60x80 frame shared by 5..8 workgroups (fewer would
+    not fit a member's slice into its lanes' registers: the launcher raises the number) against ONE workgroup and the
+    oracle -- refinement trace (steps, inlier count per step, inlier map, LM iterations) identical, pose to 1e-10."""
+    try:
+        for k in range(4):
+            f = S.make_frame(400 + k)
+            ha = S.gating_assignment(f, 128)
+            engine.set_refine_team(0)
+            solo = _team_run(engine, oracle, f, ha, 21, k)
+            assert solo["info"]["mode"] == "one_workgroup" and solo["info"]["workgroups"] == 1
+            ref = oracle.forward(f["coords"], ha, shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"],
+                                 ppy=f["ppy"], sub_sampling=f["sub"], seed=21, call=k)
+            for members in (2, 5, 6, 7, 8):
+                engine.set_refine_team(members)
+                team = _team_run(engine, oracle, f, ha, 21, k)
+                info = team["info"]
+                assert info["mode"] == "team" and info["workgroups"] == max(members, 5) and not info["timed_out"], info
+                # observed placement: workgroup b runs on XCD b % 8 -- the members (every eighth workgroup) share one
+                assert info["same_xcd"] and sum(int(c, 16) for c in info["xcd_census"]) == info["workgroups"], info
+                _same_refinement(team, solo)
+                assert int(team["rec"][api.RES_REF_STEPS]) == ref["ref_steps"]
+                np.testing.assert_array_equal(team["counts"], ref["inlier_counts"])
+                np.testing.assert_array_equal(team["map"], ref["inlier_map"])
+                np.testing.assert_allclose(team["rec"][api.RES_RVEC:api.RES_RVEC + 6], ref["refined"], rtol=0, atol=1e-6)
+    finally:
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
+
+
+def test_refinement_team_on_different_xcds(engine, oracle):
+    """ESAC_DEBUG_TEAM_SPREAD launches the members as CONSECUTIVE workgroups, which the hardware places on eight
+    different XCDs -- the exchange (write-through granules, L1-bypassing polls) must not depend on where the members
+    run: same trace, same pose; the info words report the mismatch."""
+    f = S.make_frame(410)
+    ha = S.gating_assignment(f, 128)
+    together = _team_run(engine, oracle, f, ha, 22, 0)
+    engine.set_debug(team_spread=True)
+    try:
+        spread = _team_run(engine, oracle, f, ha, 22, 0)
+    finally:
+        engine.set_debug()
+    assert together["info"]["same_xcd"] and not spread["info"]["same_xcd"], (together["info"], spread["info"])
+    assert spread["info"]["mode"] == "team" and spread["info"]["workgroups"] == 8 and not spread["info"]["timed_out"]
+    assert max(int(c, 16) for c in spread["info"]["xcd_census"]) < 8
+    np.testing.assert_array_equal(spread["rec"][:31], together["rec"][:31])  # the same sums in the same order: bit for bit
+    np.testing.assert_array_equal(spread["map"], together["map"])
+
+
+def test_refinement_team_time_out_falls_back_to_one_workgroup(engine, oracle):
+    """A member that never becomes resident (ESAC_DEBUG_COOP_STALL: the last one leaves at once): the others give up after
+    a bounded spin, the BLOCKING call refines again in one workgroup and returns that result; an asynchronous call
+    leaves a record without the valid marker and esac_hip_check reports -12; the context recovers."""
+    import time
+    f = S.make_frame(411)
+    ha = S.gating_assignment(f, 128)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    p = engine.make_params(1, 60, 80, 128, seed=23, call=1)
+    try:
+        engine.set_refine_team(0)
+        solo = engine.forward_device(sc, hat, p).copy()
+        engine.set_refine_team(8)
+        before = engine.refine_info()["team_fallbacks"]
+        engine.set_debug(coop_stall=True)
+        t0 = time.time()
+        rec = engine.forward_device(sc, hat, p).copy()
+        assert time.time() - t0 < 5.0
+        info = engine.refine_info()
+        assert info["mode"] == "one_workgroup" and info["team_fallbacks"] == before + 1, info
+        np.testing.assert_array_equal(rec[:31], solo[:31])
+        dev_rec = torch.full((32,), 7.0, dtype=torch.float64, device="cuda")
+        engine.forward_device(sc, hat, p, result_out=dev_rec, want_host=False)
+        with pytest.raises(RuntimeError, match="status -12"):
+            engine.check()
+        assert float(dev_rec[31]) == 0.0  # no ESAC_RES_VALID on a failed record
+    finally:
+        engine.set_debug()
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
+    again = engine.forward_device(sc, hat, p)
+    assert engine.refine_info()["mode"] == "team" and not engine.refine_info()["timed_out"]
+    np.testing.assert_allclose(again[:31], solo[:31], rtol=0, atol=1e-8)
+    engine.check()
+
+
+@pytest.mark.parametrize("H,W,sub", [(32, 40, 8), (33, 47, 5), (60, 80, 8), (64, 128, 4), (59, 83, 8)])
+def test_refinement_team_on_other_grids(engine, oracle, H, W, sub):
+    """Grids of 1024 .. 8192 cells, rows that are not a multiple of four cells, 1 to 4 cells per lane: the team against
+    the oracle (trace, map, pose) and against one workgroup."""
+    f = S.make_frame(420 + H, H=H, W=W, sub=sub)
+    ha = S.gating_assignment(f, 64)
+    try:
+        engine.set_refine_team(0)
+        solo = _team_run(engine, oracle, f, ha, 24, H)
+        engine.set_refine_team(8)
+        team = _team_run(engine, oracle, f, ha, 24, H)
+    finally:
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
+    assert team["info"]["mode"] == "team", team["info"]
+    _same_refinement(team, solo)
+    ref = oracle.forward(f["coords"], ha, shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"],
+                         sub_sampling=f["sub"], seed=24, call=H)
+    np.testing.assert_array_equal(team["counts"], ref["inlier_counts"])
+    np.testing.assert_array_equal(team["map"], ref["inlier_map"])
+    assert int(team["rec"][api.RES_LM_ITERS]) == ref.get("lm_iters", int(team["rec"][api.RES_LM_ITERS]))
+    np.testing.assert_allclose(team["rec"][api.RES_RVEC:api.RES_RVEC + 6], ref["refined"], rtol=0, atol=1e-6)
+
+
+def test_refinement_team_debug_error_image_and_step_limit(engine, oracle):
+    """The team's fused passes with the options that change what a pass must leave behind: the error image of the refined
+    pose (ESAC_DEBUG_ERROR_IMAGE) and max_ref_steps = 0, 1, 2 (the loop ends on the step limit, esac_util.h:396)."""
+    f = S.make_frame(430)
+    ha = S.gating_assignment(f, 96)
+    engine.set_debug(keep_error_image=True)
+    try:
+        for steps in (0, 1, 2, -1):
+            team = _team_run(engine, oracle, f, ha, 25, 3, max_ref_steps=steps)
+            errs = engine.read(api.BUF_WINNER_ERRS)
+            ref = oracle.forward(f["coords"], ha, shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"],
+                                 ppy=f["ppy"], sub_sampling=f["sub"], seed=25, call=3, max_ref_steps=steps)
+            assert team["info"]["mode"] == "team"
+            assert int(team["rec"][api.RES_REF_STEPS]) == ref["ref_steps"]
+            n = len(ref["inlier_counts"])  # (the oracle's trace has max_ref_steps + 1 entries)
+            np.testing.assert_array_equal(team["counts"][:n], ref["inlier_counts"])
+            assert (team["counts"][n:] == -1).all()
+            np.testing.assert_array_equal(team["map"], ref["inlier_map"])
+            np.testing.assert_allclose(team["rec"][api.RES_RVEC:api.RES_RVEC + 6], ref["refined"], rtol=0, atol=1e-6)
+            if "winner_errs" in ref:
+                np.testing.assert_allclose(errs, ref["winner_errs"], rtol=0, atol=2e-3)
+                np.testing.assert_array_equal(errs < 10.0, ref["winner_errs"] < 10.0)
+    finally:
+        engine.set_debug()

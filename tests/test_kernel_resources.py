@@ -34,15 +34,25 @@ def _usage(source, tmp_path):
 def test_refinement_kernels_do_not_spill(tmp_path):
     k = _usage("esac_refine.hip", tmp_path)
     refine = {n: v for n, v in k.items() if "k_refine" in n}
-    # {LDS, global list} x {vector, scalar error pass} x {winner, slots} + the two shared winner variants (cooperating
-    # workgroups on large grids, a team on small ones)
-    assert len(refine) == 10
+    # {LDS, global list} x {vector, scalar error pass} x {winner, slots} + the cooperating-workgroups winner variant of the
+    # large grids (the team of the small grids is a kernel of its own, below)
+    assert len(refine) == 9
     for name, u in refine.items():
         assert u["ScratchSize"] == 0, (name, u)
         # one wavefront per SIMD by design: the pose state, 24 accumulators and two correspondences in flight
         assert u["VGPRs"] + u.get("AGPRs", 0) <= 512, (name, u)
         if "ELb0E" in name.split("k_refineILi256")[1][:6]:  # LDS-list variants hold the 128 KiB list + reduction scratch
             assert 128 * 1024 <= u["LDS"] <= 160 * 1024, (name, u)
+
+
+def test_team_refinement_kernels_do_not_spill(tmp_path):
+    k = _usage("esac_refine_team.hip", tmp_path)
+    team = {n: v for n, v in k.items() if "k_refine_team" in n}
+    assert len(team) == 4  # 1..4 cells per lane
+    for name, u in team.items():
+        assert u["ScratchSize"] == 0, (name, u)
+        assert u["VGPRs"] + u.get("AGPRs", 0) <= 512, (name, u)
+        assert 80 * 1024 < u["LDS"] <= 160 * 1024, (name, u)  # more than half a CU's LDS: one member per CU
 
 
 def test_streaming_and_selection_kernels_stay_lean(tmp_path):

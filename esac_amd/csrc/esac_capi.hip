@@ -482,9 +482,16 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         // the refinement kernel stores the record and then the epoch word into pinned host memory
         // (one ESAC_PIN_DOUBLES slot per frame: record, epoch word, status word)
         auto wait_record = [&](double want) -> int {
+            // a slot has landed when its epoch word is this call's AND its check word fits the other 34 words (the kernel
+            // stores them without a fence: esac_kernels.hpp, pin_mix)
             auto all_landed = [&]() {
-                for (int b = 0; b < B; b++)
-                    if (*(volatile double*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES + 32) != want) return false;
+                for (int b = 0; b < B; b++) {
+                    const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES);
+                    if (*(const volatile double*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES + 32) != want) return false;
+                    unsigned long long h = 0;
+                    for (int k = 0; k < 34; k++) h ^= pin_mix(w[k], k);
+                    if (h != w[34]) return false;
+                }
                 return true;
             };
             bool landed = false;

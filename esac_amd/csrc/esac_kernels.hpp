@@ -17,7 +17,16 @@ constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the er
 constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refinement (one per CU: all must be resident)
 constexpr int ESAC_REFINE_TEAM_MAX_K = 8;    // ... on a grid that fits one workgroup's LDS list: a team on one XCD (esac_refine.hip)
 constexpr int ESAC_REFINE_TEAM_MIN_CELLS = 1024;  // smaller grids are refined by one workgroup (a pass is shorter than an exchange)
-constexpr int ESAC_PIN_DOUBLES = 34;       // pinned host slot per frame: result record [32] + epoch word + status word
+constexpr int ESAC_PIN_DOUBLES = 36;       // pinned host slot per frame: result record [32] + epoch word + status word + check word + pad
+// The pinned record is handed over WITHOUT a system-scope fence: the kernel stores the 34 words and a 35th that is a
+// checksum of them (one store instruction), the host accepts a slot once its epoch word is the call's and the check word
+// fits the other 34 -- whatever order the words arrive in across PCIe, a partly updated slot fails the check and is
+// simply polled again.  pin_mix(bits of word k, k), XOR-ed over k = 0..33, is the check word.
+__host__ __device__ inline unsigned long long pin_mix(unsigned long long bits, int k) {
+    const unsigned long long h = (bits + (unsigned long long)(k + 1) * 0x9E3779B97F4A7C15ull) * 0xD6E8FEB86659FD93ull;
+    const int r = k & 63;
+    return r ? (h << r) | (h >> (64 - r)) : h;
+}
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
 constexpr int ESAC_FLAG_EXACT_SAMPLING_K = 16, ESAC_FLAG_SCORES_BY_INDEX_K = 32;  // = ESAC_FLAG_* (checked in esac_capi.hip)
 constexpr int ESAC_SELECT_SPLIT = 16;          // cell ranges (workgroups) per contender in k_select_rescore when H*W >= 32768

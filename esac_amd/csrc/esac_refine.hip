@@ -476,6 +476,8 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const int picked = SLOTS ? 0 : refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
     const int win = SLOTS ? a.bwd.sel[blockIdx.x] : picked;
     const double win_score = a.scores[win];
+    RecordInputs rec_in{0.0, 0.0, 0ull};
+    if (!SLOTS && writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
     const int e = expert_of(a, win);
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
 
@@ -531,8 +533,11 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     }
     // ---- pose2trans (esac_util.h:537-548) and the result record
     CYC_BEGIN();
+    __syncthreads();  // s_part is free: the record is staged there
+    if (threadIdx.x < 64 && writer) {
+        refine_write_record(a, rec_in, pose, win, win_score, e, nc, accepted, last_inliers, lm_total, map_buf, MODE, co, 0ull, s_part);
+    }
     if (threadIdx.x == 0 && writer) {
-        refine_write_record(a, pose, win, win_score, e, nc, accepted, last_inliers, lm_total, map_buf, MODE, co, 0ull);
 #ifdef ESAC_PROFILE_CYCLES
         CYC_END(3);
         g_cyc[0] = clock64() - cyc_start;

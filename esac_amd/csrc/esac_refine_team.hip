@@ -60,11 +60,11 @@ __device__ __forceinline__ TauBand make_band(const KArgs& a) {
 }
 
 // One pass at `param` (see the header).  in: run_set = the set the re-fit works on, use_next = moments over the next set
-// instead.  out: next_set, sums (totals over the team, identical in every thread of every member), ch = chain-rule
-// matrices at param.
+// instead.  out: next_set, sums (totals over the team, identical in every thread of every member), Mw = chain-rule
+// matrix at param (the left Jacobian of SO(3), lm_math.hpp).
 template <int CPL>
 __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& cl, const double (&param)[6], const Cam& cam, const TauBand& band,
-                                          unsigned run_set, bool use_next, unsigned& next_set, double (&sums)[TEAM_NSUM], LmChain& ch,
+                                          unsigned run_set, bool use_next, unsigned& next_set, double (&sums)[TEAM_NSUM], double (&Mw)[3][3],
                                           Coop& co, double* s_part, double* s_tot, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
@@ -142,32 +142,56 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
     // wavefront totals -> LDS -> this member's totals (threads < 27) -> granules -> every member adds all members'
     wave_totals28_to_lds<TEAM_NSUM>(sums, s_part);
     team_publish<TEAM_NSUM>(workgroup_total28<REFINE_B>(s_part), co);
-    lm_pose_chain_rest(tg, param + 3, ch);  // while the exchange is in flight
+    lm_pose_left_jacobian(tg, Mw);  // while the exchange is in flight
     team_collect<TEAM_NSUM>(sums, co, s_tot);
     CYC_END(6);
     CYC_ADD(9, 1);
 }
 
-// normal equations in (rvec, tvec) space from the moments of a pass at the pose `ch` belongs to
-__device__ __forceinline__ void team_normal_equations(const double (&sums)[TEAM_NSUM], const Cam& cam, const LmChain& ch, double (&U21)[21],
-                                                      double (&g6)[6], long long* g_cyc) {
+// normal equations in (rvec, tvec) space from the moments of a pass at the pose (.., t) whose chain-rule matrix is Mw
+__device__ __forceinline__ void team_normal_equations(const double (&sums)[TEAM_NSUM], const Cam& cam, const double (&Mw)[3][3], const double* t,
+                                                      double (&U21)[21], double (&g6)[6], long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
     double acc[LM_NACC];
     lm_moments_to_acc(sums, cam.fx, acc);
-    lm_transform(acc, ch, U21, g6);
+    lm_transform_t(acc, Mw, t, U21, g6);
     CYC_PIN(U21, 21);
     CYC_PIN(g6, 6);
     CYC_END(7);
 }
 
+// sqrt(a) > sqrt(b) -- CvLevMarq compares error NORMS -- without the square roots unless a and b are a few ulp apart
+// (a double-precision square root is ~40 dependent instructions on the serial section of every pass).  sqrt is monotone
+// and correctly rounded: a <= b (or a NaN) can never give a larger root, and a relative gap of 8 eps separates the roots
+// by more than their rounding.
+__device__ __forceinline__ bool norm_greater(double a, double b) {
+    if (!(a > b)) return false;
+    if (a > b * (1.0 + 8.0 * DBL_EPSILON)) return true;
+    return sqrt(a) > sqrt(b);
+}
+// cvNorm(param, prevParam, CV_RELATIVE_L2) < FLT_EPSILON, i.e. sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < eps, dn = |param - prev|^2,
+// pn = |prev|^2: decided on the squares wherever the answer is clear of the threshold by 1e-9 (relative), by the
+// reference's own expression in between.  sqrt(pn) <= max(1, pn) bounds the DBL_EPSILON term from above.
+__device__ __forceinline__ bool relative_step_below_eps(double dn, double pn) {
+    const double e2 = (double)FLT_EPSILON * (double)FLT_EPSILON;
+    const double lo = e2 * pn;
+    if (dn < lo * (1.0 - 1e-9)) return true;
+    const double hi = lo + e2 * DBL_EPSILON * (2.0 * (pn > 1.0 ? pn : 1.0) + DBL_EPSILON);
+    if (dn > hi * (1.0 + 1e-9)) return false;
+    return sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < (double)FLT_EPSILON;
+}
+
 // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
+// (lambda = 10^lambda_lg10 from a table in LDS: the binary exponentiation + division of pow10_int is ~600 cycles of
+// dependent work)
 __device__ __forceinline__ void team_step(const double (&U21)[21], const double (&g6)[6], int lambda_lg10, const double (&prev)[6], double (&param)[6],
-                                          double* s_part, long long* g_cyc) {
+                                          const double* s_pow10, double* s_part, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
     double dx[6];
-    if (!lm_solve6(U21, g6, pow10_int(lambda_lg10), dx)) lm_solve6_pinv(U21, g6, pow10_int(lambda_lg10), dx, s_part);
+    const double lambda = s_pow10[lambda_lg10 + 16];
+    if (!lm_solve6(U21, g6, lambda, dx)) lm_solve6_pinv(U21, g6, lambda, dx, s_part);
 #pragma unroll
     for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
     CYC_PIN(param, 6);
@@ -184,6 +208,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     __shared__ int s_besti[B / 64];
     __shared__ int s_bestg[B / 64];
     __shared__ int s_coop_dead;
+    __shared__ double s_pow10[33];  // 10^-16 .. 10^16: the LM damping factors
     __shared__ char s_pad[TEAM_LDS_PAD];
     if (a.team_stride < 0) s_pad[threadIdx.x] = 1;  // (never: keeps the allocation)
     const int P = a.H * a.W;
@@ -205,34 +230,40 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         team_publish<1>((double)(1ull << (4 * (xcc & 7))), co);
     }
+    if (threadIdx.x < 33) s_pow10[threadIdx.x] = pow10_int((int)threadIdx.x - 16);  // (visible after the barrier of the winner pick)
     const bool writer = co.g == 0;
     if (writer)
         for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;  // (drained by the barrier of the winner pick)
     const int cell0 = (int)((long long)P * co.g / co.G), cell1 = (int)((long long)P * (co.g + 1) / co.G);
 
+    // this lane's cells: with one expert the map is known before the winner is (one dependent load less on the way in)
+    TeamCells<CPL> cl;
+    auto load_cells = [&](const float* __restrict__ mx) {
+#pragma unroll
+        for (int p = 0; p < CPL; p++) {
+            const int i = cell0 + p * B + (int)threadIdx.x;
+            const bool have = i < cell1;
+            const int ic = have ? i : cell0;
+            cl.cell[p] = have ? i : -1;
+            const int row = ic / a.W, col = ic - row * a.W;
+            cl.X[p] = have ? (double)mx[ic] : 0.0;
+            cl.Y[p] = have ? (double)mx[P + ic] : 0.0;
+            cl.Z[p] = have ? (double)mx[2 * P + ic] : 0.0;
+            cl.px[p] = (double)(float)cell_pxi(a, col);  // Point2f of the integer pixel centre (esac_util.h:64-66, :180)
+            cl.py[p] = (double)(float)cell_pyi(a, row);
+        }
+    };
+    if (a.E == 1) load_cells(a.sc);
     const int nc = a.n_contenders[0];
     const int win = refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
     const double win_score = a.scores[win];
+    RecordInputs rec_in{0.0, 0.0, 0ull};
+    if (writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
     const int e = expert_of(a, win);
-    const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
     double pose[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
-    // this lane's cells
-    TeamCells<CPL> cl;
-#pragma unroll
-    for (int p = 0; p < CPL; p++) {
-        const int i = cell0 + p * B + (int)threadIdx.x;
-        const bool have = i < cell1;
-        const int ic = have ? i : cell0;
-        cl.cell[p] = have ? i : -1;
-        const int row = ic / a.W, col = ic - row * a.W;
-        cl.X[p] = have ? (double)mx[ic] : 0.0;
-        cl.Y[p] = have ? (double)mx[P + ic] : 0.0;
-        cl.Z[p] = have ? (double)mx[2 * P + ic] : 0.0;
-        cl.px[p] = (double)(float)cell_pxi(a, col);  // Point2f of the integer pixel centre (esac_util.h:64-66, :180)
-        cl.py[p] = (double)(float)cell_pyi(a, row);
-    }
+    if (a.E != 1) load_cells(a.sc + (size_t)e * 3 * P);
     double census[1] = {0.0};
     team_collect<1>(census, co, s_tot);
     CYC_END(1);
@@ -240,7 +271,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     // ---- refineHyp (esac_util.h:378-454) around ONE pass site
     const TauBand band = make_band(a);
     double sums[TEAM_NSUM];
-    LmChain ch;
+    double Mw[3][3];
     unsigned run_set = 0, next_set = 0, acc_set = 0;  // sets as bit masks over this lane's cells: the running re-fit's, the one the last
                                                       // full pass found, the last ACCEPTED step's (inlierMap, esac_util.h:440)
     double param[6], prev[6], U21[21], g6[6];
@@ -248,9 +279,9 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     for (int k = 0; k < 6; k++) param[k] = prev[k] = pose[k];
     int accepted = 0, last_inliers = 0, lm_total = 0, rstep = 0;
     unsigned best_inliers = 4;
-    // LM state: lambda = 10^lambda_lg10, iterations of the running re-fit, |err| at `prev`
+    // LM state: lambda = 10^lambda_lg10, iterations of the running re-fit, |err|^2 at `prev`
     int lambda_lg10 = -3, iters = 0;
-    double prev_err_norm = 0;
+    double prev_err2 = 0;
     bool in_refit = false;  // false: the next pass is the error image at `pose` (= param) with the first LM pass of its set
     for (;;) {
         // Does this trial, if accepted, end the re-fit?  (CvLevMarq: ++iters >= max_iter, or the relative step
@@ -263,28 +294,26 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
                 dn += (param[k] - prev[k]) * (param[k] - prev[k]);
                 pn += prev[k] * prev[k];
             }
-            const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
-            ends_refit = iters + 1 >= 20 || rel < (double)FLT_EPSILON;
+            ends_refit = iters + 1 >= 20 || relative_step_below_eps(dn, pn);
         }
-        team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, ch, co, s_part, s_tot, g_cyc);
+        team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, Mw, co, s_part, s_tot, g_cyc);
         if (co.dead) break;  // an exchange timed out: the sums are garbage, the call reports it
         CYC_BEGIN();
         if (in_refit) {
-            const double err_norm = sqrt(sums[24]);
-            if (err_norm > prev_err_norm && ++lambda_lg10 <= 16) {  // state CHECK_ERR failed: retry from `prev` with a larger lambda
+            if (norm_greater(sums[24], prev_err2) && ++lambda_lg10 <= 16) {  // state CHECK_ERR failed: retry from `prev` with a larger lambda
                 CYC_END(16);
-                team_step(U21, g6, lambda_lg10, prev, param, s_part, g_cyc);
+                team_step(U21, g6, lambda_lg10, prev, param, s_pow10, s_part, g_cyc);
                 continue;
             }
             lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
             ++iters;
             if (!ends_refit) {  // state CALC_J at the accepted point
-                prev_err_norm = err_norm;
+                prev_err2 = sums[24];
 #pragma unroll
                 for (int k = 0; k < 6; k++) prev[k] = param[k];
                 CYC_END(16);
-                team_normal_equations(sums, cam, ch, U21, g6, g_cyc);
-                team_step(U21, g6, lambda_lg10, prev, param, s_part, g_cyc);
+                team_normal_equations(sums, cam, Mw, prev + 3, U21, g6, g_cyc);
+                team_step(U21, g6, lambda_lg10, prev, param, s_pow10, s_part, g_cyc);
                 continue;
             }
             // the re-fit is done: its last trial is the refined pose, and this pass was its error image
@@ -306,12 +335,12 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         in_refit = true;
         lambda_lg10 = -3;
         iters = 0;
-        prev_err_norm = sqrt(sums[25]);
+        prev_err2 = sums[25];
 #pragma unroll
         for (int k = 0; k < 6; k++) prev[k] = param[k];
         CYC_END(16);
-        team_normal_equations(sums, cam, ch, U21, g6, g_cyc);
-        team_step(U21, g6, lambda_lg10, prev, param, s_part, g_cyc);
+        team_normal_equations(sums, cam, Mw, prev + 3, U21, g6, g_cyc);
+        team_step(U21, g6, lambda_lg10, prev, param, s_pow10, s_part, g_cyc);
     }
     // the refined pose: the last accepted re-fit's (esac_util.h:439); a pass that ended the loop was evaluated AT it
     // (or at the initial pose when no re-fit was accepted)
@@ -325,13 +354,15 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
             if (cl.cell[p] >= 0) a.inlier_map[cl.cell[p]] = (uint8_t)((acc_set >> p) & 1u);
     }
     CYC_BEGIN();
-    if (threadIdx.x == 0 && writer) {
-        refine_write_record(a, pose, win, win_score, e, nc, accepted, last_inliers, lm_total, accepted > 0 ? 0 : -1, REFINE_TEAM, co,
-                            (unsigned long long)census[0]);
+    if (threadIdx.x < 64 && writer) {  // (s_part: the last exchange's barrier lies behind every reader of it)
+        refine_write_record(a, rec_in, pose, win, win_score, e, nc, accepted, last_inliers, lm_total, accepted > 0 ? 0 : -1, REFINE_TEAM, co,
+                            (unsigned long long)census[0], s_part);
 #ifdef ESAC_PROFILE_CYCLES
-        CYC_END(3);
-        g_cyc[0] = clock64() - cyc_start;
-        for (int k = 0; k < 24; k++) a.cycles[k] = g_cyc[k];
+        if (threadIdx.x == 0) {
+            CYC_END(3);
+            g_cyc[0] = clock64() - cyc_start;
+            for (int k = 0; k < 24; k++) a.cycles[k] = g_cyc[k];
+        }
 #endif
     }
 }

@@ -280,10 +280,8 @@ ESAC_HD void lm_pose_rotation(const double param[6], double R[9], LmTrig& tg) {
     tg.c1 = c1;
 }
 
-ESAC_HD void lm_pose_chain_rest(const LmTrig& tg, const double t[3], LmChain& ch) {
+ESAC_HD void lm_pose_left_jacobian(const LmTrig& tg, double (&Mw)[3][3]) {
 #pragma clang fp contract(fast)
-    double (&Mw)[3][3] = ch.Mw;
-    double (&K)[3][3] = ch.K;
     if (tg.identity) {
 #pragma unroll
         for (int i = 0; i < 3; i++)
@@ -304,6 +302,13 @@ ESAC_HD void lm_pose_chain_rest(const LmTrig& tg, const double t[3], LmChain& ch
         Mw[1][0] = sb * xy + ca * rz; Mw[1][1] = sa + sb * yy;      Mw[1][2] = sb * yz - ca * rx;
         Mw[2][0] = sb * xz - ca * ry; Mw[2][1] = sb * yz + ca * rx; Mw[2][2] = sa + sb * zz;
     }
+}
+
+ESAC_HD void lm_pose_chain_rest(const LmTrig& tg, const double t[3], LmChain& ch) {
+#pragma clang fp contract(fast)
+    double (&Mw)[3][3] = ch.Mw;
+    double (&K)[3][3] = ch.K;
+    lm_pose_left_jacobian(tg, Mw);
 #pragma unroll
     for (int j = 0; j < 3; j++) {  // K[:,j] = t x Mw[:,j]
         K[0][j] = t[1] * Mw[2][j] - t[2] * Mw[1][j];
@@ -379,6 +384,71 @@ ESAC_HD void lm_transform(const double acc[LM_NACC], const LmChain& ch, double U
     for (int i = 0; i < 3; i++) {
         g6[i] = Mw[0][i] * acc[20] + Mw[1][i] * acc[21] + Mw[2][i] * acc[22] + K[0][i] * acc[23] + K[1][i] * acc[24] +
                 K[2][i] * acc[25];
+        g6[3 + i] = acc[23 + i];
+    }
+}
+
+// The same map with K = [t]x Mw folded in (a team's passes, esac_refine_team.hip): with Tx = [t]x
+//     U_rr = Mw^T B Mw,   B = Aww + E Tx + (Awv Tx)^T,   E = Awv + Tx^T Avv;     U_rt = Mw^T E;     U_tt = Avv
+//     g_r  = Mw^T (g_w + g_v x t),   g_t = g_v
+// -- products with Tx are two terms per entry, B is symmetric (six entries): ~130 fused ops instead of ~235 on the serial
+// section every lane walks between a pass and the next step.  Equal to lm_transform to rounding (host test).
+ESAC_HD void lm_transform_t(const double acc[LM_NACC], const double (&Mw)[3][3], const double t[3], double U21[21], double g6[6]) {
+#pragma clang fp contract(fast)
+    const double t0 = t[0], t1 = t[1], t2 = t[2];
+    const double Aww[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[6], acc[7]}, {acc[2], acc[7], acc[11]}};
+    const double Awv[3][3] = {{acc[3], acc[4], acc[5]}, {acc[8], acc[9], acc[10]}, {acc[12], acc[13], acc[14]}};
+    const double Avv[3][3] = {{acc[15], 0.0, acc[16]}, {0.0, acc[17], acc[18]}, {acc[16], acc[18], acc[19]}};
+    // (X Tx)[i][:] = (X[i][1] t2 - X[i][2] t1,  X[i][2] t0 - X[i][0] t2,  X[i][0] t1 - X[i][1] t0)   (row x t, negated: -(t x row))
+    // (Tx^T Y)[:][j] = -(t x Y[:][j]) = Y[:][j] x t
+    double E[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        E[0][j] = Awv[0][j] + (Avv[1][j] * t2 - Avv[2][j] * t1);
+        E[1][j] = Awv[1][j] + (Avv[2][j] * t0 - Avv[0][j] * t2);
+        E[2][j] = Awv[2][j] + (Avv[0][j] * t1 - Avv[1][j] * t0);
+    }
+    double ET[3][3], AT[3][3];  // E Tx, Awv Tx
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        ET[i][0] = E[i][1] * t2 - E[i][2] * t1;
+        ET[i][1] = E[i][2] * t0 - E[i][0] * t2;
+        ET[i][2] = E[i][0] * t1 - E[i][1] * t0;
+        AT[i][0] = Awv[i][1] * t2 - Awv[i][2] * t1;
+        AT[i][1] = Awv[i][2] * t0 - Awv[i][0] * t2;
+        AT[i][2] = Awv[i][0] * t1 - Awv[i][1] * t0;
+    }
+    double B[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) {
+            // B is symmetric analytically; one of the two roundings serves both entries
+            const double bij = Aww[i][j] + (ET[i][j] + AT[j][i]);
+            B[i][j] = bij;
+            B[j][i] = bij;
+        }
+    double C[3][3];  // B Mw
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[i][j] = B[i][0] * Mw[0][j] + B[i][1] * Mw[1][j] + B[i][2] * Mw[2][j];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = i; j < 3; j++) U21[n++] = Mw[0][i] * C[0][j] + Mw[1][i] * C[1][j] + Mw[2][i] * C[2][j];
+#pragma unroll
+        for (int j = 0; j < 3; j++) U21[n++] = Mw[0][i] * E[0][j] + Mw[1][i] * E[1][j] + Mw[2][i] * E[2][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = i; j < 3; j++) U21[n++] = Avv[i][j];
+    const double gw[3] = {acc[20] + (acc[24] * t2 - acc[25] * t1), acc[21] + (acc[25] * t0 - acc[23] * t2), acc[22] + (acc[23] * t1 - acc[24] * t0)};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        g6[i] = Mw[0][i] * gw[0] + Mw[1][i] * gw[1] + Mw[2][i] * gw[2];
         g6[3 + i] = acc[23 + i];
     }
 }

@@ -323,58 +323,73 @@ __device__ __forceinline__ int refine_pick_winner(const KArgs& a, double* s_best
     return bi == 0x7fffffff ? 0 : bi;
 }
 
-// ---- pose2trans (esac_util.h:537-548) and the result record; ONE thread of the workgroup that owns the outputs.
-// census: XCD census of a team (hex digit x = members on XCD x), 0 otherwise.
-__device__ __forceinline__ void refine_write_record(const KArgs& a, const double (&pose)[6], int win, double win_score, int e, int nc, int accepted,
-                                                    int last_inliers, int lm_total, int map_buf, int mode, const Coop& co,
-                                                    unsigned long long census) {
-    double R[9];
-    rodrigues_vec2mat<false>(pose, R, nullptr);
-    double T[16];
-    pose_to_inverse_transform(R, pose + 3, T);
-    double* r = a.result;
-    r[ESAC_RES_SCORE_K] = win_score;
-    r[ESAC_RES_HYP_K] = (double)global_hyp(a, win);
-#pragma unroll
-    for (int k = 0; k < 6; k++) r[ESAC_RES_RVEC_K + k] = pose[k];
-#pragma unroll
-    for (int k = 0; k < 16; k++) r[ESAC_RES_POSE_K + k] = (double)(float)T[k];
-    r[ESAC_RES_REF_STEPS_K] = (double)accepted;
-    r[ESAC_RES_INLIERS_K] = (double)last_inliers;
+// ---- pose2trans (esac_util.h:537-548) and the result record.
+// What the record needs besides the refinement's own outcome is known when the kernel starts (the selection kernel wrote
+// it): loaded there, so that the end of the kernel is arithmetic and stores only.
+struct RecordInputs {
+    double prob, entropy;       // selection probability of the winner, entropy of the distribution (esac.cpp:157-158)
+    unsigned long long status;  // epoch of the last sampling launch that met an out-of-range hypAssignment
+};
+__device__ __forceinline__ RecordInputs refine_record_inputs(const KArgs& a, double win_score) {
     const double smax = a.stats[0], ssum = a.stats[1];
-    r[ESAC_RES_PROB_K] = exp(win_score - smax) / ssum;
-    r[ESAC_RES_ENTROPY_K] = a.stats[2];
-    r[ESAC_RES_CONTENDERS_K] = (double)nc;
-    r[ESAC_RES_LM_ITERS_K] = (double)lm_total;
-    r[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
+    return RecordInputs{exp(win_score - smax) / ssum, a.stats[2], a.status[0]};
+}
+
+// Called by ALL 64 lanes of the first wavefront of the workgroup that owns the outputs.  s_rec: >= 36 doubles of LDS that
+// nobody else touches any more.  census: XCD census of a team (hex digit x = members on XCD x), 0 otherwise.
+__device__ __forceinline__ void refine_write_record(const KArgs& a, const RecordInputs& in, const double (&pose)[6], int win, double win_score, int e,
+                                                    int nc, int accepted, int last_inliers, int lm_total, int map_buf, int mode, const Coop& co,
+                                                    unsigned long long census, double* s_rec) {
+    const int lane = threadIdx.x & 63;
     // an exchange between the workgroups sharing this refinement timed out: the record is not to be trusted
     const bool coop_failed = mode != REFINE_SOLO && (co.dead || __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag);
-    if (a.refine_info) {
-        int same = 0;
-        for (int x = 0; x < 8; x++) same |= ((census >> (4 * x)) & 15ull) == (unsigned long long)co.G;
-        a.refine_info[0] = mode;
-        a.refine_info[1] = co.G;
-        a.refine_info[2] = (int)(unsigned)census;
-        a.refine_info[3] = mode == REFINE_TEAM ? same : 0;
-        a.refine_info[4] = (int)co.arrivals;
-        a.refine_info[5] = coop_failed ? 1 : 0;
-    }
-    r[ESAC_RES_EXPERT_K] = (double)(e + a.expert_base);
-    if (a.result_user) {
+    if (lane == 0) {
+        double R[9];
+        rodrigues_vec2mat<false>(pose, R, nullptr);
+        double T[16];
+        pose_to_inverse_transform(R, pose + 3, T);
+        s_rec[ESAC_RES_SCORE_K] = win_score;
+        s_rec[ESAC_RES_HYP_K] = (double)global_hyp(a, win);
+        s_rec[ESAC_RES_EXPERT_K] = (double)(e + a.expert_base);
 #pragma unroll
-        for (int k = 0; k < 31; k++) a.result_user[k] = r[k];
+        for (int k = 0; k < 6; k++) s_rec[ESAC_RES_RVEC_K + k] = pose[k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) s_rec[ESAC_RES_POSE_K + k] = (double)(float)T[k];
+        s_rec[ESAC_RES_REF_STEPS_K] = (double)accepted;
+        s_rec[ESAC_RES_INLIERS_K] = (double)last_inliers;
+        s_rec[ESAC_RES_PROB_K] = in.prob;
+        s_rec[ESAC_RES_ENTROPY_K] = in.entropy;
+        s_rec[ESAC_RES_CONTENDERS_K] = (double)nc;
+        s_rec[ESAC_RES_LM_ITERS_K] = (double)lm_total;
+        s_rec[31] = (double)map_buf;  // which inlier-map buffer holds the last accepted set (-1: none)
+        s_rec[32] = a.epoch;
+        // status word: 1 = out-of-range hypAssignment seen by the launch that sampled, 3 = the shared refinement timed out
+        s_rec[33] = coop_failed ? 3.0 : (in.status == (unsigned long long)a.sample_epoch) ? 1.0 : 0.0;
+        if (a.refine_info) {
+            int same = 0;
+            for (int x = 0; x < 8; x++) same |= ((census >> (4 * x)) & 15ull) == (unsigned long long)co.G;
+            a.refine_info[0] = mode;
+            a.refine_info[1] = co.G;
+            a.refine_info[2] = (int)(unsigned)census;
+            a.refine_info[3] = mode == REFINE_TEAM ? same : 0;
+            a.refine_info[4] = (int)co.arrivals;
+            a.refine_info[5] = coop_failed ? 1 : 0;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wavefront: its LDS operations complete in order
+    const double v = lane < 34 ? s_rec[lane] : 0.0;
+    if (lane < 32) {
+        a.result[lane] = v;
         // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" from a record; never set on a failed one
-        a.result_user[31] = coop_failed ? 0.0 : 1.0;
+        if (a.result_user) a.result_user[lane] = lane == 31 ? (coop_failed ? 0.0 : 1.0) : v;
     }
     if (a.result_pin) {
-        // straight into pinned host memory: the host polls the epoch word instead of waiting for a
-        // copy kernel + stream-completion signal (saves ~15-20 us of the blocking call's latency)
+        // straight into pinned host memory (the host polls instead of waiting for a copy kernel + stream-completion signal:
+        // ~15-20 us of a blocking call's latency), 34 words + their check word, no fence (esac_kernels.hpp: pin_mix)
+        unsigned long long h = lane < 34 ? pin_mix((unsigned long long)__double_as_longlong(v), lane) : 0ull;
 #pragma unroll
-        for (int k = 0; k < 32; k++) a.result_pin[k] = r[k];
-        a.result_pin[33] = (a.status[0] == (unsigned long long)a.sample_epoch) ? 1.0 : 0.0;  // out-of-range hypAssignment seen by k_sample
-        if (coop_failed) a.result_pin[33] = 3.0;
-        __threadfence_system();
-        *reinterpret_cast<volatile double*>(a.result_pin + 32) = a.epoch;
+        for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o);
+        if (lane < 35) a.result_pin[lane] = lane < 34 ? v : __longlong_as_double((long long)h);
     }
 }
 

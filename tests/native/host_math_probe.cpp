@@ -63,6 +63,20 @@ void probe_lm_normal_moments(const float* obj, const float* img, int n, const do
     lm_transform(acc, ch, U21, g6);
     *e2 = acc[26];
 }
+// lm_transform_t (K folded in) against lm_transform on the same twist-space sums: max |difference| relative to the largest entry
+double probe_transform_t_diff(const double* acc, const double* pose) {
+    double R[9], U1[21], g1[6], U2[21], g2[6];
+    LmChain ch;
+    lm_pose_chain(pose, R, ch);
+    lm_transform(acc, ch, U1, g1);
+    lm_transform_t(acc, ch.Mw, pose + 3, U2, g2);
+    double d = 0, mU = 0, mg = 0;
+    for (int k = 0; k < 21; k++) mU = fmax(mU, fabs(U1[k]));
+    for (int k = 0; k < 6; k++) mg = fmax(mg, fabs(g1[k]));
+    for (int k = 0; k < 21; k++) d = fmax(d, fabs(U1[k] - U2[k]) / mU);
+    for (int k = 0; k < 6; k++) d = fmax(d, fabs(g1[k] - g2[k]) / mg);
+    return d;
+}
 // closed-form chain (lm_pose_chain) vs the chain built from dR/drvec (lm_chain): max |difference| over R, Mw, K
 double probe_chain_diff(const double* pose) {
     double R1[9], dRdr[27], R2[9];

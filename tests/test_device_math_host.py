@@ -38,6 +38,8 @@ def probe():
     lib.probe_chain_diff.argtypes = [vp]
     lib.probe_chain_diff.restype = d
     lib.probe_pose_chain.argtypes = [vp, vp, vp, vp]
+    lib.probe_transform_t_diff.argtypes = [vp, vp]
+    lib.probe_transform_t_diff.restype = d
     return lib
 
 
@@ -178,6 +180,19 @@ def test_lm_normal_equations_match_numeric_jacobian(oracle, probe):
             A = Um.copy()
             A[np.diag_indices(6)] *= 1 + lam
             np.testing.assert_allclose(dx, np.linalg.solve(A, g), rtol=1e-8, atol=1e-12)
+
+
+def test_lm_transform_with_the_translation_folded_in(probe):
+    """lm_transform_t (esac_refine_team.hip's route: K = [t]x Mw never formed, B symmetric) == lm_transform on random
+    twist-space sums with the structure the kernels produce (entry (3,4) of the normal matrix zero, acc[14] = 0)."""
+    rng = np.random.default_rng(21)
+    worst = 0.0
+    for it in range(200):
+        acc = rng.normal(size=27) * 10.0 ** rng.uniform(-2, 4)
+        acc[14] = 0.0
+        pose = np.concatenate([rng.normal(size=3) * [1e-9, 0.3, 1.5][it % 3], rng.normal(size=3) * [0.1, 3.0][it % 2]])
+        worst = max(worst, probe.probe_transform_t_diff(_p(acc), _p(pose)))
+    assert worst < 1e-13, worst
 
 
 # ---------------------------------------------------------------- training path (bwd_math.hpp)

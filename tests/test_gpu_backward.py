@@ -223,7 +223,9 @@ def test_backward_matches_forward_hypotheses(engine, oracle):
     probs = engine.read(api.BUF_BWD_PROBS)
     w = int(res[api.RES_HYP])
     assert int(np.argmax(probs)) == w
-    np.testing.assert_array_equal(engine.read(api.BUF_BWD_REF_HYPS)[w], res[api.RES_RVEC:api.RES_RVEC + 6])
+    # (the forward's winner is refined by a team, the backward's slots by one workgroup each: the same re-fits with another
+    # summation order of the LM sums)
+    np.testing.assert_allclose(engine.read(api.BUF_BWD_REF_HYPS)[w], res[api.RES_RVEC:api.RES_RVEC + 6], rtol=0, atol=1e-8)
 
 
 def _fd_check(engine, oracle, max_ref_steps, rel_bar, n_cells=3):

@@ -249,12 +249,26 @@ struct LmTrig {
 ESAC_HD void lm_pose_rotation(const double param[6], double R[9], LmTrig& tg) {
 #pragma clang fp contract(fast)
     double rx = param[0], ry = param[1], rz = param[2];
-    const double theta = sqrt(rx * rx + ry * ry + rz * rz);
-    tg.theta = theta;
+    const double theta2 = rx * rx + ry * ry + rz * rz;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 1/theta from the hardware's reciprocal square root + two Newton steps, theta = theta^2 / theta: ~8 dependent
+    // operations where sqrt followed by a division is ~25 (this chain is serial in every lane, once per pass); both are
+    // good to an ulp, which is what the rotation needs (the LM fixed point does not depend on their rounding)
+    double itheta = __builtin_amdgcn_rsq(theta2);
+    itheta = itheta * __builtin_fma(-0.5 * theta2, itheta * itheta, 1.5);
+    itheta = itheta * __builtin_fma(-0.5 * theta2, itheta * itheta, 1.5);
+    const double theta = theta2 * itheta;
+    tg.identity = theta2 < DBL_EPSILON * DBL_EPSILON;  // (theta2 = 0: rsq = inf, handled here; a NaN pose stays NaN below)
+#else
+    const double theta = sqrt(theta2);
+    const double itheta = 1. / theta;
     tg.identity = theta < DBL_EPSILON;
+#endif
+    tg.theta = theta;
     if (tg.identity) {
         R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
         tg.nx = tg.ny = tg.nz = 0;
+        tg.theta = 0;
         tg.itheta = 0;
         tg.s = 0;
         tg.c1 = 0;
@@ -262,13 +276,12 @@ ESAC_HD void lm_pose_rotation(const double param[6], double R[9], LmTrig& tg) {
     }
     double c, s;
 #if defined(__HIP_DEVICE_COMPILE__)
-    sincos(theta, &s, &c);  // one argument reduction for both (this chain is serial in every lane)
+    sincos(theta, &s, &c);  // one argument reduction for both
 #else
     c = cos(theta);
     s = sin(theta);
 #endif
     const double c1 = 1. - c;
-    const double itheta = 1. / theta;
     rx *= itheta; ry *= itheta; rz *= itheta;
     const double xx = rx * rx, xy = rx * ry, xz = rx * rz, yy = ry * ry, yz = ry * rz, zz = rz * rz;
     R[0] = c + c1 * xx;      R[1] = c1 * xy - s * rz; R[2] = c1 * xz + s * ry;

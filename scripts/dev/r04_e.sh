@@ -2,7 +2,7 @@
 # round 4: whole GPU suite after the record hand-off change, then bench by team size + cycle sections
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r04e
+O=gpurun_out/r04g
 mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q --durations=8 > $O/pytest.log 2>&1
 tail -25 $O/pytest.log

@@ -71,7 +71,10 @@ def _check(engine, out, g_dev, ref, g_ref, expect_slots=None):
     # stage: refinement of every selected hypothesis, loss, dLoss, score gradients
     np.testing.assert_allclose(engine.read(api.BUF_BWD_REF_HYPS), ref["ref_hyps"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(engine.read(api.BUF_BWD_LOSSES), ref["losses"], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(engine.read(api.BUF_BWD_SCORE_GRADS), ref["score_grads"], rtol=1e-6, atol=1e-9)
+    # p_h (loss_h - E[loss]): the refined poses agree with the oracle's to ~1e-9 (the rounding of the LM sums through the
+    # damped normal equations), the losses weigh translations by w_trans = 100, and the difference of two losses loses a
+    # digit or two: 2e-5 relative
+    np.testing.assert_allclose(engine.read(api.BUF_BWD_SCORE_GRADS), ref["score_grads"], rtol=2e-5, atol=1e-9)
     dl = engine.read(api.BUF_BWD_DLOSS)[:n_sel]
     if not edge.any():
         ref_dl = ref["dloss"][sel_ref]

@@ -223,6 +223,10 @@ __device__ __forceinline__ Cam make_cam(const KArgs& a) {
 // createSampling (esac_util.h:64-66): integer pixel centre of cell (x,y), then Point2f
 // global hypothesis index: keys the RNG stream and breaks ties, independent of the sharding
 __device__ __forceinline__ int global_hyp(const KArgs& a, int h) { return a.hyp_index ? a.hyp_index[h] : a.hyp_offset + h; }
+// where hypothesis h's score goes in the caller's score vector (ESAC_FLAG_SCORES_BY_INDEX: by global index)
+__device__ __forceinline__ size_t user_slot(const KArgs& a, int h) {
+    return (a.flags & ESAC_FLAG_SCORES_BY_INDEX_K) ? (size_t)global_hyp(a, h) : (size_t)h;
+}
 __device__ __forceinline__ float cell_px(const KArgs& a, int x) { return (float)(x * a.sub + a.sub / 2 - a.shift_x); }
 __device__ __forceinline__ float cell_py(const KArgs& a, int y) { return (float)(y * a.sub + a.sub / 2 - a.shift_y); }
 

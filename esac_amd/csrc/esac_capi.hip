@@ -80,6 +80,7 @@ struct esac_hip_ctx {
     bool team_spread = false;             // ESAC_DEBUG_TEAM_SPREAD: the members are consecutive workgroups (one per XCD)
     unsigned long long refine_tag = 0;    // tag of the most recent shared (cooperative / team) refinement launch, 0: none yet
     long long team_fallbacks = 0;         // blocking calls whose team timed out and were refined again by one workgroup
+    bool fold_select = true;              // the team kernel may run the selection in its prologue (ESAC_FOLD_SELECT=0: measurement scripts)
     BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
     int bN = 0, bP = 0, bcap = 0;
     bool b_lists = false;
@@ -132,6 +133,7 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
         const int g = atoi(e);
         c->team = g < 2 ? 0 : (g > ESAC_REFINE_TEAM_MAX ? ESAC_REFINE_TEAM_MAX : g);
     }
+    if (const char* e = getenv("ESAC_FOLD_SELECT")) c->fold_select = atoi(e) != 0;
     *out = c;
     return 0;
 }
@@ -464,8 +466,10 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     else       launch_score(a, s);
     if ((rc = check_launch(exact ? "k_rescore(all)" : "k_score_fast"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[2], s));
-    if (exact) launch_stats_exact(a, s);
-    else       launch_select_rescore(a, s);
+    // a single frame of <= 256 hypotheses that a team refines: the selection runs in that kernel's prologue
+    a.fold_select = c->fold_select && refine_folds_select(a) ? 1 : 0;
+    if (exact)               launch_stats_exact(a, s);
+    else if (!a.fold_select) launch_select_rescore(a, s);
     if ((rc = check_launch(exact ? "k_stats_exact" : "k_select_rescore"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
     c->refine_tag = launch_refine(a, s);
@@ -526,6 +530,10 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             c->epoch += 1.0;
             a.epoch = c->epoch;
             a.team = 0;
+            if (a.fold_select) {  // the selection was that kernel's too
+                a.fold_select = 0;
+                launch_select_rescore(a, s);
+            }
             c->refine_tag = launch_refine(a, s);
             if ((rc = check_launch("k_refine (one workgroup, after a team time-out)"))) return rc;
             if ((rc = wait_record(c->epoch))) return rc;
@@ -561,11 +569,12 @@ extern "C" int esac_hip_time_stages(esac_hip_ctx* c, const float* d_sc, const in
     c->rt32_stale = false;
     mark_sampling(c, a);
     const bool exact = (a.flags & ESAC_FLAG_EXACT_SCORES) != 0;
+    a.fold_select = c->fold_select && refine_folds_select(a) ? 1 : 0;  // as esac_hip_forward would run it: stage 2 is then part of stage 3 (reads 0)
     auto stage = [&](int k) {
         switch (k) {
             case 0: launch_sample(a, s); break;
             case 1: if (exact) launch_rescore_all(a, s); else launch_score(a, s); break;
-            case 2: if (exact) launch_stats_exact(a, s); else launch_select_rescore(a, s); break;
+            case 2: if (exact) launch_stats_exact(a, s); else if (!a.fold_select) launch_select_rescore(a, s); break;
             default: c->refine_tag = launch_refine(a, s); break;
         }
     };

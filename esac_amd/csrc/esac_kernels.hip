@@ -136,12 +136,6 @@ __device__ __forceinline__ void store_hypothesis(const KArgs& a, int h, const fl
     a.tries[h] = tries_val;
 }
 
-// where hypothesis h's score goes in the caller's vector: local position, or its GLOBAL index (a multi-GPU shard writing
-// straight into its slots of the exchange buffer, ESAC_FLAG_SCORES_BY_INDEX)
-__device__ __forceinline__ size_t user_slot(const KArgs& a, int h) {
-    return (a.flags & ESAC_FLAG_SCORES_BY_INDEX_K) ? (size_t)global_hyp(a, h) : (size_t)h;
-}
-
 // How hard is an expert's map for the sampler?  Two counters per expert (bin e % 1024, behind the four list counters of
 // samp_count; a single frame, several experts, a few thousand hypotheses -- the shape in which most pending hypotheses are
 // easy ones): hypotheses assigned / hypotheses the first tries left pending.  An expert on whose map (nearly) every

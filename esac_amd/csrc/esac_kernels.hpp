@@ -124,6 +124,8 @@ struct KArgs {
     int team;                           // members of a refinement team on small grids (0: one workgroup refines; esac_hip_set_refine_team)
     int team_stride;                    // the team's members are the workgroups blockIdx.x % team_stride == 0 (8: one XCD; 1: debug, spread)
     int* refine_info;                   // [8] mode, members, XCD census (4 bits per XCD), same-XCD flag, exchanges, failed
+    int fold_select;                    // the team kernel also runs the selection (softmax statistics, band of contenders, their exact
+                                        // re-score) in its prologue: no k_select_rescore launch in front of it (refine_folds_select)
     // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
     int* order;           // [N] hypothesis at sorted position pos (sorted by expert)
     float* rt_sorted;     // [N,12] rt32 rows in sorted order
@@ -163,6 +165,7 @@ int refine_team_members(const KArgs& a);  // members of the team that refines a 
 unsigned long long launch_refine(const KArgs& a, hipStream_t s);  // returns the tag of a shared (cooperative / team) launch, 0 otherwise
 unsigned long long launch_refine_team(const KArgs& a, hipStream_t s);  // esac_refine_team.hip; requires refine_team_members(a) > 0
 unsigned long long next_refine_tag();
+bool refine_folds_select(const KArgs& a);  // the refinement launch of this call can (and will) do the selection itself
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);
 void launch_bwd_select(const KArgs& a, hipStream_t s);

@@ -26,6 +26,11 @@
 //     are register masks).  ~24 rounds per frame instead of ~33, same accepted points, same decisions.
 //   * ONE HOP PER ROUND between the members: refine_common.hpp, tagged granules.  The chain-rule matrices of the pose are
 //     computed while the exchange is in flight.
+//   * THE SELECTION IN THE PROLOGUE (a.fold_select: single frames of <= 256 hypotheses, the headline call).  softMax /
+//     entropy statistics of the fp32 scores, the band of contenders and their re-score in reference arithmetic
+//     (esac_util.h:235-260, 461-530 -- what k_select_rescore does in a launch of its own) run here: every member scores
+//     ITS cells for every contender, one exchange adds them up, every member picks the winner from the same totals.  A
+//     launch, its boundary and a 256-workgroup ramp less on a call whose selection re-scores one to three hypotheses.
 // All members carry the same pose and take the same decisions from bitwise identical sums; member 0 writes the outputs,
 // every member writes its cells of the inlier map once, at the end.
 #include <hip/hip_runtime.h>
@@ -199,6 +204,166 @@ __device__ __forceinline__ void team_step(const double (&U21)[21], const double 
     CYC_END(8);
 }
 
+// ---- the selection, folded into the prologue (see the header).  N <= REFINE_B: one hypothesis per thread.
+// Returns the winner (local index); win_score, nc and the record inputs come back through the references.  Writes what
+// k_select_rescore writes: scores / exact_flag / scores_user of every hypothesis, n_contenders, stats (member 0).
+constexpr int TEAM_SEL_CHUNK = 16;  // contenders re-scored per exchange (16 x 12 pose values fit one load per thread)
+template <int CPL>
+__device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>& cl, bool cells_loaded, int cell0, int cell1, const Cam& cam, Coop& co,
+                                           bool writer, double* s_part, double* s_tot, double* s_best, int* s_besti, int* s_bestg, int* s_list,
+                                           double* s_rt, double& win_score, int& nc_out, RecordInputs& rec_in) {
+    constexpr int B = REFINE_B;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int P = a.H * a.W;
+    // fp32 maximum (NaN-ignoring) and the band of contenders
+    const float fs = t < a.N ? a.fast_scores[t] : -INFINITY;
+    float m = fs;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float* s_maxf = reinterpret_cast<float*>(s_best);
+    if (lane == 0) s_maxf[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_maxf[0], s_maxf[1]), fmaxf(s_maxf[2], s_maxf[3]));
+    const float band = m - a.margin;
+    const bool cont = t < a.N && fs >= band;
+    // softmax statistics (esac_util.h:461-497) from the fp32-path scores, in double; number of contenders
+    double acc[3] = {0, 0, 0};
+    if (t < a.N) {
+        const double d = (double)fs - (double)m;
+        const double ex = exp(d);
+        acc[0] = ex;
+        acc[1] = ex * d;
+        acc[2] = cont ? 1.0 : 0.0;
+    }
+    block_sum<3, B>(acc, s_part, s_tot);
+    const int nc = (int)acc[2];
+    nc_out = nc;
+    const double entropy = log2(acc[0]) - acc[1] / (acc[0] * 0.6931471805599453);  // -sum p log2 p, p = exp(d) / S
+    if (writer && t == 0) {
+        a.n_contenders[0] = nc;
+        a.stats[0] = (double)m;
+        a.stats[1] = acc[0];
+        a.stats[2] = entropy;
+    }
+    if (writer && t < a.N && !cont) {
+        a.scores[t] = (double)fs;
+        if (a.scores_user) a.scores_user[user_slot(a, t)] = (double)fs;
+        a.exact_flag[t] = 0;
+    }
+    // the contenders, ascending
+    int* s_wcnt = s_besti;
+    const unsigned long long bal = __ballot(cont);
+    if (lane == 0) s_wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    {
+        int base = 0;
+        for (int w = 0; w < wave; w++) base += s_wcnt[w];
+        if (cont) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+    }
+    __syncthreads();
+    // exact re-score, TEAM_SEL_CHUNK contenders per exchange: every member its cells, reference arithmetic op by op
+    double bs = -INFINITY;
+    int bi = 0x7fffffff, bg = 0x7fffffff;
+    const float scale = a.alpha / a.W / a.H;  // float / int / int (esac_util.h:256)
+    for (int c0 = 0; c0 < nc; c0 += TEAM_SEL_CHUNK) {
+        const int cnt = nc - c0 < TEAM_SEL_CHUNK ? nc - c0 : TEAM_SEL_CHUNK;
+        if (t < cnt * 12) {  // R as the sampler formed it (hyps_R), t: 12 values per contender
+            const int ci = t / 12, k = t - ci * 12, h = s_list[c0 + ci];
+            s_rt[t] = k < 9 ? a.hyps_R[(size_t)h * 9 + k] : a.hyps[(size_t)h * 6 + 3 + (k - 9)];
+        }
+        __syncthreads();
+        for (int ci = 0; ci < cnt; ci++) {
+            const int h = s_list[c0 + ci];
+            double R[9], tv[3];
+#pragma unroll
+            for (int k = 0; k < 9; k++) R[k] = s_rt[ci * 12 + k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tv[k] = s_rt[ci * 12 + 9 + k];
+            const float* __restrict__ mx = a.sc + (size_t)expert_of(a, h) * 3 * P;
+            double v = 0;
+#pragma unroll
+            for (int p = 0; p < CPL; p++) {
+                const int i = cell0 + p * B + t;
+                if (i >= cell1) continue;
+                float X, Y, Z, px, py;
+                if (cells_loaded) {  // one expert: the map is the one in the registers
+                    X = (float)cl.X[p]; Y = (float)cl.Y[p]; Z = (float)cl.Z[p]; px = (float)cl.px[p]; py = (float)cl.py[p];
+                } else {
+                    const int row = i / a.W, col = i - row * a.W;
+                    X = mx[i]; Y = mx[P + i]; Z = mx[2 * P + i];
+                    px = (float)cell_pxi(a, col); py = (float)cell_pyi(a, row);
+                }
+                float err = project_exact_err(R, tv, cam, X, Y, Z, px, py);
+                err = err < a.max_reproj ? err : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+                v += soft_inlier_exact(err, a.tau, a.beta);
+            }
+            v = wave_sum(v);
+            if (lane == 0) s_part[wave * 28 + ci] = v;
+        }
+        __syncthreads();
+        double tot[TEAM_SEL_CHUNK];
+        team_publish<TEAM_SEL_CHUNK>(t < TEAM_SEL_CHUNK ? (s_part[t] + s_part[28 + t]) + (s_part[56 + t] + s_part[84 + t]) : 0.0, co);
+        team_collect<TEAM_SEL_CHUNK>(tot, co, s_tot);
+        if (co.dead) break;
+        if (t < cnt) {
+            const int h = s_list[c0 + t];
+            double sc = s_tot[t];
+            sc *= scale;  // double *= float
+            if (writer) {
+                a.scores[h] = sc;
+                if (a.scores_user) a.scores_user[user_slot(a, h)] = sc;
+                a.exact_flag[h] = 1;
+            }
+            const int g = global_hyp(a, h);
+            if (sc > bs || (sc == bs && g < bg)) {  // (one contender per thread and chunk: ascending h, so only `>` ever fires)
+                bs = sc;
+                bi = h;
+                bg = g;
+            }
+        }
+        __syncthreads();  // s_rt / s_part / s_tot are rewritten by the next chunk
+    }
+    // draw(probs, training=false): argmax of the exact scores, first (global) index on ties (esac_util.h:512-529)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(bs, o);
+        const int oi = __shfl_xor(bi, o);
+        const int og = __shfl_xor(bg, o);
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        s_best[wave] = bs;
+        s_besti[wave] = bi;
+        s_bestg[wave] = bg;
+    }
+    __syncthreads();
+    bs = s_best[0];
+    bi = s_besti[0];
+    bg = s_bestg[0];
+#pragma unroll
+    for (int w = 1; w < B / 64; w++) {
+        const double os = s_best[w];
+        const int oi = s_besti[w];
+        const int og = s_bestg[w];
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    const int win = bi == 0x7fffffff ? 0 : bi;
+    // the winner's score: a contender's exact one; with no contender at all (every score NaN) what the selection kernel
+    // leaves in scores[0]
+    win_score = bi == 0x7fffffff ? (double)a.fast_scores[0] : bs;
+    rec_in = RecordInputs{exp(win_score - (double)m) / acc[0], entropy, a.status[0]};
+    return win;
+}
+
 template <int CPL>
 __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     constexpr int B = REFINE_B;
@@ -209,6 +374,8 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     __shared__ int s_besti[B / 64];
     __shared__ int s_bestg[B / 64];
     __shared__ int s_coop_dead;
+    __shared__ int s_list[B];                        // folded selection: the contenders, ascending
+    __shared__ double s_rt[TEAM_SEL_CHUNK * 12];     // ... and the poses of a chunk of them
     __shared__ double s_pow10[33];  // 10^-16 .. 10^16: the LM damping factors
     __shared__ char s_pad[TEAM_LDS_PAD];
     if (a.team_stride < 0) s_pad[threadIdx.x] = 1;  // (never: keeps the allocation)
@@ -255,18 +422,27 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         }
     };
     if (a.E == 1) load_cells(a.sc);
-    const int nc = a.n_contenders[0];
-    const int win = refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
-    const double win_score = a.scores[win];
+    int nc, win;
+    double win_score;
     RecordInputs rec_in{0.0, 0.0, 0ull};
-    if (writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
+    double census[1] = {0.0};
+    if (a.fold_select) {
+        __syncthreads();  // (s_pow10, s_coop_dead)
+        team_collect<1>(census, co, s_tot);
+        win = team_select<CPL>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
+                               rec_in);
+    } else {
+        nc = a.n_contenders[0];
+        win = refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
+        win_score = a.scores[win];
+        if (writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
+    }
     const int e = expert_of(a, win);
     double pose[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
     if (a.E != 1) load_cells(a.sc + (size_t)e * 3 * P);
-    double census[1] = {0.0};
-    team_collect<1>(census, co, s_tot);
+    if (!a.fold_select) team_collect<1>(census, co, s_tot);
     CYC_END(1);
 
     // ---- refineHyp (esac_util.h:378-454) around ONE pass site
@@ -379,6 +555,12 @@ int refine_team_members(const KArgs& a) {
     if (G < need) G = need;
     if (a.coop_max < G * (a.team_stride > 0 ? a.team_stride : 8)) return 0;
     return G;
+}
+
+// The selection can run in the team kernel's prologue: a team refines this call, one hypothesis per thread of a member, the
+// default score route (ESAC_FLAG_EXACT_SCORES has statistics of its own), no device-side span stamps to reduce.
+bool refine_folds_select(const KArgs& a) {
+    return refine_coop_slice(a) == 0 && refine_team_members(a) > 0 && a.N <= REFINE_B && !(a.flags & ESAC_FLAG_EXACT_SCORES_K) && !a.tstamps;
 }
 
 unsigned long long launch_refine_team(const KArgs& a, hipStream_t s) {

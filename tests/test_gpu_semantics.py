@@ -481,8 +481,10 @@ def _same_refinement(a, b):
     """Two runs of one refinement that differ in how many workgroups shared it: every discrete output identical, the
     pose equal to what the rounding of the LM sums (their summation order differs) becomes through the damped normal
     equations: measured <= 6e-10, asserted 1e-8 (the bar against the oracle is 1e-6)."""
-    discrete = [api.RES_SCORE, api.RES_HYP, api.RES_EXPERT, api.RES_REF_STEPS, api.RES_INLIERS, api.RES_LM_ITERS]
+    discrete = [api.RES_HYP, api.RES_EXPERT, api.RES_REF_STEPS, api.RES_INLIERS, api.RES_LM_ITERS]
     np.testing.assert_array_equal(a["rec"][discrete], b["rec"][discrete])
+    # (the winner's exact score: a team that also runs the selection sums the cells member by member)
+    assert abs(a["rec"][api.RES_SCORE] - b["rec"][api.RES_SCORE]) <= 1e-12 * max(1.0, abs(b["rec"][api.RES_SCORE]))
     np.testing.assert_array_equal(a["counts"], b["counts"])
     np.testing.assert_array_equal(a["map"], b["map"])
     np.testing.assert_allclose(a["rec"][:31], b["rec"][:31], rtol=0, atol=1e-8)
@@ -623,3 +625,42 @@ def test_refinement_team_debug_error_image_and_step_limit(engine, oracle):
             np.testing.assert_array_equal(errs < 10.0, want < 10.0)  # the inlier side is decided exactly
     finally:
         engine.set_debug()
+
+
+def test_selection_folded_into_the_team_kernel_equals_the_selection_kernel(engine, oracle):
+    """A single frame of <= 256 hypotheses that a team refines runs the selection (softmax statistics, the band of
+    contenders, their re-score in reference arithmetic) in the refinement kernel's prologue; the same call phase by phase
+    (esac_hip_sample / _score / _select / _refine) runs k_select_rescore.  Both must leave the same score vector,
+    contender flags, winner, exact score, probability, entropy and contender count -- and the oracle's winner.  Cases:
+    one and several experts, a wide band (dozens of contenders: several exchanges of 16), a band that takes everything."""
+    cases = [dict(E=1, N=256, alpha=100.0), dict(E=3, N=200, alpha=100.0), dict(E=1, N=97, alpha=100.0, margin=30.0),
+             dict(E=2, N=64, alpha=7.0, margin=50.0)]
+    for k, c in enumerate(cases):
+        f = S.make_frame(440 + k, E=c["E"], true_expert=c["E"] - 1)
+        ha = S.gating_assignment(f, c["N"], mode="gating" if c["E"] > 1 else "single")
+        sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+        p = engine.make_params(c["E"], 60, 80, c["N"], seed=31, call=k, inlier_alpha=c["alpha"], rescore_margin=c.get("margin", 0.0))
+        rec = engine.forward_device(sc, hat, p).copy()
+        assert engine.refine_info()["mode"] == "team"
+        scores, flags = engine.read(api.BUF_SCORES).copy(), engine.read(api.BUF_EXACT_FLAGS).copy()
+        engine.sample(sc, hat, p)
+        engine.score(sc, hat, p)
+        engine.select(sc, hat, p)
+        engine.refine(sc, hat, p)
+        torch.cuda.synchronize()
+        rec2 = engine.read(api.BUF_RESULT)
+        np.testing.assert_array_equal(flags, engine.read(api.BUF_EXACT_FLAGS))
+        scores2 = engine.read(api.BUF_SCORES)
+        np.testing.assert_array_equal(scores[flags == 0], scores2[flags == 0])
+        np.testing.assert_allclose(scores[flags == 1], scores2[flags == 1], rtol=1e-12, atol=0)  # another summation order of the cells
+        for field in (api.RES_HYP, api.RES_EXPERT, api.RES_CONTENDERS, api.RES_REF_STEPS, api.RES_INLIERS, api.RES_LM_ITERS):
+            assert rec[field] == rec2[field], (k, field, rec[field], rec2[field])
+        np.testing.assert_allclose(rec[[api.RES_SCORE, api.RES_PROB, api.RES_ENTROPY]], rec2[[api.RES_SCORE, api.RES_PROB, api.RES_ENTROPY]],
+                                   rtol=1e-12, atol=0)
+        assert int(rec[api.RES_CONTENDERS]) == int(flags.sum())
+        if k == 2:
+            assert int(rec[api.RES_CONTENDERS]) > 16  # more than one exchange of contenders
+        ref = oracle.forward(f["coords"], ha, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=31, call=k,
+                             inlier_alpha=c["alpha"])
+        assert int(rec[api.RES_HYP]) == ref["winner"]
+        np.testing.assert_allclose(scores[flags == 1], ref["scores"][flags == 1], rtol=0, atol=1e-7 * max(1.0, c["alpha"]))

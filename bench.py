@@ -192,6 +192,15 @@ def load_profile(config):
     return None
 
 
+# one-GPU stage times (ms) of the BASELINE workloads, from this round's bench lines (profiles/r04_bench_<cfg>.json): the inputs of
+# `expected_scaling`.  host = ms_per_step - sum of the stages (launches, boundaries, hand-off)
+EXPECTED_T1_MS = {
+    "cfg2": {"sample": 0.0213, "score": 0.0039, "select": 0.0, "refine": 0.091, "host": 0.026},
+    "cfg3": {"sample": 0.080, "score": 0.008, "select": 0.010, "refine": 0.090, "host": 0.030},
+    "cfg4": {"sample": 0.115, "score": 0.022, "select": 0.011, "refine": 0.085, "host": 0.030},
+    "cfg5a": {"sample": 1.60, "score": 0.075, "select": 0.012, "refine": 0.095, "host": 0.030},
+    "cfg5b": {"sample": 1.81, "score": 2.70, "select": 0.035, "refine": 0.42, "host": 0.05},
+}
 STAGE_OF = (("k_sample", "sample"), ("k_bucket", "score"), ("k_score", "score"), ("k_select", "select_rescore"),
             ("k_refine", "refine"))
 # what bounds each stage: the figures are op-count models, stated there
@@ -199,7 +208,8 @@ OWN_BOUND = {
     "sample": "fp64 VALU issue (P3P in registers; 4.9 cycles per wave-instruction measured)",
     "score": "fp32 VALU issue + transcendental rate (3.0 / 8.7 cycles per wave-instruction measured); HBM only feeds it",
     "select_rescore": "latency: one launch, a few fp64 re-scores",
-    "refine": "fp64 VALU issue of the ONE CU a refinement occupies",
+    "refine": "a chain of ~25 dependent rounds: fp64 latency of the serial section every lane walks (pose chain, normal equations, 6x6 solve) + one "
+              "exchange between the 8 workgroups of the team per round (single frames on 60x80-sized grids); fp64 VALU issue of ONE CU elsewhere",
 }
 
 
@@ -218,6 +228,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="frames per launch set for the extra `batched` figure (0 = skip)")
     ap.add_argument("--no-training", action="store_true", help="skip the extra `training` (esac.backward) figure")
     ap.add_argument("--no-extras", action="store_true", help="only the contract line: no batched / training / h2d / stage legs")
+    ap.add_argument("--no-exact", action="store_true", help="skip the `value_exact` leg (the guaranteed routes)")
     args = ap.parse_args()
     preset = dict(PRESETS[args.config])
     for k in ("hyps", "experts", "grid", "policy", "scaling"):
@@ -356,6 +367,27 @@ def main():
         torch.cuda.synchronize()
         seed1305 = n_total * steps / (time.perf_counter() - t1)
         params.seed = BENCH_SEED
+    # the same K steps on the GUARANTEED routes (ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING: every score in reference
+    # arithmetic, the sampling loop try by try without the fp32 screen) -- what "score tensors identical" costs; never `value`
+    value_exact = None
+    if world == 1 and config_name in ("cfg2", "cfg3") and not args.no_exact:
+        pe = eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=0, exact_scores=True, exact_sampling=True, **kw)
+        ke = max(10, steps // (1 if config_name == "cfg2" else 4))
+        def step_exact(i):
+            pe.call = i
+            return eng.forward_device(d_coords[i % n_frames], d_assign[i % n_frames], pe, scores_out=scores)
+        for i in range(min(warmup, 10)):
+            step_exact(i)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(ke):
+            step_exact(warmup + i)
+        torch.cuda.synchronize()
+        te = time.perf_counter() - t1
+        value_exact = {"value": n_total * ke / te, "unit": "hypotheses/s", "ms_per_step": te / ke * 1e3, "steps": ke,
+                       "flags": "ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING",
+                       "note": "every hypothesis scored in the reference's float/double mix (score vector, probability, entropy = the reference's "
+                               "values to 1e-12), hypotheses sampled without the fp32 screen; never `value`"}
     def _mean_ms(name):
         v = [a.elapsed_time(b) for n, (a, b) in ar_timers if n == name]
         return float(np.mean(v)) if v else None
@@ -395,9 +427,31 @@ def main():
         }
         if seed1305 is not None:
             out["value_seed1305"] = seed1305
+        if value_exact is not None:
+            out["value_exact"] = value_exact
+        if world == 1:
+            out["refine"] = eng.refine_info()  # how the winner's refinement of the last step ran (ESAC_BUF_REFINE_INFO)
         if world > 1:
             out["allreduce_ms"] = allreduce_ms
             out["shard_build_ms"] = shard_build_ms  # esac_hip_shard_balanced, inside the timed step (policy balanced)
+            # what the design predicts, so that a measured 1/2/4/8 curve can be checked against a model: the winner's
+            # refinement runs on every rank (its local best), the collective and the pick are latency, only sampling + scoring
+            # + selection divide by the rank count.  T1_* = one-GPU stage times of this workload (profiles/r04_bench_<cfg>.json).
+            t1 = EXPECTED_T1_MS.get(config_name)
+            ar = allreduce_ms if allreduce_ms is not None else 0.04
+            fixed = (t1["refine"] if t1 else None)
+            out["expected_scaling"] = {
+                "model": "ms(N) = refine + host/boundaries + shard_build + all_reduce + pick + (sample + score + select) / N   [strong]; "
+                         "weak scaling: the divisible part stays that of one GPU",
+                "one_gpu_stage_ms": t1, "all_reduce_ms_estimate": 0.04, "all_reduce_ms_measured": allreduce_ms, "shard_build_ms_measured": shard_build_ms,
+                "pick_ms_estimate": 0.01,
+                "predicted_ms_per_step": (None if not t1 else
+                                          fixed + t1["host"] + (shard_build_ms or 0.0) + ar + 0.01 +
+                                          (t1["sample"] + t1["score"] + t1["select"]) / (world if scaling == "strong" else 1)),
+                "note": "strong scaling of the many-expert workloads is bounded by the fixed part (Amdahl); no scaling curve has been measured by "
+                        "the builder (gpurun offers one GPU)"}
+            if out["expected_scaling"]["predicted_ms_per_step"]:
+                out["expected_scaling"]["predicted_value"] = n_total / (out["expected_scaling"]["predicted_ms_per_step"] * 1e-3)
         if world == 1:
             out["phase_ms"] = {"sample_p3p": float(phase[0]), "score": float(phase[1]), "select_rescore": float(phase[2]),
                                "refine": float(phase[3]), "gpu_total": float(phase[4]), "event_bracket_overhead": float(phase[5]),

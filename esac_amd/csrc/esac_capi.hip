@@ -251,6 +251,10 @@ static bool want_tiled(const esac_hip_params* p, const float* d_sc, int B) {
                        p->E <= ESAC_TILED_MAX_EXPERTS && P >= 4;
     const long long partial_bytes = (long long)tiled_sub_tiles((int)P) * p->N * 4;
     if (!legal || partial_bytes > (4LL << 30) || (p->flags & ESAC_FLAG_SCORE_STREAM)) return false;
+    // the tile kernel folds k = |beta| log2(e) into the pose rows and multiplies by 2^(-+k tau) after the exp2: beyond
+    // k tau ~ 126 that constant under- / overflows (scores NaN or saturated); the stream keeps the subtraction in the
+    // exponent and is right for any parameters
+    if (!(fabsf(p->inlier_beta) * 1.4426950408889634f * fabsf(p->inlier_thresh) <= 100.0f)) return false;
     if (p->flags & ESAC_FLAG_SCORE_TILED) return true;
     return P >= 32768 && p->N >= 64;
 }

@@ -798,11 +798,14 @@ __device__ __forceinline__ f32x2 soft_inlier_fast2(const PoseF& p, float fx, flo
     const f32x2 xc = __builtin_elementwise_fma(splat2(p.r0), X, __builtin_elementwise_fma(splat2(p.r1), Y, __builtin_elementwise_fma(splat2(p.r2), Z, splat2(p.t0))));
     const f32x2 yc = __builtin_elementwise_fma(splat2(p.r3), X, __builtin_elementwise_fma(splat2(p.r4), Y, __builtin_elementwise_fma(splat2(p.r5), Z, splat2(p.t1))));
     const f32x2 zc = __builtin_elementwise_fma(splat2(p.r6), X, __builtin_elementwise_fma(splat2(p.r7), Y, __builtin_elementwise_fma(splat2(p.r8), Z, splat2(p.t2))));
-    const f32x2 iz = {(zc.x != 0.0f) ? __builtin_amdgcn_rcpf(zc.x) : 1.0f, (zc.y != 0.0f) ? __builtin_amdgcn_rcpf(zc.y) : 1.0f};
-    const f32x2 du = px - __builtin_elementwise_fma(splat2(fx), xc * iz, splat2(cx));
-    const f32x2 dv = splat2(py) - __builtin_elementwise_fma(splat2(fy), yc * iz, splat2(cy));
-    const f32x2 d2 = __builtin_elementwise_fma(du, du, dv * dv);
-    const f32x2 err = {fminf(__builtin_amdgcn_sqrtf(d2.x), max_reproj), fminf(__builtin_amdgcn_sqrtf(d2.y), max_reproj)};
+    // err = sqrt(d2n) / |zc|, d2n = ((px - cx) zc - fx xc)^2 + ((py - cy) zc - fy yc)^2, as d2n * rsq(d2n zc^2): one
+    // transcendental instead of rcp + sqrt (esac_score_tiled.hip: soft_inlier_tile2 has the edge cases)
+    const f32x2 da = __builtin_elementwise_fma(px - splat2(cx), zc, -(splat2(fx) * xc));
+    const f32x2 db = __builtin_elementwise_fma(splat2(py - cy), zc, -(splat2(fy) * yc));
+    const f32x2 d2n = __builtin_elementwise_fma(da, da, db * db);
+    const f32x2 q = __builtin_elementwise_fma(d2n, zc * zc, splat2(1e-36f));
+    const f32x2 er = d2n * f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+    const f32x2 err = {fminf(er.x, max_reproj), fminf(er.y, max_reproj)};
     const f32x2 arg = (err - splat2(tau)) * splat2(beta_log2e);
     const f32x2 den = splat2(1.0f) + f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
     return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
@@ -842,7 +845,6 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
             const int col = (i - row * wq) << 2;
             const float py = cell_py(a, row);
             const float px = cell_px(a, col);
-#ifndef ESAC_STREAM_SCALAR
             const f32x2 s01 = soft_inlier_fast2(p, fx, fy, cx, cy, f32x2{X.x - o.x, X.y - o.x}, f32x2{Y.x - o.y, Y.y - o.y}, f32x2{Z.x - o.z, Z.y - o.z},
                                                 f32x2{px, px + step}, py, a.max_reproj, beta_log2e, a.tau);
             const f32x2 s23 = soft_inlier_fast2(p, fx, fy, cx, cy, f32x2{X.z - o.x, X.w - o.x}, f32x2{Y.z - o.y, Y.w - o.y}, f32x2{Z.z - o.z, Z.w - o.z},
@@ -851,12 +853,6 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
             acc += s01.y;
             acc += s23.x;
             acc += s23.y;
-#else
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.x - o.x, Y.x - o.y, Z.x - o.z, px, py, a.max_reproj, beta_log2e, a.tau);
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.y - o.x, Y.y - o.y, Z.y - o.z, px + step, py, a.max_reproj, beta_log2e, a.tau);
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.z - o.x, Y.z - o.y, Z.z - o.z, px + 2 * step, py, a.max_reproj, beta_log2e, a.tau);
-            acc += soft_inlier_fast(p, fx, fy, cx, cy, X.w - o.x, Y.w - o.y, Z.w - o.z, px + 3 * step, py, a.max_reproj, beta_log2e, a.tau);
-#endif
         }
     } else {
         for (int i = threadIdx.x; i < P; i += B) {
@@ -1321,7 +1317,10 @@ void launch_sample(const KArgs& a, hipStream_t s) {
 #define ESAC_CHAIN_PER_HYP 8
 #endif
     const long long w8 = (a.E == 1 ? 1LL : (long long)ESAC_CHAIN_PER_HYP) * total;
-    const int waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > 131072 ? 131072 : w8));
+    // (every pending hypothesis needs at least ONE wavefront: wavefront L serves list entry L % count, so a launch smaller
+    // than the list would leave its tail unscreened -- beyond 131072 hypotheses the launch grows with them)
+    const long long wcap = total > 131072 ? total : 131072;
+    const int waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > wcap ? wcap : w8));
     if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
         if (handover) b.handover = ESAC_HANDOVER;
         // up to 256 hypotheses: four wavefronts each (64 tries per round, one workgroup per CU at this kernel's ~440

@@ -27,10 +27,7 @@
 
 namespace esac {
 
-#ifndef ESAC_TILE_CPT
-#define ESAC_TILE_CPT 12
-#endif
-constexpr int TILE_CPT = ESAC_TILE_CPT;     // cells per lane (a multiple of 4)
+constexpr int TILE_CPT = 12;     // cells per lane (a multiple of 4)
 constexpr int TILE_CELLS = 64 * TILE_CPT;   // cells per sub-tile (one wavefront)
 constexpr int BUCKET_B = 1024;
 
@@ -169,19 +166,6 @@ __device__ __forceinline__ PoseU pose_of(const sgpr4& q0, const sgpr4& q1, const
 
 // one cell: 1 / (1 + exp(beta (min(err, maxReproj) - tau))), err = |pixel - projection|.  Everything arrives scaled by
 // k = |beta| log2(e) (rows A, B, px, py, kmax = k maxReproj); c0 = 2^(-k tau); NEG: beta < 0 (the exponent changes sign).
-template <bool NEG>
-__device__ __forceinline__ float soft_inlier_tile(const PoseU& p, float X, float Y, float Z, float px, float py, float kmax, float c0) {
-    const float un = fmaf(p.a0, X, fmaf(p.a1, Y, fmaf(p.a2, Z, p.ta)));
-    const float vn = fmaf(p.b0, X, fmaf(p.b1, Y, fmaf(p.b2, Z, p.tb)));
-    const float zc = fmaf(p.c0, X, fmaf(p.c1, Y, fmaf(p.c2, Z, p.tc)));
-    // zc == 0 exactly: rcp = inf, the error clamps to maxReproj (the reference's `z ? 1/z : 1` guard differs there only)
-    const float iz = __builtin_amdgcn_rcpf(zc);
-    const float du = fmaf(-un, iz, px);
-    const float dv = fmaf(-vn, iz, py);
-    const float err = fminf(__builtin_amdgcn_sqrtf(fmaf(du, du, dv * dv)), kmax);  // fminf drops a NaN operand
-    return __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(NEG ? -err : err), c0, 1.0f));
-}
-
 // two cells at a time with packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32: 4.9 cycles for two operations against
 // 3.0 for one, scripts/dev/valu_rate.hip); the four transcendentals and the clamp have no packed form
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -191,11 +175,17 @@ __device__ __forceinline__ f32x2 soft_inlier_tile2(const PoseU& p, f32x2 X, f32x
     const f32x2 un = __builtin_elementwise_fma(splat2(p.a0), X, __builtin_elementwise_fma(splat2(p.a1), Y, __builtin_elementwise_fma(splat2(p.a2), Z, splat2(p.ta))));
     const f32x2 vn = __builtin_elementwise_fma(splat2(p.b0), X, __builtin_elementwise_fma(splat2(p.b1), Y, __builtin_elementwise_fma(splat2(p.b2), Z, splat2(p.tb))));
     const f32x2 zc = __builtin_elementwise_fma(splat2(p.c0), X, __builtin_elementwise_fma(splat2(p.c1), Y, __builtin_elementwise_fma(splat2(p.c2), Z, splat2(p.tc))));
-    const f32x2 iz = {__builtin_amdgcn_rcpf(zc.x), __builtin_amdgcn_rcpf(zc.y)};
-    const f32x2 du = __builtin_elementwise_fma(-un, iz, px);
-    const f32x2 dv = __builtin_elementwise_fma(-vn, iz, splat2(py));
-    const f32x2 d2 = __builtin_elementwise_fma(du, du, dv * dv);
-    const f32x2 err = {fminf(__builtin_amdgcn_sqrtf(d2.x), kmax), fminf(__builtin_amdgcn_sqrtf(d2.y), kmax)};
+    // err = |pixel - projection| = sqrt(d2n) / |zc| with d2n = (px zc - un)^2 + (py zc - vn)^2, formed as d2n * rsq(d2n zc^2):
+    // ONE transcendental (v_rsq_f32) where 1/zc and the square root were two -- 3 per cell with the sigmoid's exp2 and rcp
+    // (k_score_tiled 2.71 -> 2.65 ms, k_score_fast<256> 74.8 -> 68.5 us, same box).  The sign of zc drops out (no
+    // cheirality test, as in the reference); + 1e-36 keeps d2n = 0 at err = 0 and sends zc = 0 to the maxReproj clamp; a NaN
+    // anywhere ends in fminf(NaN, kmax) = kmax.
+    const f32x2 da = __builtin_elementwise_fma(px, zc, -un);
+    const f32x2 db = __builtin_elementwise_fma(splat2(py), zc, -vn);
+    const f32x2 d2n = __builtin_elementwise_fma(da, da, db * db);
+    const f32x2 q = __builtin_elementwise_fma(d2n, zc * zc, splat2(1e-36f));
+    const f32x2 er = d2n * f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+    const f32x2 err = {fminf(er.x, kmax), fminf(er.y, kmax)};
     const f32x2 ex = {__builtin_amdgcn_exp2f(NEG ? -err.x : err.x), __builtin_amdgcn_exp2f(NEG ? -err.y : err.y)};
     const f32x2 den = __builtin_elementwise_fma(ex, splat2(c0), splat2(1.0f));
     return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
@@ -253,7 +243,7 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
         // the next pose's scalar loads are in flight during this hypothesis' ~200 VALU instructions (clamped: no branch)
         pose_issue(poses + (size_t)(i + 1 < count ? i + 1 : i) * 12, n0, n1, n2);
         const PoseU cur = pose_of(c0, c1, c2);
-#ifndef ESAC_TILE_SCALAR  // packed: 2.80 ms against 3.67 ms scalar on config 5b (A/B: -DESAC_TILE_SCALAR)
+        // two cells per packed instruction: 2.80 ms against 3.67 ms for the scalar form on config 5b (round 2)
         f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
         for (int u = 0; u < TILE_CPT; u += 2)
@@ -261,14 +251,6 @@ __global__ __launch_bounds__(64) void k_score_tiled(KArgs a) {
                                             soft_inlier_tile2<NEG>(cur, f32x2{X[u], X[u + 1]}, f32x2{Y[u], Y[u + 1]}, f32x2{Z[u], Z[u + 1]},
                                                                    f32x2{px[u], px[u + 1]}, py[u >> 2], kmax, e0), acc);
         const float acc0 = acc.x, acc1 = acc.y;
-#else
-        float acc0 = 0.0f, acc1 = 0.0f;
-#pragma unroll
-        for (int u = 0; u < TILE_CPT; u += 2) {
-            acc0 = fmaf(m[u >> 2], soft_inlier_tile<NEG>(cur, X[u], Y[u], Z[u], px[u], py[u >> 2], kmax, e0), acc0);
-            acc1 = fmaf(m[u >> 2], soft_inlier_tile<NEG>(cur, X[u + 1], Y[u + 1], Z[u + 1], px[u + 1], py[u >> 2], kmax, e0), acc1);
-        }
-#endif
         const float tot = wave_sum(acc0 + acc1);  // the same total in every lane
         if ((i & 63) == lane) res = tot;
         if ((i & 63) == 63) {  // 64 partial sums gathered across the lanes: one coalesced 256-byte store

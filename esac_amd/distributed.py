@@ -216,7 +216,7 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
     if policy == "range":
         # the returned score vector is a view of the persistent buffer: valid until the next call on this device
         buf = contribute_range(engine, scene_coords, ha_full, params_kw, rank, world, _exchange_buffer(dev, n_total, world))
-        if world > 1:
+        if dist.is_initialized():  # (also in a one-rank group: the collective's dtype / stream path is then the one N ranks take)
             _all_reduce_sum(buf, group, timers)  # the one collective of this path
         return pick_global(buf, n_total, world, engine)
     if policy == "balanced":
@@ -253,7 +253,7 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
         buf[gidx_dev.to(torch.long)] = scores_local
         if owned:
             record[2] = record[2] * world + rank  # local map index -> global expert id (esac.cpp:189 returns it)
-    if world > 1:
+    if dist.is_initialized():  # (also in a one-rank group: the collective's dtype / stream path is then the one N ranks take)
         _all_reduce_sum(buf, group, timers)  # the one collective of this path
     return pick_global(buf, n_total, world, engine)
 
@@ -265,7 +265,7 @@ _balanced_ws = {}
 def _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, group, maps, timers):
     """policy "balanced": contribute_balanced, one all-reduce, device-side pick."""
     buf = contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps, timers)
-    if world > 1:
+    if dist.is_initialized():  # (also in a one-rank group: the collective's dtype / stream path is then the one N ranks take)
         _all_reduce_sum(buf, group, timers)  # the one collective of this path
     return pick_global(buf, int(ha_full.shape[0]), world, engine)
 

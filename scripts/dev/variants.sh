@@ -3,10 +3,9 @@
 R=$GRAFT_REPO_ROOT
 cd $R
 ARGS=$1; shift
-SRC="esac_amd/csrc/esac_kernels.hip esac_amd/csrc/esac_score_tiled.hip esac_amd/csrc/esac_refine.hip esac_amd/csrc/esac_backward.hip esac_amd/csrc/esac_capi.hip"
 for v in "$@"; do
   name=${v%%=*}; flags=${v#*=}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $flags $SRC -o /tmp/lib_$name.so 2>/dev/null &
+  python esac_amd/build.py /tmp/lib_$name.so $flags > /dev/null 2>&1 &
 done
 wait
 for rep in 1 2; do

@@ -32,7 +32,10 @@ def test_forward_sharded_world1_matches_plain(engine, policy):
         sc = torch.from_numpy(f["coords"]).cuda()
         hat = torch.from_numpy(ha).cuda()
         kw = dict(seed=1305, call=8)
-        scores_g, best = D.forward_sharded(engine, sc, hat, kw, policy=policy)
+        timers = []
+        scores_g, best = D.forward_sharded(engine, sc, hat, kw, policy=policy, timers=timers)
+        # the ONE collective has run -- a one-rank RCCL all-reduce(SUM) of the real float64 exchange buffer on the launch stream
+        assert [n for n, _ in timers].count("allreduce") == 1
         p = engine.make_params(3, 60, 80, 192, **kw)
         res = engine.forward_device(sc, hat, p)
         assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]) and int(best[api.RES_EXPERT]) == int(res[api.RES_EXPERT])

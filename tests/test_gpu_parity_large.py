@@ -104,6 +104,45 @@ def test_tiled_score_equals_the_per_hypothesis_stream(engine, oracle, shape):
     np.testing.assert_allclose(s_t[f_t], ref["scores"][f_t], rtol=0, atol=1e-7)
 
 
+def test_more_pending_hypotheses_than_the_screened_chain_used_to_launch_wavefronts(engine, oracle):
+    """140,000 hypotheses over two experts with the screened chain starting at try 0: more pending hypotheses than the
+    131072 wavefronts the chain's launch was once capped at -- wavefront L serves list entry L % count, so every entry
+    needs a wavefront of its own.  Sampled cells and accepted tries of ALL hypotheses against the oracle (a small try
+    budget keeps the oracle's wrong-expert searches short; an exhausted budget is -1 on both sides)."""
+    N = 140000
+    f = S.make_frame(230, E=2, true_expert=1)
+    ha = S.gating_assignment(f, N, mode="gating")
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    kw = dict(focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=9, call=2, max_tries=48)
+    engine.sample(sc, hat, engine.make_params(2, 60, 80, N, **kw))
+    tries, xy = engine.read(api.BUF_TRIES), engine.read(api.BUF_SAMPLE_XY)
+    ref = oracle.sample(f["coords"], ha, **kw) if hasattr(oracle, "sample") else oracle.forward(f["coords"], ha, max_ref_steps=0, **kw)
+    np.testing.assert_array_equal(tries, ref["tries"])
+    np.testing.assert_array_equal(xy, ref["sample_xy"])
+    assert (tries == -1).any() and (tries >= 32).any()
+
+
+def test_large_beta_tau_on_a_tiled_size_grid(engine, oracle):
+    """beta * tau beyond the range of the tile kernel's folded sigmoid constant (2^(-k tau), k = |beta| log2 e, underflows
+    from k tau ~ 126): the C ABI must route such calls to the per-hypothesis stream -- also when the tiled shape is ASKED
+    for -- and the scores must stay finite and within the band of the reference arithmetic."""
+    H, W, sub, E, N = 128, 160, 4, 2, 300
+    f = S.make_frame(212, E=E, true_expert=1, H=H, W=W, sub=sub)
+    ha = S.gating_assignment(f, N, mode="gating")
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    for beta, tau in ((9.0, 10.0), (0.5, 400.0), (-9.0, 10.0)):
+        kw = dict(shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=sub, seed=3, call=9,
+                  inlier_beta=beta, inlier_thresh=tau, max_reproj=max(100.0, 2 * tau))
+        ref = oracle.forward(f["coords"], ha, **kw)
+        for mode in ("auto", "tiled"):
+            res = engine.forward_device(sc, hat, engine.make_params(E, H, W, N, score_shape=mode, **kw))
+            scores, flags = engine.read(api.BUF_SCORES), engine.read(api.BUF_EXACT_FLAGS).astype(bool)
+            assert np.isfinite(scores).all(), (beta, tau, mode)
+            d = np.abs(scores[~flags] - ref["scores"][~flags])
+            assert np.sort(d)[-3:].max() <= 2 * 100.0 / (H * W) + 2e-3, (beta, tau, mode, d.max())
+            assert int(res[api.RES_HYP]) == ref["winner"], (beta, tau, mode)
+
+
 def test_packed_map_copy_for_the_sampler(engine, oracle):
     """ESAC_FLAG_PACK_MAPS (taken by default for maps far beyond the caches): the sampler gathers (x,y,z) records from a
     packed copy of the maps -- sampled cells, accepted tries and everything downstream must not change.  5000 hypotheses

@@ -166,9 +166,7 @@ __device__ __forceinline__ void mark_pending(const KArgs& a, int h, int e, bool 
     if (expert_stats_on(a)) atomicAdd(expert_stats(a, e) + 1, 1);
 }
 constexpr int FIRST_PHASE_TRIES = 32;  // tries per hypothesis before the screened chain takes over
-#ifndef ESAC_FIRST_WIDE_MAX
-#define ESAC_FIRST_WIDE_MAX 8192  // up to this many hypotheses: one pass, 32 lanes per hypothesis (else two passes of 16)
-#endif
+constexpr int ESAC_FIRST_WIDE_MAX = 8192;  // up to this many hypotheses: one pass, 32 lanes per hypothesis (else two passes of 16)
 
 // Throughput shape, first phase: a hypothesis on a usable map is accepted within its first few tries, so a whole
 // wavefront per hypothesis solves ~60 P3P problems nobody needs.  Here a wavefront serves SEVERAL hypotheses, TRIES tries
@@ -389,9 +387,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
 // wide: a lone maybe would otherwise cost the whole wavefront a full fp64 solve.  The queue is flushed when it holds
 // SCREEN_FLUSH tries, when the screen itself sees a 4th point within tau (almost certainly the accepted try), and at
 // the end of the budget.
-#ifndef ESAC_CHAIN_WAVES
-#define ESAC_CHAIN_WAVES 8192  // wavefronts of the screened search that work whatever the number of pending hypotheses is
-#endif
+constexpr int ESAC_CHAIN_WAVES = 8192;  // wavefronts of the screened search that work whatever the number of pending hypotheses is
 constexpr int ESAC_RESIDENT_WAVES = 2048;  // k_sample_prescreen: 256 CUs x 4 SIMDs x 2
 constexpr float SCREEN_MARGIN = 3.0f;  // pixels; the largest screen error of an fp64-accepted try in calibration: tau + 0.008
 constexpr int SCREEN_FLUSH = 8;
@@ -438,7 +434,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int fr = entry / a.N, h = entry - fr * a.N;
     frame_view(a, fr);
     const int e = expert_of(a, h);
-#ifndef ESAC_NO_HELPER_CLASSES
     // Few hypotheses pending (several helpers of a hypothesis are resident AT ONCE and walk its rounds in lockstep): an EASY
     // hypothesis -- its expert settled most of its hypotheses in the first tries -- is accepted in its first round, and
     // every further helper is a wasted round (and a dozen "maybe" tries for k_sample_decide) that a wrong-expert straggler
@@ -453,7 +448,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int* st = expert_stats(a, e);
         if (2 * st[1] < st[0]) return;
     }
-#endif
     const int P = a.H * a.W;
     const float* __restrict__ map = a.sc + (size_t)e * 3 * P;
     const Philox rng(a.seed, a.call);
@@ -461,13 +455,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t gh = (uint32_t)global_hyp(a, h);
     const float thr = a.tau + SCREEN_MARGIN;
     int* resume = a.samp_resume + h;
-#ifndef ESAC_STALE_STOP
     // the stop flag one round old is fine while a hypothesis has one helper at a time (thousands pending); with the chip's
     // 2048 resident wavefronts on a few dozen hypotheses it is a whole superfluous round of every one of them
     const bool fresh = count <= ESAC_RESIDENT_WAVES;
-#else
-    const bool fresh = false;
-#endif
     // Two round trips to L2 per 64-try round used to sit on this loop's critical path (~1.5 us each against ~6 us of
     // arithmetic, at two wavefronts per SIMD): the ticket for the round (atomicAdd with return) and, whenever a lane said
     // "maybe" (a third of the rounds), the slot in the global list.  The ticket for the NEXT round is now drawn while the
@@ -651,13 +641,11 @@ __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
     __shared__ int s_queue[SCREEN_QUEUE];
     frame_view(a);
     const int h = blockIdx.x, lane = threadIdx.x;
-#ifndef ESAC_ALWAYS_RESET
     // the last kernel of the screened chain leaves the chain's counters (list lengths, per-expert counters) at zero for the
     // next call: nothing after k_sample_decide reads them, and a fill in front of every sampling launch is a 3 us
     // launch and a kernel boundary on a 250 us call (esac_capi.hip zeroes them when the workspace is allocated)
     if (RESUME && blockIdx.x == 0 && blockIdx.y == 0)
         for (int i = lane; i < 4 + 2 * ESAC_STAT_BINS; i += 64) a.samp_count[i] = 0;
-#endif
     // (RESUME: the list builders marked what is pending -- also when the chain started at try 0)
     if ((RESUME || a.first_try > 0) && a.tries[h] != SAMPLE_PENDING) return;
     if (!RESUME && a.first_try == 0 && lane == 0) flag_bad_assignment(a, h);
@@ -1287,9 +1275,6 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     // entries of the "maybe" list, hypotheses of the pending list (+ the per-expert counters behind them, see expert_stats)
     // are zero between calls: the last kernel of the screened chain clears them (k_sample_screened<true>).  A fill in front
     // of every sampling launch cost the headline call, which never appends to them, 5 us (0.2058 -> 0.2010 ms).
-#ifdef ESAC_ALWAYS_RESET
-    (void)hipMemsetAsync(a.samp_count, 0, (4 + 2 * ESAC_STAT_BINS) * sizeof(int), s);
-#endif
     KArgs b = a;
     b.handover = 0x7fffffff;
     // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on four lanes at first)
@@ -1302,20 +1287,14 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     // screened chain)
     const bool exact = (a.flags & ESAC_FLAG_EXACT_SAMPLING_K) != 0;
     const bool handover = a.E > 1 && a.max_tries > 1024 && !exact;
-#ifndef ESAC_LATENCY_MAX
-#define ESAC_LATENCY_MAX 1024
-#endif
-#ifndef ESAC_HANDOVER
-#define ESAC_HANDOVER 32  // (64: k_sample<128> 41 us + screened search 29 us at config 3; 32: 30 + 31 us)
-#endif
+constexpr int ESAC_LATENCY_MAX = 1024;
+constexpr int ESAC_HANDOVER = 32;  // (64: k_sample<128> 41 us + screened search 29 us at config 3; 32: 30 + 31 us)
     // wavefronts of the screened chain: every one of them works whatever the number of pending hypotheses is (they take the
     // 64-try rounds of the hypotheses on the list in order), so the launch is sized for the chip -- 2048 wavefronts are
     // resident at two per SIMD -- with some slack for the tail; when (nearly) every hypothesis is pending, as in the
     // 50-expert workloads, eight per hypothesis measured best (A/B on one box, config 5a: 4 / 8 / 32 per hypothesis ->
     // 2.00 / 1.95 / 2.18 ms)
-#ifndef ESAC_CHAIN_PER_HYP
-#define ESAC_CHAIN_PER_HYP 8
-#endif
+constexpr int ESAC_CHAIN_PER_HYP = 8;
     const long long w8 = (a.E == 1 ? 1LL : (long long)ESAC_CHAIN_PER_HYP) * total;
     // (every pending hypothesis needs at least ONE wavefront: wavefront L serves list entry L % count, so a launch smaller
     // than the list would leave its tail unscreened -- beyond 131072 hypotheses the launch grows with them)
@@ -1335,12 +1314,10 @@ void launch_sample(const KArgs& a, hipStream_t s) {
         if (total <= ESAC_FIRST_WIDE_MAX) {
             hipLaunchKernelGGL(k_sample_first<32>, dim3((a.N + 1) / 2, a.frames), dim3(64), 0, s, b);
             b.first_try += 32;
-#ifndef ESAC_KEEP_FIRST_PHASE
         } else if (a.E > 1 && !exact) {
             // tens of thousands of hypotheses over many experts (config 5: 16384 over 50, Dirichlet gating): nearly all of them
             // sit on wrong experts, where 32 tries in full fp64 are 32 solves for nothing -- the screened chain takes them
             // from try 0 (a hypothesis of the right expert costs it one screened round and a handful of fp64 decisions)
-#endif
         } else {
             for (int pass = 0; pass < FIRST_PHASE_TRIES / 16 && b.first_try < a.max_tries; pass++) {
                 hipLaunchKernelGGL(k_sample_first<16>, dim3((a.N + 3) / 4, a.frames), dim3(64), 0, s, b);
@@ -1352,6 +1329,9 @@ void launch_sample(const KArgs& a, hipStream_t s) {
                 hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);  // every try solved in full
             } else {
                 hipLaunchKernelGGL(k_pending_list, dim3((a.N + 1023) / 1024, a.frames), dim3(1024), 0, s, b);
+                // (the list stays in hypothesis order: expert-major and dealt to the XCDs, the full-resolution workload's
+                // gathers hit L2 at 0.59 instead of 0.07 and fetch 4.8 GB instead of 11.1 GB per call -- and the kernel takes
+                // the same 1.7 ms: it does not wait for them.  profiles/r04_cfg5b_pending_order.txt, LAB_NOTES.md)
                 launch_sample_stragglers(b, waves, s);
             }
         }
@@ -1383,9 +1363,7 @@ void launch_select_rescore(const KArgs& a, hipStream_t s) {
     const int split = (long long)a.H * a.W >= 32768 ? ESAC_SELECT_SPLIT : 1;
     const int cap = (a.frames > 1 ? 16 : 256) / split;
     const int grid = a.N < cap ? a.N : (cap < 1 ? 1 : cap);
-#ifndef ESAC_SELECT_B
-#define ESAC_SELECT_B 1024  // threads of the single-frame variant (A/B: scripts/dev/variants.sh)
-#endif
+constexpr int ESAC_SELECT_B = 1024;  // threads of the single-frame variant (A/B: scripts/dev/variants.sh)
     if (split == 1 && a.N <= grid) hipLaunchKernelGGL((k_select_rescore<ESAC_SELECT_B, false>), dim3(grid, a.frames), dim3(ESAC_SELECT_B), 0, s, a);
     else                           hipLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, a);
 }

@@ -152,6 +152,7 @@ void launch_hyps_to_rt32(const KArgs& a, hipStream_t s);
 void launch_score_fast(const KArgs& a, hipStream_t s);
 void launch_score(const KArgs& a, hipStream_t s);  // the fp32 score in the shape the C ABI chose (a.partials != null: tiled)
 void launch_score_tiled(const KArgs& a, hipStream_t s);
+void launch_bucket_order(const KArgs& a, hipStream_t s);  // esac_score_tiled.hip: order[] = hypotheses sorted by expert
 int tiled_sub_tiles(int P);
 void launch_select_rescore(const KArgs& a, hipStream_t s);
 void launch_rescore_all(const KArgs& a, hipStream_t s);

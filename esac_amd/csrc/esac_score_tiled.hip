@@ -297,11 +297,16 @@ __global__ __launch_bounds__(256) void k_score_tiled_reduce(KArgs a) {
 
 int tiled_sub_tiles(int P) { return (P + TILE_CELLS - 1) / TILE_CELLS; }
 
-void launch_score_tiled(const KArgs& a, hipStream_t s) {
+// order[] (hypotheses sorted by expert), chunks, rt_sorted from the assignment vector (and the current rt32 rows)
+void launch_bucket_order(const KArgs& a, hipStream_t s) {
     (void)hipMemsetAsync(a.bucket_fill, 0, (size_t)a.E * sizeof(int), s);
     hipLaunchKernelGGL(k_bucket_count, dim3((a.N + BUCKET_B - 1) / BUCKET_B), dim3(BUCKET_B), 0, s, a);
     hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(BUCKET_B), 0, s, a);
     hipLaunchKernelGGL(k_bucket_scatter, dim3((a.N + BUCKET_B - 1) / BUCKET_B), dim3(BUCKET_B), 0, s, a);
+}
+
+void launch_score_tiled(const KArgs& a, hipStream_t s) {
+    launch_bucket_order(a, s);
     const long long per_xcd = (long long)((a.n_sub + 7) / 8) * a.n_chunks_max;
     if (a.beta < 0) hipLaunchKernelGGL(k_score_tiled<true>, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, s, a);
     else            hipLaunchKernelGGL(k_score_tiled<false>, dim3((unsigned)(per_xcd * 8)), dim3(64), 0, s, a);

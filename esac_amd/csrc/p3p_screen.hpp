@@ -28,9 +28,7 @@ ESAC_HD float dotf(V3f a, V3f b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 ESAC_HD V3f crossf(V3f a, V3f b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
 #define ESAC_SCREEN_MAYBE (-1.0f)
-#ifndef ESAC_SCREEN_CONGRUENCE
-#define ESAC_SCREEN_CONGRUENCE 1e-3f
-#endif
+constexpr float ESAC_SCREEN_CONGRUENCE = 1e-3f;
 
 // ---- the screen's private copy of the roots and depths ------------------------------------------------------------------------
 // p3p_setup / p3p_candidate_lengths (pose_math.hpp) follow the CPU solver operation by operation -- IEEE mul and add, the
@@ -96,10 +94,6 @@ struct ScreenSetup {
 #ifndef ESAC_SCREEN_STAT
 #define ESAC_SCREEN_STAT(k)
 #endif
-#ifdef ESAC_SCREEN_NOGUARD  // A/B switches (scripts/dev/kvariants.sh): what the propagated bounds cost, as a whole / per part
-#define ESAC_SCREEN_NOGUARD_Q
-#define ESAC_SCREEN_NOGUARD_R
-#endif
 #ifndef ESAC_SCREEN_HIST
 #define ESAC_SCREEN_HIST(k, v)
 #endif
@@ -159,18 +153,10 @@ ESAC_HD double cbrt_pos(double a) {
 // is not reproducible to SCREEN_REL, the try is "maybe" (decided by the exact route).  The probe
 // (tests/native/p3p_screen_probe.cpp, scripts/dev/screen_adversarial.py) runs this code against the exact route on
 // planar / fronto-parallel / spherical / warped maps where every sample is a near-double-root configuration.
-#ifndef SCREEN_CU
-#define SCREEN_CU (2 * 2.220446049250313e-16)
-#endif
-#ifndef SCREEN_SIG
-#define SCREEN_SIG 250.0
-#endif
-#ifndef SCREEN_REL
-#define SCREEN_REL 1e-2
-#endif
-#ifndef SCREEN_FERRARI_SAFETY
-#define SCREEN_FERRARI_SAFETY 1e3
-#endif
+constexpr double SCREEN_CU = (2 * 2.220446049250313e-16);
+constexpr double SCREEN_SIG = 250.0;
+constexpr double SCREEN_REL = 1e-2;
+constexpr double SCREEN_FERRARI_SAFETY = 1e3;
 // real roots of the quartic, Ferrari through the first real root of the resolvent cubic: the branch structure of
 // quartic_real_roots / cubic_first_roots (pose_math.hpp), contracted arithmetic, fast cubic root.
 // ua..ue: bounds of the coefficients' differences between the two routes; dx01 / dx23: bound of the difference of the
@@ -194,13 +180,8 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
     // resolvent: y^3 - c y^2 + (d b - 4 e) y + (4 c e - d^2 - b^2 e)
     const double cb = -c, cc = d * b - 4 * e, cd = 4 * c * e - d * d - b2 * e;
     const float eps4 = 8.9e-16f;
-#ifndef ESAC_SCREEN_NOGUARD_Q
     const float ucc = fd * ub + fb * ud + 4 * ue + eps4 * (fd * fb + 4 * fe);
     const float ucd = 4 * (fc * ue + fe * uc) + 2 * fd * ud + 2 * fb * fe * ub + fb2 * ue + eps4 * (4 * fc * fe + fd * fd + fb2 * fe);
-#else
-    const float ucc = 0, ucd = 0;
-    (void)eps4;
-#endif
     const double Q = (3 * cc - cb * cb) * (1. / 9.), R = (9 * cb * cc - 27 * cd - 2 * cb * cb * cb) * (1. / 54.);
     const double Q3 = Q * Q * Q, D = Q3 + R * R;
     const double cb3 = (1. / 3.) * cb;
@@ -225,11 +206,7 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
     const float fr = (float)fabs(r0);
     const float islope = scr_rcpf((float)fabs((3 * r0 + 2 * cb) * r0 + cc));  // slope 0: inf -> "maybe" below
     const float er = 4e-16f * (((fr + fc) * fr + (float)fabs(cc)) * fr + (float)fabs(cd)) * islope;
-#ifndef ESAC_SCREEN_NOGUARD_Q
     const float ec = ((uc * fr + ucc) * fr + ucd) * islope;
-#else
-    const float ec = 0;
-#endif
     // Ferrari takes square roots of quantities that cancel: R2 = (half the difference of the two quadratic factors'
     // linear terms)^2, D2 and E2 = squared separations of the root pairs, with v ~ 1 / sqrt(R2)
     const double R2 = 0.25 * b2 - c + r0;
@@ -238,21 +215,14 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
     ESAC_SCREEN_HIST(0, er / fR2);
     ESAC_SCREEN_HIST(1, uR2 / fR2);
     bad |= !(fR2 > (float)(SCREEN_FERRARI_SAFETY * 10) * er + (float)SCREEN_SIG * uR2);
-#ifdef ESAC_GUARD_BRANCHY  // A/B switch (scripts/dev/variants.sh): leave at the first failed guard
-    if (bad) return -1;
-#endif
     if (R2 < 0) return bad ? -1 : 0;
     const double Rr = scr_sqrt(R2), iRr = scr_rcp(Rr);
     const double num = 4 * bc - 8 * d - b3;
     const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * num * iRr;
     const double D2 = u + v, E2 = u - v;
     const float fiRr = (float)iRr, fiR2 = fiRr * fiRr, fv = (float)fabs(v);
-#ifndef ESAC_SCREEN_NOGUARD_Q
     const float unum = 4 * (fc * ub + fb * uc) + 8 * ud + 3 * fb2 * ub + eps4 * (4 * fb * fc + 8 * fd + fb * fb2);
     const float uD = 1.5f * fb * ub + 2 * uc + uR2 + 0.25f * unum * fiRr + 0.5f * fv * uR2 * fiR2;  // coefficient part of D2's / E2's bound
-#else
-    const float uD = 0;
-#endif
     const float rD = er * (1 + 0.5f * fv * fiR2) + 1e-16f * (0.75f * fb2 + 2 * fc + fR2 + fv);       // rounding part
     const float fD2 = (float)fabs(D2), fE2 = (float)fabs(E2);
     ESAC_SCREEN_HIST(2, rD / fminf(fD2, fE2));
@@ -260,9 +230,6 @@ ESAC_HD int quartic_roots_fast(double a, double b, double c, double d, double e,
     {
         const float dv = (float)SCREEN_FERRARI_SAFETY * rD + (float)SCREEN_SIG * uD;
         bad |= !(fminf(fD2, fE2) > dv);
-#ifdef ESAC_GUARD_BRANCHY
-        if (bad) return -1;
-#endif
     }
     const double b_4 = 0.25 * b, R_2 = 0.5 * Rr;
     // bound of a root's difference: x = +-R/2 +- sqrt(D2)/2 - b/4
@@ -385,18 +352,6 @@ ESAC_HD int screen_lengths(const ScreenSetup& S, double x, float dx, double& X, 
     const double f1 = g2 * xx + g1 * x + g0;
     const double f2 = (k3 * x + k2) * xx + k1 * x + k0;
     const double b1 = f1 * f2;
-#ifdef ESAC_SCREEN_NOGUARD_R  // the validity tests alone, as in round 2
-    if (b1 <= 0) return 0;
-    {
-        const double y0 = S.inv_b0 * b1, v0 = xx + y0 * y0 - x * y0 * r;
-        if (v0 <= 0) return 0;
-        Z = S.dist2 * scr_rcp(scr_sqrt(v0));
-        X = x * Z;
-        Y = y0 * Z;
-        return 1;
-    }
-#endif
-#ifndef ESAC_GUARD_D64  // A/B (scripts/dev/kvariants.sh): -DESAC_GUARD_D64 = the derivative in fp64 (measured 8 % SLOWER: 1709 vs 1578 us)
     // How far can b1 -- its sign, and the depth ratio y = b1 / b0 -- be from the exact route's?  By the rounding of the two
     // factors (SCREEN_CU of the magnitudes of their terms: |p|, |q|, |r| <= 2 bounds the bracketed sums of f2 by 8 M, 72 M,
     // 136 M, 136 M with M = (1 + a + b)^2 -- loose by up to ~30x, which only matters where f2 has lost ten digits to
@@ -412,19 +367,6 @@ ESAC_HD int screen_lengths(const ScreenSetup& S, double x, float dx, double& X, 
     ESAC_SCREEN_HIST(6, db1x / fb1);
     ESAC_SCREEN_HIST(7, f1f / m1);
     ESAC_SCREEN_HIST(8, f2f / m2);
-#else
-    // How far can b1 -- its sign, and the depth ratio y = b1 / b0 -- be from the exact route's?  By the rounding of the two
-    // factors -- at most SCREEN_CU of the magnitudes of their terms each: |f1| terms <= (1+a+b)(x+1)^2, |f2| terms <=
-    // 136 (1+a+b)^2 (x+1)^3 (|p|, |q|, |r| <= 2 bounds the bracketed sums of f2 by 8 M, 72 M, 136 M, 136 M; loose by up to
-    // ~30x, which only matters where f2 has lost ten digits to cancellation) -- and by what the root's own difference
-    // does to it (first order: |b1'(x)| dx, the derivative exact, in fp64 next to the value).  Bookkeeping: fp32.
-    const double d1 = (2 * g2 * x + g1) * f2 + f1 * ((3 * k3 * x + 2 * k2) * x + k1);
-    const float xp1 = (float)x + 1.0f, xp2 = xp1 * xp1;
-    const float db1 = 2.0f * (float)SCREEN_CU * (S.sf * xp2) * (S.m136 * xp2 * xp1) + (float)fabs(d1) * dx;
-    const float fb1 = (float)fabs(b1);
-    ESAC_SCREEN_HIST(5, 2.0f * (float)SCREEN_CU * (S.sf * xp2) * (S.m136 * xp2 * xp1) / fb1);
-    ESAC_SCREEN_HIST(6, (float)fabs(d1) * dx / fb1);
-#endif
     const double y = S.inv_b0 * b1;
     const double v = xx + y * y - x * y * r;
     // sign of b1 or the value of y = b1 / b0 not reproducible (covers b1 ~ 0 and NaN); v is a positive definite form of

@@ -40,3 +40,18 @@ def build_screen_probe(force=False):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                                "-fopenmp", "-include", "omp.h", "-Wno-unused-result", SCREEN_SRC, "-o", SCREEN_LIB])
     return SCREEN_LIB
+
+
+CAMPAIGN_SRC = os.path.join(HERE, "screen_campaign.hip")
+CAMPAIGN_LIB = os.path.join(HERE, "libscreen_campaign.so")
+
+
+def build_screen_campaign(force=False):
+    """DEVICE build of the screen-vs-exact-route campaign (screen_campaign.hip): the product's own compiler flags, so the
+    screen runs the arithmetic the kernels run (v_rcp / v_rsq / v_sqrt estimates, the same contraction)."""
+    from esac_amd import build as product
+    deps = [CAMPAIGN_SRC] + [os.path.join(CSRC, h) for h in ("pose_math.hpp", "p3p_screen.hpp")]
+    if force or not os.path.exists(CAMPAIGN_LIB) or any(os.path.getmtime(d) > os.path.getmtime(CAMPAIGN_LIB) for d in deps):
+        hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+        subprocess.check_call([hipcc] + product.FLAGS + [CAMPAIGN_SRC, "-o", CAMPAIGN_LIB])
+    return CAMPAIGN_LIB

@@ -664,3 +664,34 @@ def test_selection_folded_into_the_team_kernel_equals_the_selection_kernel(engin
                              inlier_alpha=c["alpha"])
         assert int(rec[api.RES_HYP]) == ref["winner"]
         np.testing.assert_allclose(scores[flags == 1], ref["scores"][flags == 1], rtol=0, atol=1e-7 * max(1.0, c["alpha"]))
+
+
+def test_sampling_screen_is_one_sided_on_the_device():
+    """The screen must never reject a try the fp64 route accepts -- checked where the kernels run it: the screen's private
+    root solver uses v_rcp / v_rsq / v_sqrt estimates and contraction on the device, IEEE operations in the host probe
+    (tests/native/p3p_screen_probe.cpp).  tests/native/screen_campaign.hip compiles the product's headers with the
+    product's flags and decides every random try both ways ON THE GPU: 1.3e8 tries per map on six adversarial maps here
+    (scripts/dev/screen_campaign_device.py runs 1e11+; log under profiles/).  No accepted try may be lost at the kernels'
+    3-pixel margin, nor at 2."""
+    import ctypes as C
+    import sys
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts", "dev"))
+    from tests.native import build as nb
+    from screen_adversarial import adversarial_maps, quantised_maps
+    from screen_campaign_device import run
+    lib = C.CDLL(nb.build_screen_campaign())
+    maps = adversarial_maps()
+    qm = quantised_maps()
+    picks = [("fronto-parallel exact", maps), ("plane warped, x and y quantised", maps), ("sphere warped 2x0.5", maps),
+             ("room, 1 cell right", maps), ("room quantised 0.05 m", qm), ("clean room piecewise constant 2x2", qm)]
+    accepted = 0
+    for k, (name, fam) in enumerate(picks):
+        out = run(lib, fam[name], 1.3e8, 4000 + k)
+        accepted += out[1]
+        assert out[0] >= 1e8 and out[7] == 0 and out[6] == 0, (name, out)
+        assert out[8] <= 10.0 + 2.0, (name, out[8])  # largest screen error of an accepted try: well inside tau + 3
+    assert accepted > 1e7

@@ -29,7 +29,7 @@ BUF_BWD_PROBS, BUF_BWD_LOSSES, BUF_BWD_REF_HYPS, BUF_BWD_SCORE_GRADS, BUF_BWD_SL
     10, 11, 12, 13, 14, 15, 16
 BUF_BWD_PATH1, BUF_BWD_PATH2 = 17, 18
 BUF_REFINE_INFO = 19
-REFINE_TEAM_MAX, REFINE_TEAM_DEFAULT = 8, 8
+REFINE_TEAM_MAX, REFINE_TEAM_DEFAULT = 32, 8
 MAX_REF_STEPS = 100
 BWD_MAX_SLOTS = 1000
 
@@ -344,7 +344,9 @@ class Engine:
         """How the most recent winner refinement ran (ESAC_BUF_REFINE_INFO)."""
         v = self.read(BUF_REFINE_INFO)
         return {"mode": ("one_workgroup", "cooperating", "team")[int(v[0])] if 0 <= int(v[0]) <= 2 else int(v[0]),
-                "workgroups": int(v[1]), "xcd_census": "%08x" % (int(v[2]) & 0xffffffff), "same_xcd": bool(v[3]),
+                "workgroups": int(v[1]),
+                "xcd_census": [(int(v[2]) >> (8 * x)) & 255 for x in range(4)] + [(int(v[7]) >> (8 * x)) & 255 for x in range(4)],
+                "same_xcd": bool(v[3]),
                 "exchanges": int(v[4]), "timed_out": bool(v[5]), "team_fallbacks": int(v[6])}
 
     def set_timing(self, on, period=1):

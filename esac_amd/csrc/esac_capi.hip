@@ -527,7 +527,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             return 0;
         };
         if ((rc = wait_record(c->epoch))) return rc;
-        if (B == 1 && c->h_pin[33] == 3.0 && refine_team_members(a) > 0 && refine_coop_slice(a) == 0) {
+        if (B == 1 && c->h_pin[33] == 3.0 && refine_team_members(a) > 0) {
             // the team's members did not all become resident in time (a shared or partitioned GPU): the same refinement in
             // one workgroup -- the hypotheses, scores and selection of this call are still in the workspace
             c->team_fallbacks++;
@@ -883,7 +883,6 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
             int32_t info[8];
             HIP_OK(hipMemcpy(info, c->ws.refine_info, sizeof(info), hipMemcpyDeviceToHost));
             info[6] = (int32_t)c->team_fallbacks;
-            info[7] = 0;
             memcpy(h_dst, info, sizeof(info));
             return 0;
         }

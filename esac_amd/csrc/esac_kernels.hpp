@@ -15,7 +15,7 @@ constexpr int ESAC_REFINE_LDS_CAP = 8192;  // correspondences the refinement ker
 constexpr int ESAC_REFINE_THREADS = 256;   // 4 wavefronts = one per SIMD of the one CU a refinement occupies
 constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the error pass
 constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refinement (one per CU: all must be resident)
-constexpr int ESAC_REFINE_TEAM_MAX_K = 8;    // ... on a grid that fits one workgroup's LDS list: a team on one XCD (esac_refine.hip)
+constexpr int ESAC_REFINE_TEAM_MAX_K = 32;   // ... on a small grid: a team on ONE XCD (its 32 CUs; esac_refine_team.hip)
 constexpr int ESAC_REFINE_TEAM_MIN_CELLS = 1024;  // smaller grids are refined by one workgroup (a pass is shorter than an exchange)
 constexpr int ESAC_PIN_DOUBLES = 36;       // pinned host slot per frame: result record [32] + epoch word + status word + check word + pad
 // The pinned record is handed over WITHOUT a system-scope fence: the kernel stores the 34 words and a 35th that is a

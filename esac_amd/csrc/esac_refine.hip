@@ -585,6 +585,7 @@ unsigned long long launch_refine(const KArgs& a, hipStream_t s) {
     const bool global_list = a.H * a.W > LDS_CAP;
     // 16-byte accesses: W % 4 == 0 keeps every row, plane (P % 4 == 0) and expert map 16-byte aligned
     const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
+    if (refine_team_members(a) > 0) return launch_refine_team(a, s);  // single frames on grids up to 32768 cells
     const int slice = refine_coop_slice(a);
     if (slice > 0) {
         KArgs b = a;
@@ -595,7 +596,6 @@ unsigned long long launch_refine(const KArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((k_refine<B, false, true, false, REFINE_COOP>), dim3(G), dim3(B), 0, s, b);
         return b.coop_tag;
     }
-    if (refine_team_members(a) > 0) return launch_refine_team(a, s);
     if (global_list) {
         if (vec) hipLaunchKernelGGL((k_refine<B, true, true, false>), dim3(1, a.frames), dim3(B), 0, s, a);
         else     hipLaunchKernelGGL((k_refine<B, true, false, false>), dim3(1, a.frames), dim3(B), 0, s, a);

@@ -70,7 +70,7 @@ __device__ __forceinline__ TauBand make_band(const KArgs& a) {
 template <int CPL>
 __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& cl, const double (&param)[6], const Cam& cam, const TauBand& band,
                                           unsigned run_set, bool use_next, unsigned& next_set, double (&sums)[TEAM_NSUM], double (&Mw)[3][3],
-                                          Coop& co, double* s_part, double* s_tot, long long* g_cyc) {
+                                          Coop& co, double* s_part, double* s_tot, double* s_x, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
     double R[9];
@@ -149,7 +149,7 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
     wave_totals28_to_lds<TEAM_NSUM>(sums, s_part);
     team_publish<TEAM_NSUM>(workgroup_total28<REFINE_B>(s_part), co);
     lm_pose_left_jacobian(tg, Mw);  // while the exchange is in flight
-    team_collect<TEAM_NSUM>(sums, co, s_tot);
+    team_collect<TEAM_NSUM>(sums, co, s_tot, s_x);
     CYC_END(6);
     CYC_ADD(9, 1);
 }
@@ -210,7 +210,7 @@ __device__ __forceinline__ void team_step(const double (&U21)[21], const double 
 constexpr int TEAM_SEL_CHUNK = 16;  // contenders re-scored per exchange (16 x 12 pose values fit one load per thread)
 template <int CPL>
 __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>& cl, bool cells_loaded, int cell0, int cell1, const Cam& cam, Coop& co,
-                                           bool writer, double* s_part, double* s_tot, double* s_best, int* s_besti, int* s_bestg, int* s_list,
+                                           bool writer, double* s_part, double* s_tot, double* s_x, double* s_best, int* s_besti, int* s_bestg, int* s_list,
                                            double* s_rt, double& win_score, int& nc_out, RecordInputs& rec_in) {
     constexpr int B = REFINE_B;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -303,7 +303,7 @@ __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>&
         __syncthreads();
         double tot[TEAM_SEL_CHUNK];
         team_publish<TEAM_SEL_CHUNK>(t < TEAM_SEL_CHUNK ? (s_part[t] + s_part[28 + t]) + (s_part[56 + t] + s_part[84 + t]) : 0.0, co);
-        team_collect<TEAM_SEL_CHUNK>(tot, co, s_tot);
+        team_collect<TEAM_SEL_CHUNK>(tot, co, s_tot, s_x);
         if (co.dead) break;
         if (t < cnt) {
             const int h = s_list[c0 + t];
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     if ((blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
     __shared__ double s_part[28 * (B / 64) > 84 ? 28 * (B / 64) : 84];  // block reductions; scratch of the pseudo-inverse step
     __shared__ double s_tot[32];
+    __shared__ double s_x[TEAM_MAX * 32];  // exchanges of more than 8 members: the polled values, [member][value]
     __shared__ double s_best[B / 64];
     __shared__ int s_besti[B / 64];
     __shared__ int s_bestg[B / 64];
@@ -392,11 +393,11 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     coop_init(co, a, (int)gridDim.x / a.team_stride, (int)blockIdx.x / a.team_stride, 1L << 22);
     co.expect = co.G;
     if (a.coop_extra && co.g == co.G - 1) return;  // ESAC_DEBUG_COOP_STALL: the last member never shows up
-    // first exchange, in flight while the winner is looked up: a census of the XCDs the members run on (16^XCC_ID each)
+    // first exchange, in flight while the winner is looked up: a census of the XCDs the members run on (64^XCC_ID each)
     {
         int xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        team_publish<1>((double)(1ull << (4 * (xcc & 7))), co);
+        team_publish<1>((double)(1ull << (6 * (xcc & 7))), co);
     }
     if (threadIdx.x < 33) s_pow10[threadIdx.x] = pow10_int((int)threadIdx.x - 16);  // (visible after the barrier of the winner pick)
     const bool writer = co.g == 0;
@@ -428,8 +429,8 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     double census[1] = {0.0};
     if (a.fold_select) {
         __syncthreads();  // (s_pow10, s_coop_dead)
-        team_collect<1>(census, co, s_tot);
-        win = team_select<CPL>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
+        team_collect<1>(census, co, s_tot, s_x);
+        win = team_select<CPL>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_x, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
                                rec_in);
     } else {
         nc = a.n_contenders[0];
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
     if (a.E != 1) load_cells(a.sc + (size_t)e * 3 * P);
-    if (!a.fold_select) team_collect<1>(census, co, s_tot);
+    if (!a.fold_select) team_collect<1>(census, co, s_tot, s_x);
     CYC_END(1);
 
     // ---- refineHyp (esac_util.h:378-454) around ONE pass site
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
             }
             ends_refit = iters + 1 >= 20 || relative_step_below_eps(dn, pn);
         }
-        team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, Mw, co, s_part, s_tot, g_cyc);
+        team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, Mw, co, s_part, s_tot, s_x, g_cyc);
         if (co.dead) break;  // an exchange timed out: the sums are garbage, the call reports it
         CYC_BEGIN();
         if (in_refit) {
@@ -544,15 +545,19 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     }
 }
 
-// Members of the team that refines a single frame (0: one workgroup refines): grids of 1024 .. 8192 cells, as many members
-// as were asked for but at least so many that a member's slice fits its lanes' registers (1024 cells); the device must
-// hold the whole launch at once.
+// Members of the team that refines a single frame (0: one workgroup refines): grids of 1024 .. 32768 cells; as many members
+// as give every lane ONE cell (the pass is then as short as it gets: 19 at 60x80), at most what was asked for
+// (esac_hip_set_refine_team) and the CUs of one XCD, at least so many that a member's slice fits its lanes' registers
+// (four cells per lane); the device must hold the whole launch at once.
 int refine_team_members(const KArgs& a) {
     const int P = a.H * a.W;
-    int G = a.team < TEAM_MAX ? a.team : TEAM_MAX;
-    if (G < 2 || P > TEAM_MAX * TEAM_CPL_MAX * REFINE_B || P < ESAC_REFINE_TEAM_MIN_CELLS || a.frames != 1 || !a.coop_partials) return 0;
+    if (a.team < 2 || P > TEAM_MAX * TEAM_CPL_MAX * REFINE_B || P < ESAC_REFINE_TEAM_MIN_CELLS || a.frames != 1 || !a.coop_partials) return 0;
+    int G = (P + REFINE_B - 1) / REFINE_B;
+    if (G > a.team) G = a.team;
+    if (G > TEAM_MAX) G = TEAM_MAX;
     const int need = (P + TEAM_CPL_MAX * REFINE_B - 1) / (TEAM_CPL_MAX * REFINE_B);
     if (G < need) G = need;
+    if (G < 2) G = 2;
     if (a.coop_max < G * (a.team_stride > 0 ? a.team_stride : 8)) return 0;
     return G;
 }
@@ -560,7 +565,7 @@ int refine_team_members(const KArgs& a) {
 // The selection can run in the team kernel's prologue: a team refines this call, one hypothesis per thread of a member, the
 // default score route (ESAC_FLAG_EXACT_SCORES has statistics of its own), no device-side span stamps to reduce.
 bool refine_folds_select(const KArgs& a) {
-    return refine_coop_slice(a) == 0 && refine_team_members(a) > 0 && a.N <= REFINE_B && !(a.flags & ESAC_FLAG_EXACT_SCORES_K) && !a.tstamps;
+    return refine_team_members(a) > 0 && a.N <= REFINE_B && !(a.flags & ESAC_FLAG_EXACT_SCORES_K) && !a.tstamps;
 }
 
 unsigned long long launch_refine_team(const KArgs& a, hipStream_t s) {

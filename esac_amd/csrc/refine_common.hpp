@@ -164,7 +164,7 @@ __device__ __forceinline__ double pow10_int(int k) {
 // launch as failed, every member winds down, and the host re-runs the refinement in one workgroup (blocking calls) or
 // reports -12 (esac_hip_check).
 enum : int { REFINE_SOLO = 0, REFINE_COOP = 1, REFINE_TEAM = 2 };
-constexpr int TEAM_MAX = ESAC_REFINE_TEAM_MAX_K;  // members of a team (the poll layout gives every value 8 lanes)
+constexpr int TEAM_MAX = ESAC_REFINE_TEAM_MAX_K;  // members of a team: the CUs of one XCD
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -226,39 +226,83 @@ __device__ __forceinline__ void team_publish(double own, const Coop& co) {
         gran_store(buf + co.g * 32 + threadIdx.x, u32x4{(unsigned)bits, (unsigned)(bits >> 32), (unsigned)tg, (unsigned)(tg >> 32)});
     }
 }
-// v[k] <- sum over the members of their value k, members added in one fixed (pairwise) order: bitwise identical in every
-// member.  REFINE_B = 256 threads: thread t polls value t >> 3 of member t & 7.  s_tot: >= 32 doubles nobody else touches
-// until the next workgroup barrier.
+// v[k] <- sum over the members of their value k, members added in one fixed order: bitwise identical in every member.
+// REFINE_B = 256 threads.  Up to 8 members: thread t polls value t >> 3 of member t & 7, three DPP stages add the
+// members.  More (up to 32): the G x 32 granules of an exchange are contiguous -- thread t polls granules t, t + 256, ...
+// (member g >> 5, value g & 31; up to four 16-byte loads in flight), the values go through LDS (s_x: 32 x 32 doubles), thread
+// t adds members (t & 7), (t & 7) + 8, ... of value t >> 3, the same three DPP stages finish.  s_tot: >= 32 doubles nobody
+// else touches until the next workgroup barrier.
 template <int NV>
-__device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot) {
-    static_assert(NV <= 32 && REFINE_B == 32 * TEAM_MAX && TEAM_MAX == 8, "poll layout: 8 lanes per value");
+__device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot, double* s_x = nullptr) {
+    static_assert(NV <= 32 && REFINE_B == 256 && TEAM_MAX <= 32, "poll layout");
     if (co.dead) return;
     const unsigned long long want = co.tag | (co.arrivals + 1ull);
     const u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
     const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
     double val = 0.0;
     bool timed_out = false;
-    if (j < co.expect && k < NV) {
-        const u32x4* p = buf + j * 32 + k;
-        long spins = 0;
-        for (;;) {
-            const u32x4 g = gran_load(p);
-            const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.y << 32);
-            const unsigned long long tg = (unsigned long long)g.z | ((unsigned long long)g.w << 32);
-            if ((tg ^ bits) == want) {
-                val = __longlong_as_double((long long)bits);
-                break;
+    auto fits = [&](const u32x4& g, double& out) {
+        const unsigned long long bits = (unsigned long long)g.x | ((unsigned long long)g.y << 32);
+        const unsigned long long tg = (unsigned long long)g.z | ((unsigned long long)g.w << 32);
+        out = __longlong_as_double((long long)bits);
+        return (tg ^ bits) == want;
+    };
+    // another member gave up (its failure word carries this launch's tag): no point in waiting out the limit
+    auto give_up = [&](long spins) {
+        return spins > co.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag);
+    };
+    if (co.expect <= 8 || s_x == nullptr) {
+        if (j < co.expect && k < NV) {
+            const u32x4* p = buf + j * 32 + k;
+            for (long spins = 1;; spins++) {
+                if (fits(gran_load(p), val)) break;
+                if (give_up(spins)) {
+                    timed_out = true;
+                    val = 0.0;
+                    break;
+                }
             }
-            ++spins;
-            // another member gave up (its failure word carries this launch's tag): no point in waiting out the limit
-            if (spins > co.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag)) {
+        }
+    } else {
+        // four granules per thread, their loads in flight together (clamped addresses for the ones this thread does not
+        // need); polled again until every needed one carries this exchange's tag
+        static_assert(TEAM_MAX * 32 / REFINE_B == 4, "four granules per thread");
+        const int total = co.expect * 32;
+        const u32x4* ptr[4];
+        bool need[4];
+        double x[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int g = (int)threadIdx.x + i * REFINE_B;
+            need[i] = g < total && (g & 31) < NV;
+            ptr[i] = buf + (g < total ? g : 0);
+        }
+        for (long spins = 1;; spins++) {
+            u32x4 g0, g1, g2, g3;
+            asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                         "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+                         : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3])
+                         : "memory");
+            const bool ok0 = !need[0] || fits(g0, x[0]), ok1 = !need[1] || fits(g1, x[1]);
+            const bool ok2 = !need[2] || fits(g2, x[2]), ok3 = !need[3] || fits(g3, x[3]);
+            if (ok0 && ok1 && ok2 && ok3) break;
+            if (give_up(spins)) {
                 timed_out = true;
                 break;
             }
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (need[i]) s_x[(int)threadIdx.x + i * REFINE_B] = timed_out ? 0.0 : x[i];
+        if (timed_out) coop_mark_failed(co);
+        timed_out = false;
+        barrier_lds();
+        if (k < NV)
+            for (int m = j; m < co.expect; m += 8) val += s_x[m * 32 + k];  // members j, j + 8, j + 16, j + 24 in that order
     }
     if (timed_out) coop_mark_failed(co);
-    val += dpp_move<0xB1>(val);   // members (0,1) (2,3) (4,5) (6,7)
+    val += dpp_move<0xB1>(val);   // lanes (0,1) (2,3) (4,5) (6,7)
     val += dpp_move<0x4E>(val);   // quads
     val += dpp_move<0x141>(val);  // all eight
     if (j == 0 && k < NV) s_tot[k] = val;
@@ -268,8 +312,6 @@ __device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* 
     for (int kk = 0; kk < NV; kk++) v[kk] = s_tot[kk];
     co.arrivals += 1ull;
 }
-
-
 
 // ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties
 //      (esac_util.h:512-529; softmax is monotone, so the argmax of the scores is the argmax of the probabilities).
@@ -367,10 +409,16 @@ __device__ __forceinline__ void refine_write_record(const KArgs& a, const Record
         s_rec[33] = coop_failed ? 3.0 : (in.status == (unsigned long long)a.sample_epoch) ? 1.0 : 0.0;
         if (a.refine_info) {
             int same = 0;
-            for (int x = 0; x < 8; x++) same |= ((census >> (4 * x)) & 15ull) == (unsigned long long)co.G;
+            for (int x = 0; x < 8; x++) same |= ((census >> (6 * x)) & 63ull) == (unsigned long long)co.G;
+            unsigned lo = 0, hi = 0;  // bytes: members on XCD 0..3 / 4..7
+            for (int x = 0; x < 4; x++) {
+                lo |= (unsigned)((census >> (6 * x)) & 63ull) << (8 * x);
+                hi |= (unsigned)((census >> (6 * (x + 4))) & 63ull) << (8 * x);
+            }
             a.refine_info[0] = mode;
             a.refine_info[1] = co.G;
-            a.refine_info[2] = (int)(unsigned)census;
+            a.refine_info[2] = (int)lo;
+            a.refine_info[7] = (int)hi;
             a.refine_info[3] = mode == REFINE_TEAM ? same : 0;
             a.refine_info[4] = (int)co.arrivals;
             a.refine_info[5] = coop_failed ? 1 : 0;

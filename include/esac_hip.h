@@ -140,10 +140,10 @@ enum {
     ESAC_BUF_BWD_PATH2 = 18,       /* double[k,3,H,W] the same for path II; k = bytes / (3*H*W*8) <= #slots     */
     ESAC_BUF_REFINE_INFO = 19      /* int32[8] how the most recent winner refinement ran (refineHyp, esac_util.h:378-454):
                                       [0] 0 one workgroup, 1 cooperating workgroups (grids beyond one LDS list), 2 a team on
-                                      one XCD (small grids); [1] workgroups sharing it; [2] XCD census of a team: hex digit x =
-                                      members that ran on XCD x; [3] 1 when all members shared one XCD; [4] exchanges between
-                                      them; [5] 1 when an exchange timed out; [6] blocking calls on this context so far whose
-                                      team timed out and were refined again by one workgroup; [7] 0                          */
+                                      one XCD (small grids); [1] workgroups sharing it; [2] XCD census of a team: byte x = members
+                                      that ran on XCD x, x = 0..3, [7] the same for XCDs 4..7; [3] 1 when all members shared one
+                                      XCD; [4] exchanges between them; [5] 1 when an exchange timed out; [6] blocking calls on this
+                                      context so far whose team timed out and were refined again by one workgroup               */
 };
 
 /* Hypotheses that take part in the training expectation: selection probability >= PROB_THRESH = 0.001
@@ -300,10 +300,12 @@ int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
 int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
 
 /* The winner's refinement (refineHyp, esac_util.h:378-454) on a single frame whose grid fits one workgroup's LDS list
- * (1024 <= H*W <= 8192 cells, W % 4 == 0) is shared by a TEAM of `members` workgroups on one XCD (2..ESAC_REFINE_TEAM_MAX;
- * default ESAC_REFINE_TEAM_DEFAULT), each owning a slice of the cells; 0 or 1: one workgroup refines, as on every other shape.
+ * (1024 <= H*W <= 32768 cells) is shared by a TEAM of workgroups on one XCD, each owning a slice of the cells: `members` of
+ * them (2..ESAC_REFINE_TEAM_MAX = the CUs of an XCD; default ESAC_REFINE_TEAM_DEFAULT: measured 8 = 19 > 10, 12, 16 at 60x80),
+ * never more than give every lane of a member one cell (ceil(H*W / 256)) and never fewer than a member's lanes can hold
+ * the cells of (ceil(H*W / 1024): four per lane); 0 or 1: one workgroup refines, as on every other shape.
  * Results do not depend on the setting beyond the rounding of the LM sums (every discrete output is identical). */
-#define ESAC_REFINE_TEAM_MAX 8
+#define ESAC_REFINE_TEAM_MAX 32
 #define ESAC_REFINE_TEAM_DEFAULT 8
 int esac_hip_set_refine_team(esac_hip_ctx* ctx, int members);
 

@@ -68,6 +68,8 @@ def main():
             wg = k.get("workgroup", 64)
             n_wg = (k.get("grid", [wg, 1])[0] // max(wg, 1)) * max(1, k.get("grid", [wg, 1])[1])
             waves = n_wg * max(1, wg // 64)
+            if "k_refine_team" in name:  # every eighth workgroup of the launch is a member, the others leave at once (placement)
+                waves = max(1, n_wg // 8) * max(1, wg // 64)
             simds = min(SIMDS, max(1, waves))
             k["simds_occupied"] = simds
             plain = max(0.0, valu - trans - f64)

@@ -447,7 +447,9 @@ def test_cooperative_refinement_reports_a_barrier_time_out(engine):
     ha = S.gating_assignment(f, 64)
     sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
     p = engine.make_params(1, 120, 160, 64, seed=2, call=2)
+    engine.set_refine_team(0)  # (a team would take this 19200-cell grid: the counter-barrier kernel is what is tested here)
     good = engine.forward_device(sc, hat, p).copy()
+    assert engine.refine_info()["mode"] == "cooperating"
     engine.set_debug(coop_stall=True)
     try:
         t0 = time.time()
@@ -462,6 +464,7 @@ def test_cooperative_refinement_reports_a_barrier_time_out(engine):
     finally:
         engine.set_debug()
     again = engine.forward_device(sc, hat, p)
+    engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
     np.testing.assert_array_equal(again, good)  # the context recovers
     engine.check()
 
@@ -491,9 +494,10 @@ def _same_refinement(a, b):
 
 
 def test_refinement_team_sizes_agree_with_one_workgroup_and_the_oracle(engine, oracle):
-    """esac_hip_set_refine_team: the winner's refinement of a single 60x80 frame shared by 5..8 workgroups (fewer would
-    not fit a member's slice into its lanes' registers: the launcher raises the number) against ONE workgroup and the
-    oracle -- refinement trace (steps, inlier count per step, inlier map, LM iterations) identical, pose to 1e-10."""
+    """esac_hip_set_refine_team: the winner's refinement of a single 60x80 frame shared by 5..19 workgroups (fewer would
+    not fit a member's slice into its lanes' registers, more than ceil(4800 / 256) = 19 would leave lanes without a cell:
+    the launcher clamps the request) against ONE workgroup and the oracle -- refinement trace (steps, inlier count per
+    step, inlier map, LM iterations) identical, pose to 1e-8."""
     try:
         for k in range(4):
             f = S.make_frame(400 + k)
@@ -503,13 +507,13 @@ def test_refinement_team_sizes_agree_with_one_workgroup_and_the_oracle(engine, o
             assert solo["info"]["mode"] == "one_workgroup" and solo["info"]["workgroups"] == 1
             ref = oracle.forward(f["coords"], ha, shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"],
                                  ppy=f["ppy"], sub_sampling=f["sub"], seed=21, call=k)
-            for members in (2, 5, 6, 7, 8):
+            for members in (2, 5, 7, 8, 9, 12, 16, 19, 32):
                 engine.set_refine_team(members)
                 team = _team_run(engine, oracle, f, ha, 21, k)
                 info = team["info"]
-                assert info["mode"] == "team" and info["workgroups"] == max(members, 5) and not info["timed_out"], info
+                assert info["mode"] == "team" and info["workgroups"] == min(max(members, 5), 19) and not info["timed_out"], info
                 # observed placement: workgroup b runs on XCD b % 8 -- the members (every eighth workgroup) share one
-                assert info["same_xcd"] and sum(int(c, 16) for c in info["xcd_census"]) == info["workgroups"], info
+                assert info["same_xcd"] and sum(info["xcd_census"]) == info["workgroups"], info
                 _same_refinement(team, solo)
                 assert int(team["rec"][api.RES_REF_STEPS]) == ref["ref_steps"]
                 np.testing.assert_array_equal(team["counts"], ref["inlier_counts"])
@@ -525,15 +529,17 @@ def test_refinement_team_on_different_xcds(engine, oracle):
     run: same trace, same pose; the info words report the mismatch."""
     f = S.make_frame(410)
     ha = S.gating_assignment(f, 128)
-    together = _team_run(engine, oracle, f, ha, 22, 0)
-    engine.set_debug(team_spread=True)
+    engine.set_refine_team(19)  # (more members than XCDs: two or three per XCD when spread)
     try:
+        together = _team_run(engine, oracle, f, ha, 22, 0)
+        engine.set_debug(team_spread=True)
         spread = _team_run(engine, oracle, f, ha, 22, 0)
     finally:
         engine.set_debug()
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
     assert together["info"]["same_xcd"] and not spread["info"]["same_xcd"], (together["info"], spread["info"])
-    assert spread["info"]["mode"] == "team" and spread["info"]["workgroups"] == 8 and not spread["info"]["timed_out"]
-    assert max(int(c, 16) for c in spread["info"]["xcd_census"]) < 8
+    assert spread["info"]["mode"] == "team" and spread["info"]["workgroups"] == 19 and not spread["info"]["timed_out"]
+    assert max(spread["info"]["xcd_census"]) <= 3 and sum(spread["info"]["xcd_census"]) == 19  # 19 consecutive workgroups over 8 XCDs
     np.testing.assert_array_equal(spread["rec"][:31], together["rec"][:31])  # the same sums in the same order: bit for bit
     np.testing.assert_array_equal(spread["map"], together["map"])
 
@@ -550,7 +556,7 @@ def test_refinement_team_time_out_falls_back_to_one_workgroup(engine, oracle):
     try:
         engine.set_refine_team(0)
         solo = engine.forward_device(sc, hat, p).copy()
-        engine.set_refine_team(8)
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
         before = engine.refine_info()["team_fallbacks"]
         engine.set_debug(coop_stall=True)
         t0 = time.time()
@@ -573,16 +579,16 @@ def test_refinement_team_time_out_falls_back_to_one_workgroup(engine, oracle):
     engine.check()
 
 
-@pytest.mark.parametrize("H,W,sub", [(32, 40, 8), (33, 47, 5), (60, 80, 8), (64, 128, 4), (59, 83, 8)])
+@pytest.mark.parametrize("H,W,sub", [(32, 40, 8), (33, 47, 5), (60, 80, 8), (64, 128, 4), (59, 83, 8), (120, 160, 4), (128, 256, 2)])
 def test_refinement_team_on_other_grids(engine, oracle, H, W, sub):
-    """Grids of 1024 .. 8192 cells, rows that are not a multiple of four cells, 1 to 4 cells per lane: the team against
-    the oracle (trace, map, pose) and against one workgroup."""
+    """Grids of 1024 .. 32768 cells, rows that are not a multiple of four cells, 1 to 4 cells per lane, 5 to 32 members: the
+    team against the oracle (trace, map, pose) and against one workgroup (or the cooperating workgroups of the large grids)."""
     f = S.make_frame(420 + H, H=H, W=W, sub=sub)
     ha = S.gating_assignment(f, 64)
     try:
         engine.set_refine_team(0)
         solo = _team_run(engine, oracle, f, ha, 24, H)
-        engine.set_refine_team(8)
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
         team = _team_run(engine, oracle, f, ha, 24, H)
     finally:
         engine.set_refine_team(api.REFINE_TEAM_DEFAULT)

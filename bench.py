@@ -195,11 +195,11 @@ def load_profile(config):
 # one-GPU stage times (ms) of the BASELINE workloads, from this round's bench lines (profiles/r04_bench_<cfg>.json): the inputs of
 # `expected_scaling`.  host = ms_per_step - sum of the stages (launches, boundaries, hand-off)
 EXPECTED_T1_MS = {
-    "cfg2": {"sample": 0.0213, "score": 0.0039, "select": 0.0, "refine": 0.091, "host": 0.026},
-    "cfg3": {"sample": 0.080, "score": 0.008, "select": 0.010, "refine": 0.090, "host": 0.030},
-    "cfg4": {"sample": 0.115, "score": 0.022, "select": 0.011, "refine": 0.085, "host": 0.030},
-    "cfg5a": {"sample": 1.60, "score": 0.075, "select": 0.012, "refine": 0.095, "host": 0.030},
-    "cfg5b": {"sample": 1.81, "score": 2.70, "select": 0.035, "refine": 0.42, "host": 0.05},
+    "cfg2": {"sample": 0.0213, "score": 0.0039, "select": 0.0004, "refine": 0.0924, "host": 0.023},
+    "cfg3": {"sample": 0.0757, "score": 0.0083, "select": 0.0102, "refine": 0.0920, "host": 0.010},
+    "cfg4": {"sample": 0.1198, "score": 0.0200, "select": 0.0105, "refine": 0.0842, "host": 0.018},
+    "cfg5a": {"sample": 1.6111, "score": 0.0696, "select": 0.0117, "refine": 0.1042, "host": 0.018},
+    "cfg5b": {"sample": 1.8332, "score": 2.6122, "select": 0.0332, "refine": 0.3904, "host": 0.10},
 }
 STAGE_OF = (("k_sample", "sample"), ("k_bucket", "score"), ("k_score", "score"), ("k_select", "select_rescore"),
             ("k_refine", "refine"))

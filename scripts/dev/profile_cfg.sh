@@ -1,11 +1,11 @@
 # profile one bench.py workload: kernel trace + the PMC passes (each its own run) -> profiles/<round>_<cfg>_kernels.{json,txt}
 # usage (on the GPU box): bash scripts/dev/profile_cfg.sh <cfg> <round> [extra bench args]
 R=$GRAFT_REPO_ROOT
-CFG=$1; RND=${2:-r03}; shift; shift
+CFG=$1; RND=${2:-r04}; shift; shift
 O=$R/gpurun_out/prof_${RND}_${CFG}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --config $CFG --no-cpu-baseline --no-extras $*"
+CMD="python $R/bench.py --config $CFG --no-cpu-baseline --no-extras --no-exact $*"
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/stats -o t -- $CMD > $O/bench_under_rocprof.json 2> $O/err_stats.txt
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
@@ -16,6 +16,6 @@ for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
 done
 cd $R
 python scripts/profile_to_json.py --config $CFG --round $RND --stats $(find $O/stats -name "*.db" | head -1) \
-   --pmc $(find $O/pmc* -name "*.db") --command "bench.py --config $CFG --no-cpu-baseline --no-extras $*" --out-dir gpurun_out/profiles_$RND
+   --pmc $(find $O/pmc* -name "*.db") --command "bench.py --config $CFG --no-cpu-baseline --no-extras --no-exact $*" --out-dir gpurun_out/profiles_$RND
 tail -1 $O/bench_under_rocprof.json > gpurun_out/profiles_$RND/${RND}_${CFG}_bench_under_rocprof.json
 rm -rf $O/stats $O/pmc*   # the rocpd databases are tens of MB each: only the summaries travel back

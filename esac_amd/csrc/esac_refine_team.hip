@@ -83,7 +83,8 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
     for (int p = 0; p < CPL; p++) on[p] = cl.cell[p] >= 0;
     LmTerms<CPL> q;  // x, y, 1/z, residual of every owned cell (all zero for a missing one)
     lm_point_terms<CPL>(R, param + 3, cam, cl.X, cl.Y, cl.Z, cl.px, cl.py, on, q);
-    // (b) the next inlier set
+    // (b) the next inlier set -- only where the pass is (also) an error image: an LM trial that cannot end its re-fit needs
+    // the residual and the moments over the running set, nothing else
     unsigned nset = 0;
     double e2[CPL];
     bool undecided[CPL];
@@ -91,20 +92,26 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
 #pragma unroll
     for (int p = 0; p < CPL; p++) {
         e2[p] = __builtin_fma(q.ex[p], q.ex[p], q.ey[p] * q.ey[p]);
-        const bool in2 = e2[p] < band.lo2, out2 = e2[p] > band.hi2;  // NaN: neither
-        undecided[p] = on[p] && !band.all_in && !(in2 || out2);
-        any_undecided |= undecided[p];
-        if (on[p] && (in2 || band.all_in)) nset |= 1u << p;
+        undecided[p] = false;
     }
-    if (__any(any_undecided)) {  // the reference's own sequence, op by op (rodrigues as cv::Rodrigues, contraction off)
-        double Rx[9];
-        rodrigues_vec2mat<false>(param, Rx, nullptr);
+    if (use_next) {
 #pragma unroll
         for (int p = 0; p < CPL; p++) {
-            if (!__any(undecided[p])) continue;
-            float err = project_exact_err(Rx, param + 3, cam, (float)cl.X[p], (float)cl.Y[p], (float)cl.Z[p], (float)cl.px[p], (float)cl.py[p]);
-            err = err < band.max_reproj ? err : band.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
-            if (undecided[p] && err < band.tau) nset |= 1u << p;
+            const bool in2 = e2[p] < band.lo2, out2 = e2[p] > band.hi2;  // NaN: neither
+            undecided[p] = on[p] && !band.all_in && !(in2 || out2);
+            any_undecided |= undecided[p];
+            if (on[p] && (in2 || band.all_in)) nset |= 1u << p;
+        }
+        if (__any(any_undecided)) {  // the reference's own sequence, op by op (rodrigues as cv::Rodrigues, contraction off)
+            double Rx[9];
+            rodrigues_vec2mat<false>(param, Rx, nullptr);
+#pragma unroll
+            for (int p = 0; p < CPL; p++) {
+                if (!__any(undecided[p])) continue;
+                float err = project_exact_err(Rx, param + 3, cam, (float)cl.X[p], (float)cl.Y[p], (float)cl.Z[p], (float)cl.px[p], (float)cl.py[p]);
+                err = err < band.max_reproj ? err : band.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+                if (undecided[p] && err < band.tau) nset |= 1u << p;
+            }
         }
     }
     next_set = nset;

@@ -241,56 +241,72 @@ ESAC_HD void lm_chain(const double R[9], const double dRdr[27], const double t[3
 // dependent chain every lane walks before it can touch its first correspondence).
 // In two halves: the rotation (what a pass needs before its first correspondence) and the chain-rule matrices (what
 // only the transform AFTER the pass's reduction needs -- a team computes them while its exchange is in flight).
+//
+// No square root, no division, no sin / cos for |r| <= sqrt(10) (every pose this path meets): with x = |r|^2
+//     R   = I + A(x) [r]x + B(x) [r]x^2,        A = sin(th)/th,  B = (1 - cos(th))/th^2,
+//     J_l = A(x) I + B(x) [r]x + C(x) r r^T,    C = (th - sin(th))/th^3 = (1 - A)/x,
+// and A, B, C are entire functions of x: their Taylor polynomials of degree 15 in x (next term 10^16 / 33! ~ 1e-21) are
+// good to 3e-16 absolute on [0, 10] (checked against 60-digit arithmetic), evaluated by Estrin's scheme: five dependent
+// operations where sqrt -> division -> sincos is ~25.  Beyond |r|^2 = 10 the trigonometric route (1 / th from v_rsq_f64).
 struct LmTrig {
-    double nx, ny, nz, theta, itheta, s, c1;  // unit axis, angle, 1/angle, sin, 1 - cos
-    bool identity;                             // theta < DBL_EPSILON
+    double rx, ry, rz, x;  // rvec, |rvec|^2
+    double A, B;           // sin(th)/th, (1 - cos(th))/th^2
+    bool identity;         // |rvec| < DBL_EPSILON
+    bool series;           // A, B came from the series: C does too
 };
+
+// sum_k c[k] x^k, k < 16: pairs, quads, octets (Estrin)
+ESAC_HD double lm_estrin16(const double (&c)[16], double x, double x2, double x4, double x8) {
+#pragma clang fp contract(fast)
+    const double p0 = c[0] + c[1] * x, p1 = c[2] + c[3] * x, p2 = c[4] + c[5] * x, p3 = c[6] + c[7] * x;
+    const double p4 = c[8] + c[9] * x, p5 = c[10] + c[11] * x, p6 = c[12] + c[13] * x, p7 = c[14] + c[15] * x;
+    const double q0 = p0 + p1 * x2, q1 = p2 + p3 * x2, q2 = p4 + p5 * x2, q3 = p6 + p7 * x2;
+    return (q0 + q1 * x4) + (q2 + q3 * x4) * x8;
+}
 
 ESAC_HD void lm_pose_rotation(const double param[6], double R[9], LmTrig& tg) {
 #pragma clang fp contract(fast)
-    double rx = param[0], ry = param[1], rz = param[2];
-    const double theta2 = rx * rx + ry * ry + rz * rz;
-#if defined(__HIP_DEVICE_COMPILE__)
-    // 1/theta from the hardware's reciprocal square root + two Newton steps, theta = theta^2 / theta: ~8 dependent
-    // operations where sqrt followed by a division is ~25 (this chain is serial in every lane, once per pass); both are
-    // good to an ulp, which is what the rotation needs (the LM fixed point does not depend on their rounding)
-    double itheta = __builtin_amdgcn_rsq(theta2);
-    itheta = itheta * __builtin_fma(-0.5 * theta2, itheta * itheta, 1.5);
-    itheta = itheta * __builtin_fma(-0.5 * theta2, itheta * itheta, 1.5);
-    const double theta = theta2 * itheta;
-    tg.identity = theta2 < DBL_EPSILON * DBL_EPSILON;  // (theta2 = 0: rsq = inf, handled here; a NaN pose stays NaN below)
-#else
-    const double theta = sqrt(theta2);
-    const double itheta = 1. / theta;
-    tg.identity = theta < DBL_EPSILON;
-#endif
-    tg.theta = theta;
+    const double rx = param[0], ry = param[1], rz = param[2];
+    const double x = rx * rx + ry * ry + rz * rz;
+    tg.rx = rx; tg.ry = ry; tg.rz = rz; tg.x = x;
+    tg.identity = x < DBL_EPSILON * DBL_EPSILON;
+    tg.series = x <= 10.0;
     if (tg.identity) {
         R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
-        tg.nx = tg.ny = tg.nz = 0;
-        tg.theta = 0;
-        tg.itheta = 0;
-        tg.s = 0;
-        tg.c1 = 0;
+        tg.A = 1;
+        tg.B = 0.5;
         return;
     }
-    double c, s;
+    double A, B;
+    if (tg.series) {
+        const double cA[16] = {1.00000000000000000e+00, -1.66666666666666657e-01, 8.33333333333333322e-03, -1.98412698412698413e-04, 2.75573192239858925e-06, -2.50521083854417202e-08, 1.60590438368216133e-10, -7.64716373181981641e-13, 2.81145725434552060e-15, -8.22063524662432950e-18, 1.95729410633912626e-20, -3.86817017063068354e-23, 6.44695028438447359e-26, -9.18368986379554601e-29, 1.13099628864477181e-31, -1.21612504155351811e-34};
+        const double cB[16] = {5.00000000000000000e-01, -4.16666666666666644e-02, 1.38888888888888894e-03, -2.48015873015873016e-05, 2.75573192239858883e-07, -2.08767569878681002e-09, 1.14707455977297245e-11, -4.77947733238738525e-14, 1.56192069685862253e-16, -4.11031762331216484e-19, 8.89679139245057408e-22, -1.61173757109611839e-24, 2.47959626322479723e-27, -3.27988923706983776e-30, 3.76998762881590539e-33, -3.80039075485474409e-36};
+        const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+        A = lm_estrin16(cA, x, x2, x4, x8);
+        B = lm_estrin16(cB, x, x2, x4, x8);
+    } else {  // (a NaN pose also lands here and stays NaN)
 #if defined(__HIP_DEVICE_COMPILE__)
-    sincos(theta, &s, &c);  // one argument reduction for both
+        double itheta = __builtin_amdgcn_rsq(x);
+        itheta = itheta * __builtin_fma(-0.5 * x, itheta * itheta, 1.5);
+        itheta = itheta * __builtin_fma(-0.5 * x, itheta * itheta, 1.5);
+        const double theta = x * itheta;
+        double c, s;
+        sincos(theta, &s, &c);
 #else
-    c = cos(theta);
-    s = sin(theta);
+        const double theta = sqrt(x), itheta = 1. / theta;
+        const double c = cos(theta), s = sin(theta);
 #endif
-    const double c1 = 1. - c;
-    rx *= itheta; ry *= itheta; rz *= itheta;
-    const double xx = rx * rx, xy = rx * ry, xz = rx * rz, yy = ry * ry, yz = ry * rz, zz = rz * rz;
-    R[0] = c + c1 * xx;      R[1] = c1 * xy - s * rz; R[2] = c1 * xz + s * ry;
-    R[3] = c1 * xy + s * rz; R[4] = c + c1 * yy;      R[5] = c1 * yz - s * rx;
-    R[6] = c1 * xz - s * ry; R[7] = c1 * yz + s * rx; R[8] = c + c1 * zz;
-    tg.nx = rx; tg.ny = ry; tg.nz = rz;
-    tg.itheta = itheta;
-    tg.s = s;
-    tg.c1 = c1;
+        A = s * itheta;
+        B = (1. - c) * (itheta * itheta);
+    }
+    tg.A = A;
+    tg.B = B;
+    const double Bx = B * rx, By = B * ry, Bz = B * rz;
+    // R = I + A [r]x + B (r r^T - x I)
+    const double d = 1. - B * x;
+    R[0] = d + Bx * rx;       R[1] = Bx * ry - A * rz;  R[2] = Bx * rz + A * ry;
+    R[3] = Bx * ry + A * rz;  R[4] = d + By * ry;       R[5] = By * rz - A * rx;
+    R[6] = Bx * rz - A * ry;  R[7] = By * rz + A * rx;  R[8] = d + Bz * rz;
 }
 
 ESAC_HD void lm_pose_left_jacobian(const LmTrig& tg, double (&Mw)[3][3]) {
@@ -300,21 +316,22 @@ ESAC_HD void lm_pose_left_jacobian(const LmTrig& tg, double (&Mw)[3][3]) {
         for (int i = 0; i < 3; i++)
 #pragma unroll
             for (int j = 0; j < 3; j++) Mw[i][j] = (i == j) ? 1.0 : 0.0;
-    } else {
-        const double rx = tg.nx, ry = tg.ny, rz = tg.nz, theta = tg.theta;
-        const double xx = rx * rx, xy = rx * ry, xz = rx * rz, yy = ry * ry, yz = ry * rz, zz = rz * rz;
-        // s/th, (1-c)/th, 1 - s/th; below 1e-2 rad the differences cancel (error ~1e-16/th), their series are exact
-        // to rounding there (next term th^8/9! < 1e-21)
-        const bool tiny = theta < 1e-2;
-        const double t2 = theta * theta;
-        const double sb_ser = t2 * (1. / 6. - t2 * (1. / 120. - t2 * (1. / 5040.)));
-        const double sa = tiny ? 1. - sb_ser : tg.s * tg.itheta;
-        const double ca = tiny ? theta * (0.5 - t2 * (1. / 24. - t2 * (1. / 720. - t2 * (1. / 40320.)))) : tg.c1 * tg.itheta;
-        const double sb = tiny ? sb_ser : 1. - sa;
-        Mw[0][0] = sa + sb * xx;      Mw[0][1] = sb * xy - ca * rz; Mw[0][2] = sb * xz + ca * ry;
-        Mw[1][0] = sb * xy + ca * rz; Mw[1][1] = sa + sb * yy;      Mw[1][2] = sb * yz - ca * rx;
-        Mw[2][0] = sb * xz - ca * ry; Mw[2][1] = sb * yz + ca * rx; Mw[2][2] = sa + sb * zz;
+        return;
     }
+    const double rx = tg.rx, ry = tg.ry, rz = tg.rz, x = tg.x, A = tg.A, B = tg.B;
+    double C;
+    if (tg.series) {
+        const double cC[16] = {1.66666666666666657e-01, -8.33333333333333322e-03, 1.98412698412698413e-04, -2.75573192239858925e-06, 2.50521083854417202e-08, -1.60590438368216133e-10, 7.64716373181981641e-13, -2.81145725434552060e-15, 8.22063524662432950e-18, -1.95729410633912626e-20, 3.86817017063068354e-23, -6.44695028438447359e-26, 9.18368986379554601e-29, -1.13099628864477181e-31, 1.21612504155351811e-34, -1.15163356207719509e-37};
+        const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+        C = lm_estrin16(cC, x, x2, x4, x8);
+    } else {
+        C = (1. - A) / x;
+    }
+    const double Cx = C * rx, Cy = C * ry, Cz = C * rz;
+    // J_l = A I + B [r]x + C r r^T
+    Mw[0][0] = A + Cx * rx;       Mw[0][1] = Cx * ry - B * rz;  Mw[0][2] = Cx * rz + B * ry;
+    Mw[1][0] = Cx * ry + B * rz;  Mw[1][1] = A + Cy * ry;       Mw[1][2] = Cy * rz - B * rx;
+    Mw[2][0] = Cx * rz - B * ry;  Mw[2][1] = Cy * rz + B * rx;  Mw[2][2] = A + Cz * rz;
 }
 
 ESAC_HD void lm_pose_chain_rest(const LmTrig& tg, const double t[3], LmChain& ch) {

@@ -701,3 +701,39 @@ def test_sampling_screen_is_one_sided_on_the_device():
         assert out[0] >= 1e8 and out[7] == 0 and out[6] == 0, (name, out)
         assert out[8] <= 10.0 + 2.0, (name, out[8])  # largest screen error of an accepted try: well inside tau + 3
     assert accepted > 1e7
+
+
+@pytest.mark.parametrize("N", [1, 2, 255, 256, 257])
+def test_team_and_folded_selection_at_the_edges_of_their_shapes(engine, oracle, N):
+    """One and two hypotheses, and the three sizes around the 256 hypotheses up to which the team kernel runs the selection
+    itself (one hypothesis per thread of a member): full forward against the oracle."""
+    f = S.make_frame(450 + N)
+    ha = S.gating_assignment(f, N)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    p = engine.make_params(1, 60, 80, N, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=41, call=N)
+    rec = engine.forward_device(sc, hat, p).copy()
+    ref = oracle.forward(f["coords"], ha, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=41, call=N)
+    assert engine.refine_info()["mode"] == "team"
+    assert int(rec[api.RES_HYP]) == ref["winner"] and int(rec[api.RES_REF_STEPS]) == ref["ref_steps"]
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_MAP), ref["inlier_map"])
+    np.testing.assert_allclose(rec[api.RES_RVEC:api.RES_RVEC + 6], ref["refined"], rtol=0, atol=1e-6)
+    flags = engine.read(api.BUF_EXACT_FLAGS).astype(bool)
+    assert flags[ref["winner"]] and int(rec[api.RES_CONTENDERS]) == int(flags.sum())
+    np.testing.assert_allclose(engine.read(api.BUF_SCORES)[flags], ref["scores"][flags], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("H,W", [(31, 33), (32, 32), (16, 64)])
+def test_grids_at_the_lower_edge_of_the_team(engine, oracle, H, W):
+    """1023 cells (one workgroup refines), 1024 cells in two shapes (the smallest grids a team takes): against the oracle."""
+    f = S.make_frame(460 + H, H=H, W=W, sub=8)
+    ha = S.gating_assignment(f, 48)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    kw = dict(shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=42, call=H)
+    rec = engine.forward_device(sc, hat, engine.make_params(1, H, W, 48, **kw)).copy()
+    ref = oracle.forward(f["coords"], ha, **kw)
+    assert engine.refine_info()["mode"] == ("team" if H * W >= 1024 else "one_workgroup")
+    assert int(rec[api.RES_HYP]) == ref["winner"] and int(rec[api.RES_REF_STEPS]) == ref["ref_steps"]
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
+    np.testing.assert_array_equal(engine.read(api.BUF_INLIER_MAP), ref["inlier_map"])
+    np.testing.assert_allclose(rec[api.RES_RVEC:api.RES_RVEC + 6], ref["refined"], rtol=0, atol=1e-6)

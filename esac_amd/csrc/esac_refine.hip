@@ -304,9 +304,10 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
                                           double g6[6], double* s_part, double* s_tot, long long* g_cyc, Coop* co = nullptr) {
     CYC_DECL;
     CYC_BEGIN();
-    double R[9];
-    LmChain ch;
-    lm_pose_chain(param, R, ch);
+    double R[9], Mw[3][3];
+    LmTrig tg;
+    lm_pose_rotation(param, R, tg);
+    lm_pose_left_jacobian(tg, Mw);
     CYC_END(4);
     CYC_BEGIN();
     double mom[LM_NMOM];
@@ -351,7 +352,7 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
     CYC_PIN(mom, LM_NMOM);
     double acc[LM_NACC];
     lm_moments_to_acc(mom, cam.fx, acc);
-    lm_transform(acc, ch, U21, g6);
+    lm_transform_t(acc, Mw, param + 3, U21, g6);  // (K = [t]x Mw folded in: ~130 fused operations instead of ~235)
     CYC_PIN(U21, 21);
     CYC_PIN(g6, 6);
     CYC_END(7);
@@ -365,19 +366,19 @@ __device__ __forceinline__ double lm_pass(ListPtr list, int n, const double para
 // with the pass inlined at several sites the code grew to 170 KB and every phase ran from cold code).
 template <int B, int MODE, typename ListPtr>
 __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], const Cam& cam, const PxMap& pm, double* s_part,
-                                        double* s_tot, long long* g_cyc, Coop* co = nullptr) {
+                                        double* s_tot, const double* s_pow10, long long* g_cyc, Coop* co = nullptr) {
     CYC_DECL;
     double param[6], prev[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) param[k] = prev[k] = pose[k];
     double U21[21], g6[6];    // normal equations at `prev` (state CALC_J)
     double U21t[21], g6t[6];  // ... at the point just evaluated
-    double prev_err_norm = 0;
+    double prev_err2 = 0;  // |err|^2 at `prev`: CvLevMarq's norms are compared on their squares (refine_common.hpp: norm_greater)
     int lambda_lg10 = -3, iters = 0;
     bool have_base = false;
     for (;;) {
         // residual norm and (speculatively) the normal equations at `param`
-        const double err_norm = sqrt(lm_pass<B, MODE>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc, co));
+        const double err2 = lm_pass<B, MODE>(list, n, param, cam, pm, U21t, g6t, s_part, s_tot, g_cyc, co);
         if (co && co->dead) break;  // a barrier timed out: the sums are garbage, the call reports -12
         CYC_BEGIN();
         CYC_PIN(g6t, 6);
@@ -385,7 +386,7 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
         if (!have_base) {
             have_base = true;  // iters == 0: prevErrNorm = |err(initial pose)|
             accept = true;
-        } else if (err_norm > prev_err_norm && ++lambda_lg10 <= 16) {
+        } else if (norm_greater(err2, prev_err2) && ++lambda_lg10 <= 16) {
             accept = false;  // state CHECK_ERR failed: retry from `prev` with a larger lambda
         } else {
             lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
@@ -395,13 +396,12 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
                 dn += (param[k] - prev[k]) * (param[k] - prev[k]);
                 pn += prev[k] * prev[k];
             }
-            const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);  // cvNorm(param, prevParam, CV_RELATIVE_L2)
             ++iters;
-            if (iters >= 20 || rel < (double)FLT_EPSILON) break;
+            if (iters >= 20 || relative_step_below_eps(dn, pn)) break;  // cvNorm(param, prevParam, CV_RELATIVE_L2) < eps
             accept = true;
         }
         if (accept) {  // state CALC_J at the accepted point
-            prev_err_norm = err_norm;
+            prev_err2 = err2;
 #pragma unroll
             for (int k = 0; k < 21; k++) U21[k] = U21t[k];
 #pragma unroll
@@ -416,7 +416,8 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
         // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
         double dx[6];
         CYC_BEGIN();
-        if (!lm_solve6(U21, g6, pow10_int(lambda_lg10), dx)) lm_solve6_pinv(U21, g6, pow10_int(lambda_lg10), dx, s_part);
+        const double lambda = s_pow10[lambda_lg10 + 16];  // 10^k from a table in LDS (pow10_int: ~600 cycles of dependent work)
+        if (!lm_solve6(U21, g6, lambda, dx)) lm_solve6_pinv(U21, g6, lambda, dx, s_part);
         CYC_PIN(dx, 6);
         CYC_END(8);
 #pragma unroll
@@ -447,7 +448,9 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     __shared__ int s_besti[B / 64];
     __shared__ int s_bestg[B / 64];
     __shared__ int s_wcnt[B / 64];  // inliers each wavefront put into its region of the list
+    __shared__ double s_pow10[33];  // 10^-16 .. 10^16: the LM damping factors
     static_assert(B == REFINE_B, "corr_region() assumes the refinement workgroup size");
+    if (threadIdx.x < 33) s_pow10[threadIdx.x] = pow10_int((int)threadIdx.x - 16);  // (visible after the barriers of the winner pick)
     frame_view(a);
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
         if (!SLOTS && writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
         if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
         best_inliers = (unsigned)n_inl;
-        lm_total += lm_refit<B, MODE>(my_list, n_wave, pose, cam, pm, s_part, s_tot, g_cyc, SHARED ? &co : nullptr);
+        lm_total += lm_refit<B, MODE>(my_list, n_wave, pose, cam, pm, s_part, s_tot, s_pow10, g_cyc, SHARED ? &co : nullptr);
         accepted++;
         last_inliers = n_inl;
         map_buf = cur;  // inlierMap = this step's set (esac_util.h:440)

@@ -174,27 +174,6 @@ __device__ __forceinline__ void team_normal_equations(const double (&sums)[TEAM_
     CYC_END(7);
 }
 
-// sqrt(a) > sqrt(b) -- CvLevMarq compares error NORMS -- without the square roots unless a and b are a few ulp apart
-// (a double-precision square root is ~40 dependent instructions on the serial section of every pass).  sqrt is monotone
-// and correctly rounded: a <= b (or a NaN) can never give a larger root, and a relative gap of 8 eps separates the roots
-// by more than their rounding.
-__device__ __forceinline__ bool norm_greater(double a, double b) {
-    if (!(a > b)) return false;
-    if (a > b * (1.0 + 8.0 * DBL_EPSILON)) return true;
-    return sqrt(a) > sqrt(b);
-}
-// cvNorm(param, prevParam, CV_RELATIVE_L2) < FLT_EPSILON, i.e. sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < eps, dn = |param - prev|^2,
-// pn = |prev|^2: decided on the squares wherever the answer is clear of the threshold by 1e-9 (relative), by the
-// reference's own expression in between.  sqrt(pn) <= max(1, pn) bounds the DBL_EPSILON term from above.
-__device__ __forceinline__ bool relative_step_below_eps(double dn, double pn) {
-    const double e2 = (double)FLT_EPSILON * (double)FLT_EPSILON;
-    const double lo = e2 * pn;
-    if (dn < lo * (1.0 - 1e-9)) return true;
-    const double hi = lo + e2 * DBL_EPSILON * (2.0 * (pn > 1.0 ? pn : 1.0) + DBL_EPSILON);
-    if (dn > hi * (1.0 + 1e-9)) return false;
-    return sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < (double)FLT_EPSILON;
-}
-
 // step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
 // (lambda = 10^lambda_lg10 from a table in LDS: the binary exponentiation + division of pow10_int is ~600 cycles of
 // dependent work)

@@ -29,6 +29,7 @@ BUF_BWD_PROBS, BUF_BWD_LOSSES, BUF_BWD_REF_HYPS, BUF_BWD_SCORE_GRADS, BUF_BWD_SL
     10, 11, 12, 13, 14, 15, 16
 BUF_BWD_PATH1, BUF_BWD_PATH2 = 17, 18
 BUF_REFINE_INFO = 19
+BUF_BWD_TEAM_INFO = 20
 REFINE_TEAM_MAX, REFINE_TEAM_DEFAULT = 32, 8
 MAX_REF_STEPS = 100
 BWD_MAX_SLOTS = 1000
@@ -278,7 +279,7 @@ class Engine:
             BUF_SCORES: ((N,), np.float64), BUF_RESULT: ((RES_DOUBLES,), np.float64),
             BUF_INLIER_MAP: ((H, W), np.uint8), BUF_INLIER_COUNTS: ((MAX_REF_STEPS + 1,), np.int32),
             BUF_WINNER_ERRS: ((H, W), np.float32), BUF_EXACT_FLAGS: ((N,), np.uint8),
-            BUF_CYCLES: ((32,), np.int64), BUF_REFINE_INFO: ((8,), np.int32),
+            BUF_CYCLES: ((32,), np.int64), BUF_REFINE_INFO: ((8,), np.int32), BUF_BWD_TEAM_INFO: ((4,), np.int32),
             BUF_BWD_PROBS: ((N,), np.float64), BUF_BWD_LOSSES: ((N,), np.float64), BUF_BWD_REF_HYPS: ((N, 6), np.float64),
             BUF_BWD_SCORE_GRADS: ((N,), np.float64), BUF_BWD_SLOTS: ((N,), np.int32),
             BUF_BWD_SLOT_INFO: ((min(N, BWD_MAX_SLOTS), 4), np.int32), BUF_BWD_DLOSS: ((min(N, BWD_MAX_SLOTS), 6), np.float64),
@@ -339,6 +340,11 @@ class Engine:
         """Workgroups that share the winner's refinement on a small single-frame grid (0 / 1: one workgroup;
         esac_hip_set_refine_team)."""
         _check(self.lib.esac_hip_set_refine_team(self.ctx, int(members)), self.lib)
+
+    def bwd_team_info(self):
+        """Training path: were the slots of the last backward call refined by teams (ESAC_BUF_BWD_TEAM_INFO)."""
+        v = self.read(BUF_BWD_TEAM_INFO)
+        return {"teams": bool(v[0]), "team_calls": int(v[1]), "team_fallbacks": int(v[2]), "slots": int(v[3])}
 
     def refine_info(self):
         """How the most recent winner refinement ran (ESAC_BUF_REFINE_INFO)."""

@@ -6,7 +6,7 @@
 //   pose_loss        loss() on the inverted (camera) transforms       esac_loss.h:45-83, esac.cpp:357-360
 //   pose_dloss       dLoss(): 1x6 derivative wrt (rvec,tvec)          esac_loss.h:94-210 (keeps the sqrt(loss) quirk)
 //   inv_spd6         (J^T J)^-1 for the pseudo-inverse of esac.cpp:434
-// Host+device (ESAC_HD) like pose_math.hpp, so the CPU test-suite can run them against the oracle.
+// Host+device (ESAC_HD) like pose_math.hpp, so the CPU test-suite can run them against its checker.
 #pragma once
 #include "pose_math.hpp"
 

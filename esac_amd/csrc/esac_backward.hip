@@ -373,6 +373,9 @@ __global__ __launch_bounds__(256) void k_bwd_accumulate(KArgs a) {
     const int e = blockIdx.y;
     const int n_sel = a.bwd.n_sel[0];
     if (a.bwd.n_sel[1] > a.bwd.cap) return;  // more slots than the workspace holds: nothing is accumulated, the host grows it and retries
+    // the slots were refined by teams and one of them timed out (a member never became resident): nothing is accumulated
+    // either, the host refines the slots again with one workgroup each
+    if (a.bwd.team && __hip_atomic_load(a.coop_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.bwd.team_tag) return;
     if (threadIdx.x < 64) {
         int count = 0;
         for (int base = 0; base < n_sel; base += 64) {

@@ -81,6 +81,10 @@ struct esac_hip_ctx {
     unsigned long long refine_tag = 0;    // tag of the most recent shared (cooperative / team) refinement launch, 0: none yet
     long long team_fallbacks = 0;         // blocking calls whose team timed out and were refined again by one workgroup
     bool fold_select = true;              // the team kernel may run the selection in its prologue (ESAC_FOLD_SELECT=0: measurement scripts)
+    int last_nsel = 0;                    // slots the most recent blocking esac_hip_backward refined (0: none yet)
+    bool slot_teams = true;               // training path: slots may be refined by teams (off after a time-out; ESAC_SLOT_TEAMS=0)
+    long long slot_team_calls = 0, slot_team_fallbacks = 0;
+    bool last_bwd_teams = false;          // the most recent esac_hip_backward refined its slots by teams
     BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
     int bN = 0, bP = 0, bcap = 0;
     bool b_lists = false;
@@ -134,13 +138,14 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
         c->team = g < 2 ? 0 : (g > ESAC_REFINE_TEAM_MAX ? ESAC_REFINE_TEAM_MAX : g);
     }
     if (const char* e = getenv("ESAC_FOLD_SELECT")) c->fold_select = atoi(e) != 0;
+    if (const char* e = getenv("ESAC_SLOT_TEAMS")) c->slot_teams = atoi(e) != 0;
     *out = c;
     return 0;
 }
 
 static void free_bws(esac_hip_ctx* c) {
     void* ptrs[] = {c->bws.sel,   c->bws.n_sel, c->bws.probs,    c->bws.losses,     c->bws.ref_hyps, c->bws.sgrad, c->bws.dloss,
-                    c->bws.maps,  c->bws.map_info, c->bws.corr_lists, c->bws.grad1, c->bws.grad2,   c->bws.out};
+                    c->bws.maps,  c->bws.map_info, c->bws.corr_lists, c->bws.grad1, c->bws.grad2,   c->bws.out, c->bws.team_gran};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->bws = BwdArgs{};
@@ -673,11 +678,13 @@ static int ensure_bws(esac_hip_ctx* c, int N, int P, int cap) {
     rc |= alloc(&c->bws.grad1, (size_t)ncap * nP * 3);
     rc |= alloc(&c->bws.grad2, (size_t)ncap * nP * 3);
     rc |= alloc(&c->bws.out, (size_t)4);
+    rc |= alloc(&c->bws.team_gran, (size_t)ncap * 2 * ESAC_REFINE_TEAM_MAX * 32 * 2);  // 16-byte granules: [slot][parity][member][value]
     if (rc) {
         free_bws(c);
         return rc;
     }
     HIP_OK(hipMemset(c->bws.n_sel, 0, 4 * sizeof(int)));
+    HIP_OK(hipMemset(c->bws.team_gran, 0, (size_t)ncap * 2 * ESAC_REFINE_TEAM_MAX * 32 * 2 * sizeof(double)));
     c->bN = nN; c->bP = nP; c->bcap = ncap; c->b_lists = nlists;
     return 0;
 }
@@ -775,10 +782,16 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
     if ((rc = check_launch("k_sample"))) return rc;
     launch_rescore_all(a, s);                                   // esac.cpp:295-316, reference arithmetic for every hypothesis
     if ((rc = check_launch("k_rescore(all)"))) return rc;
+    // Slot refinement by teams of 8 (esac_refine_team.hip) when the previous blocking call selected few enough
+    // hypotheses that every team has an XCD's CUs to itself (<= 32); a blocking call can refine again with one workgroup
+    // per slot should a team time out, an asynchronous one cannot and does not use teams.
+    bool use_teams = h_out && c->slot_teams && c->last_nsel > 0 && c->last_nsel <= 32;
     for (int attempt = 0;; attempt++) {
         if ((rc = ensure_bws(c, p->N, P, cap))) return rc;
         a.bwd = c->bws;
         a.bwd.cap = cap;
+        a.bwd.team = 0;
+        a.bwd.team_tag = 0;
         a.bwd.out_grad = d_out_gradients;
         a.bwd.w_rot = (double)w_loss_rot;
         a.bwd.w_trans = (double)w_loss_trans;
@@ -787,7 +800,13 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
         for (int i = 0; i < 6; i++) a.bwd.gt_pose[i] = gt_pose[i];
         launch_bwd_select(a, s);                                    // esac.cpp:319-331
         if ((rc = check_launch("k_bwd_select"))) return rc;
-        launch_refine_slots(a, s);                                  // esac.cpp:328-347
+        const bool teams = use_teams && refine_slots_can_team(a);
+        if (teams) {
+            launch_refine_slots_team(a, s);                         // esac.cpp:328-347, a team per slot
+            c->slot_team_calls++;
+        } else {
+            launch_refine_slots(a, s);                              // esac.cpp:328-347
+        }
         if ((rc = check_launch("k_refine(slots)"))) return rc;
         launch_bwd_loss(a, s);                                      // esac.cpp:354-362 + dLoss + softmax derivative
         if ((rc = check_launch("k_bwd_loss"))) return rc;
@@ -799,7 +818,18 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
         if ((rc = check_launch("k_bwd_accumulate"))) return rc;
         if (!h_out) return 0;
         HIP_OK(hipMemcpyAsync(h_out, a.bwd.out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+        unsigned long long failed_tag = 0;
+        if (teams) HIP_OK(hipMemcpyAsync(&failed_tag, a.coop_counter + 1, sizeof(failed_tag), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
+        if (teams && failed_tag == a.bwd.team_tag) {  // a team timed out: nothing was accumulated; one workgroup per slot from here on
+            c->slot_team_fallbacks++;
+            c->slot_teams = false;
+            use_teams = false;
+            attempt--;
+            continue;
+        }
+        c->last_nsel = (int)h_out[1];
+        c->last_bwd_teams = teams;
         const int needed = (int)h_out[1];
         if (needed <= cap || attempt >= 1) break;  // one retry suffices: the second pass is sized by the true count
         cap = needed + 31 > worst ? worst : (needed + 31) / 32 * 32;
@@ -876,6 +906,12 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
             src = c->ws.errs; want = P * sizeof(float); break;
         case ESAC_BUF_EXACT_FLAGS: src = c->ws.exact_flag; want = N; break;
         case ESAC_BUF_CYCLES: src = c->ws.cycles; want = 32 * sizeof(long long); break;
+        case ESAC_BUF_BWD_TEAM_INFO: {
+            if (bytes != 4 * sizeof(int32_t)) return fail(-7, "esac_hip_read: the slot-team info holds 16 bytes, caller asked for %zu", bytes);
+            const int32_t info[4] = {c->last_bwd_teams ? 1 : 0, (int32_t)c->slot_team_calls, (int32_t)c->slot_team_fallbacks, (int32_t)c->last_nsel};
+            memcpy(h_dst, info, sizeof(info));
+            return 0;
+        }
         case ESAC_BUF_REFINE_INFO: {
             if (bytes != 8 * sizeof(int32_t)) return fail(-7, "esac_hip_read: the refinement info holds 32 bytes, caller asked for %zu", bytes);
             if (!c->ws.refine_info) return fail(-6, "esac_hip_read: buffer %d is empty (no call has run yet)", which);

@@ -64,6 +64,10 @@ struct BwdArgs {
     double gt_pose[6];    // trans2pose(gt) (esac_util.h:555-568)
     double w_rot, w_trans, cut;
     int cap;
+    // slot refinement by TEAMS (esac_refine_team.hip): 8 workgroups of one XCD per slot; 0 = one workgroup per slot
+    int team;
+    double* team_gran;               // [cap][2][32][32] granules (16 B each) of the slots' exchanges
+    unsigned long long team_tag;     // tag of the slot-team launch: the downstream kernels skip their work when it failed
 };
 
 struct KArgs {
@@ -169,6 +173,8 @@ unsigned long long next_refine_tag();
 bool refine_folds_select(const KArgs& a);  // the refinement launch of this call can (and will) do the selection itself
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);
+bool refine_slots_can_team(const KArgs& a);            // grid fits a team of 8 (1024 .. 8192 cells)
+unsigned long long launch_refine_slots_team(KArgs& a, hipStream_t s);  // esac_refine_team.hip; sets a.bwd.team_tag, returns it
 void launch_bwd_select(const KArgs& a, hipStream_t s);
 void launch_bwd_loss(const KArgs& a, hipStream_t s);
 void launch_bwd_path1(const KArgs& a, hipStream_t s);

@@ -350,10 +350,18 @@ __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>&
     return win;
 }
 
-template <int CPL>
+// SLOTS (training path, esac.cpp:328-347): one team of 8 per selection slot.  Blocks come in groups of 64 = 8 teams, one
+// per XCD: block L is member (L % 64) / 8 of the team on XCD L % 8 of group L / 64, which refines slot (L / 64) * 8 + L % 8.
+// Every block of such a launch is a member; teams of slots beyond n_sel leave at once.  No winner pick, no selection, no
+// record: the refined pose goes to bwd.ref_hyps, the trace to bwd.map_info, the last accepted inlier set to buffer 0 of
+// the slot's maps.  Teams become resident in dispatch order, so a launch with more teams than the chip holds at once
+// (32) drains group by group; a team never waits for a later one.
+template <int CPL, bool SLOTS = false>
 __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     constexpr int B = REFINE_B;
-    if ((blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
+    if (!SLOTS && (blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
+    const int slot = SLOTS ? (int)(blockIdx.x >> 6) * 8 + (int)(blockIdx.x & 7) : 0;
+    if (SLOTS && slot >= a.bwd.n_sel[0]) return;
     __shared__ double s_part[28 * (B / 64) > 84 ? 28 * (B / 64) : 84];  // block reductions; scratch of the pseudo-inverse step
     __shared__ double s_tot[32];
     __shared__ double s_x[TEAM_MAX * 32];  // exchanges of more than 8 members: the polled values, [member][value]
@@ -376,7 +384,13 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 #endif
     CYC_BEGIN();
     Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &s_coop_dead, false, nullptr, 0ull};
-    coop_init(co, a, (int)gridDim.x / a.team_stride, (int)blockIdx.x / a.team_stride, 1L << 22);
+    if (SLOTS) {
+        coop_init(co, a, 8, (int)(blockIdx.x & 63) >> 3, 1L << 22);
+        co.gran = reinterpret_cast<u32x4*>(a.bwd.team_gran) + (size_t)slot * (2 * TEAM_MAX * 32);
+        co.tag = a.bwd.team_tag;
+    } else {
+        coop_init(co, a, (int)gridDim.x / a.team_stride, (int)blockIdx.x / a.team_stride, 1L << 22);
+    }
     co.expect = co.G;
     if (a.coop_extra && co.g == co.G - 1) return;  // ESAC_DEBUG_COOP_STALL: the last member never shows up
     // first exchange, in flight while the winner is looked up: a census of the XCDs the members run on (64^XCC_ID each)
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     }
     if (threadIdx.x < 33) s_pow10[threadIdx.x] = pow10_int((int)threadIdx.x - 16);  // (visible after the barrier of the winner pick)
     const bool writer = co.g == 0;
-    if (writer)
+    if (writer && !SLOTS)
         for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;  // (drained by the barrier of the winner pick)
     const int cell0 = (int)((long long)P * co.g / co.G), cell1 = (int)((long long)P * (co.g + 1) / co.G);
 
@@ -409,11 +423,14 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         }
     };
     if (a.E == 1) load_cells(a.sc);
-    int nc, win;
-    double win_score;
+    int nc = 0, win;
+    double win_score = 0;
     RecordInputs rec_in{0.0, 0.0, 0ull};
     double census[1] = {0.0};
-    if (a.fold_select) {
+    if (SLOTS) {
+        win = a.bwd.sel[slot];
+        __syncthreads();  // (s_pow10, s_coop_dead)
+    } else if (a.fold_select) {
         __syncthreads();  // (s_pow10, s_coop_dead)
         team_collect<1>(census, co, s_tot, s_x);
         win = team_select<CPL>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_x, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
@@ -429,7 +446,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
     if (a.E != 1) load_cells(a.sc + (size_t)e * 3 * P);
-    if (!a.fold_select) team_collect<1>(census, co, s_tot, s_x);
+    if (SLOTS || !a.fold_select) team_collect<1>(census, co, s_tot, s_x);
     CYC_END(1);
 
     // ---- refineHyp (esac_util.h:378-454) around ONE pass site
@@ -491,7 +508,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         // error image at `param` (reproErrs, esac.cpp:169 / esac_util.h:445-452): next_set, its size, its normal equations
         if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
         const int n_inl = (int)sums[26];
-        if (writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
+        if (!SLOTS && writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
         if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
         best_inliers = (unsigned)n_inl;
         // the re-fit over next_set starts from `param`: this pass already was its first one (iters == 0: prevErrNorm = |err(initial pose)|)
@@ -513,9 +530,22 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 
     // inlierMap of the last accepted step (esac_util.h:440), every member its cells; buffer 0 (result[31] names it)
     if (accepted > 0) {
+        uint8_t* const map0 = SLOTS ? a.bwd.maps + (size_t)slot * 2 * P : a.inlier_map;
 #pragma unroll
         for (int p = 0; p < CPL; p++)
-            if (cl.cell[p] >= 0) a.inlier_map[cl.cell[p]] = (uint8_t)((acc_set >> p) & 1u);
+            if (cl.cell[p] >= 0) map0[cl.cell[p]] = (uint8_t)((acc_set >> p) & 1u);
+    }
+    if (SLOTS) {
+        if (writer && threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) a.bwd.ref_hyps[(size_t)win * 6 + k] = pose[k];
+            int* mi = a.bwd.map_info + 4 * slot;
+            mi[0] = accepted > 0 ? 0 : -1;
+            mi[1] = last_inliers;
+            mi[2] = accepted;
+            mi[3] = lm_total;
+        }
+        return;
     }
     CYC_BEGIN();
     if (threadIdx.x < 64 && writer) {  // (s_part: the last exchange's barrier lies behind every reader of it)
@@ -546,6 +576,27 @@ int refine_team_members(const KArgs& a) {
     if (G < 2) G = 2;
     if (a.coop_max < G * (a.team_stride > 0 ? a.team_stride : 8)) return 0;
     return G;
+}
+
+// Training path: a team of 8 per selection slot (k_refine_team<CPL, true>) -- grids whose eighth fits a member's registers
+bool refine_slots_can_team(const KArgs& a) {
+    const int P = a.H * a.W;
+    return a.team >= 2 && a.frames == 1 && P >= ESAC_REFINE_TEAM_MIN_CELLS && P <= 8 * TEAM_CPL_MAX * REFINE_B && a.bwd.team_gran != nullptr;
+}
+unsigned long long launch_refine_slots_team(KArgs& a, hipStream_t s) {
+    a.bwd.team_tag = next_refine_tag();
+    a.bwd.team = 8;
+    const int P = a.H * a.W;
+    const int cpl = ((P + 7) / 8 + REFINE_B - 1) / REFINE_B;
+    const int cap = a.N < a.bwd.cap ? a.N : a.bwd.cap;
+    const dim3 grid((unsigned)((cap + 7) / 8) * 64), block(REFINE_B);
+    switch (cpl) {
+        case 1: hipLaunchKernelGGL((k_refine_team<1, true>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_refine_team<2, true>), grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_refine_team<3, true>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_refine_team<4, true>), grid, block, 0, s, a); break;
+    }
+    return a.bwd.team_tag;
 }
 
 // The selection can run in the team kernel's prologue: a team refines this call, one hypothesis per thread of a member, the

@@ -75,7 +75,7 @@ ESAC_HD void rodrigues_vec2mat(const double r[3], double R[9], double* J) {
     }
 }
 
-// matrix -> vector (R orthonormal to rounding; see oracle/README.md on the omitted SVD clean-up)
+// matrix -> vector (R orthonormal to rounding: the SVD clean-up of cv::Rodrigues is omitted, as documented with the CPU checker)
 ESAC_HD void rodrigues_mat2vec(const double R[9], double r[3]) {
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
     const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);

@@ -138,6 +138,11 @@ enum {
     ESAC_BUF_BWD_DLOSS = 16,       /* double[min(N,ESAC_BWD_MAX_SLOTS),6] d loss / d refined pose per slot    */
     ESAC_BUF_BWD_PATH1 = 17,       /* double[k,3,H,W] gradient slabs of the first k slots, path I (unweighted)  */
     ESAC_BUF_BWD_PATH2 = 18,       /* double[k,3,H,W] the same for path II; k = bytes / (3*H*W*8) <= #slots     */
+    ESAC_BUF_BWD_TEAM_INFO = 20,   /* int32[4] training path: [0] 1 when the slots of the most recent esac_hip_backward were refined by
+                                      teams of 8 workgroups (one XCD each) instead of one workgroup per slot -- blocking calls
+                                      whose predecessor selected <= 32 hypotheses, grids of 1024..8192 cells; [1] such calls so
+                                      far; [2] of them, calls in which a team timed out and the slots were refined again by one
+                                      workgroup each (teams stay off on this context afterwards); [3] slots of the last call */
     ESAC_BUF_REFINE_INFO = 19      /* int32[8] how the most recent winner refinement ran (refineHyp, esac_util.h:378-454):
                                       [0] 0 one workgroup, 1 cooperating workgroups (grids beyond one LDS list), 2 a team on
                                       one XCD (small grids); [1] workgroups sharing it; [2] XCD census of a team: byte x = members

@@ -55,4 +55,7 @@ def test_doc_binding_runs_and_matches_the_product_module():
     g_doc, g_own = torch.zeros_like(sc), torch.zeros_like(sc)
     l_doc = ns["backward"](sc, g_doc, ha, gt, 1.0, 100.0, 100.0, *args)   # doc binding: call 1
     l_own = esac.backward(sc, g_own, ha, gt, 1.0, 100.0, 100.0, *args)    # product module: call 1 as well
-    assert l_doc == l_own and torch.equal(g_doc, g_own) and float(g_own.abs().max()) > 0
+    # (the doc binding's fresh context refines its slots with one workgroup each, the product module's -- which has seen a
+    # call select few hypotheses -- with teams: the same re-fits, another summation order of the LM sums)
+    assert abs(l_doc - l_own) <= 1e-9 * max(1.0, abs(l_own)) and float(g_own.abs().max()) > 0
+    assert float((g_doc - g_own).abs().max()) <= 1e-3 * float(g_own.abs().max())

@@ -9,18 +9,19 @@
 namespace esac {
 
 // ---------------------------------------------------------------- cross-lane sums
+// CTRL must be a pattern that gives EVERY lane a source (quad_perm, row_mirror, row_half_mirror: all this file uses):
+// the move then has no "old" operand.  (__builtin_amdgcn_update_dpp(v, v, ...) ties the destination to a copy of v --
+// two extra v_mov_b32 per double and stage, 56 of them in one 28-value wavefront reduction.)
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
-    int x = __float_as_int(v);
-    x = __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
-    return __int_as_float(x);
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 // all 64 lanes end up with the same (bitwise identical) total
 __device__ __forceinline__ double wave_sum(double v) {

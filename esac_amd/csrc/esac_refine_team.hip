@@ -42,6 +42,7 @@ namespace esac {
 
 constexpr int TEAM_CPL_MAX = 4;   // cells per lane a member can hold: slices of up to 1024 cells
 constexpr int TEAM_NSUM = 27;     // 24 moments | residual^2 over the running set | residual^2 over the next set | size of the next set
+constexpr int TEAM_STASH = 34;    // doubles per wavefront: U21, g6, prev (+1: 16-byte rows), see team_step
 constexpr int TEAM_LDS_PAD = 96 * 1024;  // LDS nobody touches: one member per CU (two would share its SIMDs)
 
 template <int CPL>
@@ -161,33 +162,57 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
     CYC_ADD(9, 1);
 }
 
-// normal equations in (rvec, tvec) space from the moments of a pass at the pose (.., t) whose chain-rule matrix is Mw
-__device__ __forceinline__ void team_normal_equations(const double (&sums)[TEAM_NSUM], const Cam& cam, const double (&Mw)[3][3], const double* t,
-                                                      double (&U21)[21], double (&g6)[6], long long* g_cyc) {
+// One LM step, the only site: param = prev - solve(JtJ with diag *= 1 + lambda, JtErr).
+// fresh: `param` was accepted (or is the start of a re-fit) -- it becomes `prev`, the normal equations in (rvec, tvec)
+// space come from this pass's moments (chain-rule matrix Mw at that pose) and go to the wavefront's stash with it;
+// otherwise (a rejected trial) all three come back from the stash.  lambda = 10^lambda_lg10 from a table in LDS (the binary
+// exponentiation + division of pow10_int is ~600 cycles of dependent work).  Returns whether the new trial, if accepted,
+// ends the re-fit (iters: accepted iterations so far).
+__device__ __forceinline__ bool team_step(bool fresh, const double (&sums)[TEAM_NSUM], const Cam& cam, const double (&Mw)[3][3], int lambda_lg10, int iters,
+                                          double (&param)[6], double* stash, const double* s_pow10, double* s_part, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
-    double acc[LM_NACC];
-    lm_moments_to_acc(sums, cam.fx, acc);
-    lm_transform_t(acc, Mw, t, U21, g6);
+    double U21[21], g6[6], prev[6];
+    if (fresh) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) prev[k] = param[k];
+        double acc[LM_NACC];
+        lm_moments_to_acc(sums, cam.fx, acc);
+        lm_transform_t(acc, Mw, prev + 3, U21, g6);
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 21; k++) stash[k] = U21[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) stash[21 + k] = g6[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) stash[27 + k] = prev[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 21; k++) U21[k] = stash[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) g6[k] = stash[21 + k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) prev[k] = stash[27 + k];
+    }
+    __builtin_amdgcn_wave_barrier();  // (the stash is per wavefront: its LDS traffic is ordered, nothing to wait for)
     CYC_PIN(U21, 21);
     CYC_PIN(g6, 6);
     CYC_END(7);
-}
-
-// step(): param = prev - solve(JtJ with diag *= 1 + lambda, JtErr)
-// (lambda = 10^lambda_lg10 from a table in LDS: the binary exponentiation + division of pow10_int is ~600 cycles of
-// dependent work)
-__device__ __forceinline__ void team_step(const double (&U21)[21], const double (&g6)[6], int lambda_lg10, const double (&prev)[6], double (&param)[6],
-                                          const double* s_pow10, double* s_part, long long* g_cyc) {
-    CYC_DECL;
     CYC_BEGIN();
     double dx[6];
     const double lambda = s_pow10[lambda_lg10 + 16];
     if (!lm_solve6(U21, g6, lambda, dx)) lm_solve6_pinv(U21, g6, lambda, dx, s_part);
+    double dn = 0, pn = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) param[k] = prev[k] - dx[k];
+    for (int k = 0; k < 6; k++) {
+        param[k] = prev[k] - dx[k];
+        dn += (param[k] - prev[k]) * (param[k] - prev[k]);
+        pn += prev[k] * prev[k];
+    }
     CYC_PIN(param, 6);
     CYC_END(8);
+    return iters + 1 >= 20 || relative_step_below_eps(dn, pn);
 }
 
 // ---- the selection, folded into the prologue (see the header).  N <= REFINE_B: one hypothesis per thread.
@@ -372,6 +397,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     __shared__ int s_list[B];                        // folded selection: the contenders, ascending
     __shared__ double s_rt[TEAM_SEL_CHUNK * 12];     // ... and the poses of a chunk of them
     __shared__ double s_pow10[33];  // 10^-16 .. 10^16: the LM damping factors
+    __shared__ __attribute__((aligned(16))) double s_stash[(REFINE_B / 64) * TEAM_STASH];  // per wavefront: what a rejected trial needs again (team_step)
     __shared__ char s_pad[TEAM_LDS_PAD];
     if (a.team_stride < 0) s_pad[threadIdx.x] = 1;  // (never: keeps the allocation)
     const int P = a.H * a.W;
@@ -455,78 +481,68 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     double Mw[3][3];
     unsigned run_set = 0, next_set = 0, acc_set = 0;  // sets as bit masks over this lane's cells: the running re-fit's, the one the last
                                                       // full pass found, the last ACCEPTED step's (inlierMap, esac_util.h:440)
-    double param[6], prev[6], U21[21], g6[6];
+    // The loop carries the pose (`param`), this lane's cells and a handful of scalars -- nothing else.  What only a REJECTED
+    // trial needs again (the normal equations and the point they were built at, `prev`) waits in LDS, one copy per wavefront
+    // (every lane holds the same values; lane 0 stores, everyone reads back: no barrier): 66 registers that would
+    // otherwise be shuffled between the two register files around every pass, and ONE site each for the pass, the
+    // normal equations and the solve.
+    double param[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) param[k] = prev[k] = pose[k];
+    for (int k = 0; k < 6; k++) param[k] = pose[k];
+    double* const stash = s_stash + (threadIdx.x >> 6) * TEAM_STASH;  // [0,21) U21, [21,27) g6, [27,33) prev
     int accepted = 0, last_inliers = 0, lm_total = 0, rstep = 0;
     unsigned best_inliers = 4;
     // LM state: lambda = 10^lambda_lg10, iterations of the running re-fit, |err|^2 at `prev`
     int lambda_lg10 = -3, iters = 0;
     double prev_err2 = 0;
-    bool in_refit = false;  // false: the next pass is the error image at `pose` (= param) with the first LM pass of its set
+    bool in_refit = false;   // false: the next pass is the error image at `param` with the first LM pass of its set
+    // Does the trial at `param`, if accepted, end the re-fit?  (CvLevMarq: ++iters >= max_iter, or the relative step
+    // cvNorm(param, prevParam, CV_RELATIVE_L2) < eps)  -- a function of the step alone, known when the step is taken.
+    bool ends_refit = true;
     for (;;) {
-        // Does this trial, if accepted, end the re-fit?  (CvLevMarq: ++iters >= max_iter, or the relative step
-        // cvNorm(param, prevParam, CV_RELATIVE_L2) < eps)  -- a function of the step alone.
-        bool ends_refit = true;
-        if (in_refit) {
-            double dn = 0, pn = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                dn += (param[k] - prev[k]) * (param[k] - prev[k]);
-                pn += prev[k] * prev[k];
-            }
-            ends_refit = iters + 1 >= 20 || relative_step_below_eps(dn, pn);
-        }
         team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, Mw, co, s_part, s_tot, s_x, g_cyc);
         if (co.dead) break;  // an exchange timed out: the sums are garbage, the call reports it
         CYC_BEGIN();
-        if (in_refit) {
-            if (norm_greater(sums[24], prev_err2) && ++lambda_lg10 <= 16) {  // state CHECK_ERR failed: retry from `prev` with a larger lambda
-                CYC_END(16);
-                team_step(U21, g6, lambda_lg10, prev, param, s_pow10, s_part, g_cyc);
-                continue;
+        bool fresh = true;  // normal equations from this pass (else: state CHECK_ERR failed, retry from `prev` with a larger lambda)
+        if (in_refit && norm_greater(sums[24], prev_err2) && ++lambda_lg10 <= 16) {
+            fresh = false;
+        } else {
+            if (in_refit) {
+                lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
+                ++iters;
+                if (!ends_refit) {  // state CALC_J at the accepted point
+                    prev_err2 = sums[24];
+                } else {  // the re-fit is done: its last trial is the refined pose, and this pass was its error image
+                    lm_total += iters;
+                    accepted++;
+                    last_inliers = (int)best_inliers;
+                    acc_set = run_set;
+                    in_refit = false;
+                    rstep++;
+                }
             }
-            lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
-            ++iters;
-            if (!ends_refit) {  // state CALC_J at the accepted point
-                prev_err2 = sums[24];
-#pragma unroll
-                for (int k = 0; k < 6; k++) prev[k] = param[k];
-                CYC_END(16);
-                team_normal_equations(sums, cam, Mw, prev + 3, U21, g6, g_cyc);
-                team_step(U21, g6, lambda_lg10, prev, param, s_pow10, s_part, g_cyc);
-                continue;
+            if (!in_refit) {
+                // error image at `param` (reproErrs, esac.cpp:169 / esac_util.h:445-452): next_set, its size, its normal equations
+                if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
+                const int n_inl = (int)sums[26];
+                if (!SLOTS && writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
+                if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
+                best_inliers = (unsigned)n_inl;
+                // the re-fit over next_set starts from `param`: this pass already was its first one (iters == 0: prevErrNorm = |err(initial pose)|)
+                run_set = next_set;
+                in_refit = true;
+                lambda_lg10 = -3;
+                iters = 0;
+                prev_err2 = sums[25];
             }
-            // the re-fit is done: its last trial is the refined pose, and this pass was its error image
-            lm_total += iters;
-            accepted++;
-            last_inliers = (int)best_inliers;
-            acc_set = run_set;
-            in_refit = false;
-            rstep++;
         }
-        // error image at `param` (reproErrs, esac.cpp:169 / esac_util.h:445-452): next_set, its size, its normal equations
-        if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
-        const int n_inl = (int)sums[26];
-        if (!SLOTS && writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
-        if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
-        best_inliers = (unsigned)n_inl;
-        // the re-fit over next_set starts from `param`: this pass already was its first one (iters == 0: prevErrNorm = |err(initial pose)|)
-        run_set = next_set;
-        in_refit = true;
-        lambda_lg10 = -3;
-        iters = 0;
-        prev_err2 = sums[25];
-#pragma unroll
-        for (int k = 0; k < 6; k++) prev[k] = param[k];
         CYC_END(16);
-        team_normal_equations(sums, cam, Mw, prev + 3, U21, g6, g_cyc);
-        team_step(U21, g6, lambda_lg10, prev, param, s_pow10, s_part, g_cyc);
+        ends_refit = team_step(fresh, sums, cam, Mw, lambda_lg10, iters, param, stash, s_pow10, s_part, g_cyc);
     }
     // the refined pose: the last accepted re-fit's (esac_util.h:439); a pass that ended the loop was evaluated AT it
-    // (or at the initial pose when no re-fit was accepted)
+    // (or at the initial pose when no re-fit was accepted; in_refit here only after a time-out: the point the trial left)
 #pragma unroll
-    for (int k = 0; k < 6; k++) pose[k] = in_refit ? prev[k] : param[k];  // in_refit here only after a time-out
+    for (int k = 0; k < 6; k++) pose[k] = in_refit ? stash[27 + k] : param[k];
 
     // inlierMap of the last accepted step (esac_util.h:440), every member its cells; buffer 0 (result[31] names it)
     if (accepted > 0) {

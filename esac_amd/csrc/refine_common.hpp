@@ -256,7 +256,12 @@ __device__ __forceinline__ void team_publish(double own, const Coop& co) {
 template <int NV>
 __device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot, double* s_x = nullptr) {
     static_assert(NV <= 32 && REFINE_B == 256 && TEAM_MAX <= 32, "poll layout");
-    if (co.dead) return;
+    if (co.dead) {  // (v is DEFINED on every way out: the caller's accumulators then die at its reduction and are
+                    // reduced in place -- left untouched here they stay live and every one of them is copied first)
+#pragma unroll
+        for (int kk = 0; kk < NV; kk++) v[kk] = 0.0;
+        return;
+    }
     const unsigned long long want = co.tag | (co.arrivals + 1ull);
     const u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
     const int k = threadIdx.x >> 3, j = threadIdx.x & 7;

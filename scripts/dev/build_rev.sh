@@ -6,4 +6,4 @@ d=/tmp/rev_$rev; rm -rf $d; mkdir -p $d
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 git archive $rev esac_amd/csrc include | tar -x -C $d
 cd $d/esac_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $(ls esac_kernels.hip esac_score_tiled.hip esac_refine.hip esac_backward.hip esac_capi.hip 2>/dev/null) -o $out
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $(ls *.hip) -o $out

@@ -96,9 +96,12 @@ __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(
 // exchange half-waves / odd-even rows between TWO registers in one instruction:
 //     swap32(a, b): a' = [a.lo | b.lo], b' = [a.hi | b.hi]   ->  a' + b' = [sum_halves(a) | sum_halves(b)]
 // i.e. one swap + one add reduces two values by one stage AND halves the number of live values.
-// 28 values -> 14 -> 7 registers, then four DPP stages inside the 16-lane rows: ~150 instructions
-// instead of ~600, every stage issued value-interleaved.  Afterwards row r of register q holds the
-// wavefront total of value 4q + ((r & 1) << 1 | (r >> 1)).
+// 28 values -> 14 -> 7 registers; inside the 16-lane rows the same idea with bank-masked DPP moves (a DPP move
+// can leave the lanes of chosen 4-lane banks untouched):
+//     pair8(a, b):  x = a, lanes 8-15 <- b[l-8];  y = b, lanes 0-7 <- a[l+8]   ->  x + y = [a: 8 + 8 | b: 8 + 8]
+//     pair4(a, b):  the same between neighbouring banks                        ->  banks [a | b | a' | b'] ...
+// 7 -> 4 -> 2 registers, and two plain butterflies inside the quads: ~115 instructions where 27 separate butterflies
+// are ~600.  Afterwards lane 16 r + 4 b of the two registers holds a wavefront total (see wave_totals28_to_lds).
 __device__ __forceinline__ double swap32_pairsum(double a, double b) {
     const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
@@ -113,6 +116,19 @@ __device__ __forceinline__ double swap16_pairsum(double a, double b) {
 // Stage 1 of the workgroup sum of up to 28 doubles per thread: every wavefront leaves ITS 28 totals in
 // s_part[wave * 28 ...] (ends with a workgroup barrier).  Stage 2 (workgroup_total28): thread t < 28 adds the wavefronts'
 // totals of value t in wavefront order.
+// keep, with the lanes of the 4-lane banks in BANKS (bit b: lanes 4b .. 4b+3 of every row) replaced by from[CTRL]
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double dpp_merge(double keep, double from) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(from), CTRL, 0xf, BANKS, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(from), CTRL, 0xf, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_pair8(double a, double b) {  // lanes 0-7: a[l] + a[l+8], lanes 8-15: b[l-8] + b[l]
+    return dpp_merge<0x128, 0xC>(a, b) + dpp_merge<0x128, 0x3>(b, a);  // row_ror:8 (l ^ 8 either way round)
+}
+__device__ __forceinline__ double dpp_pair4(double a, double b) {  // banks 0, 2: a[l] + a[l+4]; banks 1, 3: b[l-4] + b[l]
+    return dpp_merge<0x114, 0xA>(a, b) + dpp_merge<0x104, 0x5>(b, a);  // row_shr:4 (lane l reads l - 4), row_shl:4 (l + 4)
+}
 template <int NV>
 __device__ __forceinline__ void wave_totals28_to_lds(const double (&v)[NV], double* s_part) {
     static_assert(NV <= 28, "at most 28 values");
@@ -126,19 +142,20 @@ __device__ __forceinline__ void wave_totals28_to_lds(const double (&v)[NV], doub
     }
 #pragma unroll
     for (int q = 0; q < 7; q++) u[q] = swap16_pairsum(w[2 * q], w[2 * q + 1]);
-#pragma unroll
-    for (int q = 0; q < 7; q++) u[q] += dpp_move<0xB1>(u[q]);
-#pragma unroll
-    for (int q = 0; q < 7; q++) u[q] += dpp_move<0x4E>(u[q]);
-#pragma unroll
-    for (int q = 0; q < 7; q++) u[q] += dpp_move<0x141>(u[q]);
-#pragma unroll
-    for (int q = 0; q < 7; q++) u[q] += dpp_move<0x140>(u[q]);
-    if ((lane & 15) == 0) {
-        const int r = lane >> 4;
+    // row r of u[q] now holds 16 partial sums of value 4q + sub(r), sub(r) = (r & 1) << 1 | r >> 1
+    const double r0 = dpp_pair8(u[0], u[1]), r1 = dpp_pair8(u[2], u[3]), r2 = dpp_pair8(u[4], u[5]);
+    const double r3 = u[6] + dpp_move<0x128>(u[6]);  // (both halves of a row)
+    double q0 = dpp_pair4(r0, r1), q1 = dpp_pair4(r2, r3);  // banks of a row: u0 u2 u1 u3 | u4 u6 u5 u6
+    q0 += dpp_move<0xB1>(q0);
+    q1 += dpp_move<0xB1>(q1);
+    q0 += dpp_move<0x4E>(q0);
+    q1 += dpp_move<0x4E>(q1);
+    if ((lane & 3) == 0) {
+        const int r = lane >> 4, bank = (lane >> 2) & 3;
         const int sub = ((r & 1) << 1) | (r >> 1);
-#pragma unroll
-        for (int q = 0; q < 7; q++) s_part[wave * 28 + 4 * q + sub] = u[q];
+        const int m = ((bank & 1) << 1) | (bank >> 1);  // 0 2 1 3
+        s_part[wave * 28 + 4 * m + sub] = q0;
+        if (bank != 3) s_part[wave * 28 + 4 * (4 + m) + sub] = q1;
     }
     barrier_lds();
 }

@@ -169,15 +169,17 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
 // exponentiation + division of pow10_int is ~600 cycles of dependent work).  Returns whether the new trial, if accepted,
 // ends the re-fit (iters: accepted iterations so far).
 __device__ __forceinline__ bool team_step(bool fresh, const double (&sums)[TEAM_NSUM], const Cam& cam, const double (&Mw)[3][3], int lambda_lg10, int iters,
-                                          double (&param)[6], double* stash, const double* s_pow10, double* s_part, long long* g_cyc) {
+                                          double (&param)[6], double inv_f, double* stash, const double* s_pow10, double* s_part, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
     double U21[21], g6[6], prev[6];
     if (fresh) {
 #pragma unroll
         for (int k = 0; k < 6; k++) prev[k] = param[k];
+        // in units of the focal length: JtJ / f^2 and JtErr / f (the damping is relative, the pivot tests are relative: the
+        // step of these equations is f times the step -- six multiplications below instead of 27 here)
         double acc[LM_NACC];
-        lm_moments_to_acc(sums, cam.fx, acc);
+        lm_moments_to_acc(sums, 1.0, acc);
         lm_transform_t(acc, Mw, prev + 3, U21, g6);
         if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -206,7 +208,7 @@ __device__ __forceinline__ bool team_step(bool fresh, const double (&sums)[TEAM_
     double dn = 0, pn = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        param[k] = prev[k] - dx[k];
+        param[k] = prev[k] - dx[k] * inv_f;
         dn += (param[k] - prev[k]) * (param[k] - prev[k]);
         pn += prev[k] * prev[k];
     }
@@ -499,6 +501,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     // Does the trial at `param`, if accepted, end the re-fit?  (CvLevMarq: ++iters >= max_iter, or the relative step
     // cvNorm(param, prevParam, CV_RELATIVE_L2) < eps)  -- a function of the step alone, known when the step is taken.
     bool ends_refit = true;
+    const double inv_f = 1.0 / cam.fx;
     for (;;) {
         team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, Mw, co, s_part, s_tot, s_x, g_cyc);
         if (co.dead) break;  // an exchange timed out: the sums are garbage, the call reports it
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
             }
         }
         CYC_END(16);
-        ends_refit = team_step(fresh, sums, cam, Mw, lambda_lg10, iters, param, stash, s_pow10, s_part, g_cyc);
+        ends_refit = team_step(fresh, sums, cam, Mw, lambda_lg10, iters, param, inv_f, stash, s_pow10, s_part, g_cyc);
     }
     // the refined pose: the last accepted re-fit's (esac_util.h:439); a pass that ended the loop was evaluated AT it
     // (or at the initial pose when no re-fit was accepted; in_refit here only after a time-out: the point the trial left)

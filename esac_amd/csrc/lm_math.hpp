@@ -242,26 +242,25 @@ ESAC_HD void lm_chain(const double R[9], const double dRdr[27], const double t[3
 // In two halves: the rotation (what a pass needs before its first correspondence) and the chain-rule matrices (what
 // only the transform AFTER the pass's reduction needs -- a team computes them while its exchange is in flight).
 //
-// No square root, no division, no sin / cos for |r| <= sqrt(10) (every pose this path meets): with x = |r|^2
+// No square root, no sin / cos for |r| <= sqrt(10) (every pose this path meets): with x = |r|^2
 //     R   = I + A(x) [r]x + B(x) [r]x^2,        A = sin(th)/th,  B = (1 - cos(th))/th^2,
 //     J_l = A(x) I + B(x) [r]x + C(x) r r^T,    C = (th - sin(th))/th^3 = (1 - A)/x,
-// and A, B, C are entire functions of x: their Taylor polynomials of degree 15 in x (next term 10^16 / 33! ~ 1e-21) are
-// good to 3e-16 absolute on [0, 10] (checked against 60-digit arithmetic), evaluated by Estrin's scheme: five dependent
-// operations where sqrt -> division -> sincos is ~25.  Beyond |r|^2 = 10 the trigonometric route (1 / th from v_rsq_f64).
+// and A, B are entire functions of x: Taylor polynomials of degree 7 at a quarter of the angle (Estrin's scheme) and two
+// angle doublings are good to 3.3e-16 absolute on [0, 10] (checked against 80-digit arithmetic; the degree-15 polynomials
+// at the full angle: 2.7e-16 -- and 32 constants of two scalar moves each on a section every lane walks, where this has
+// 16): ~10 dependent operations where sqrt -> division -> sincos is ~25.  Beyond |r|^2 = 10 the trigonometric route
+// (1 / th from v_rsq_f64).
 struct LmTrig {
     double rx, ry, rz, x;  // rvec, |rvec|^2
     double A, B;           // sin(th)/th, (1 - cos(th))/th^2
     bool identity;         // |rvec| < DBL_EPSILON
-    bool series;           // A, B came from the series: C does too
 };
 
-// sum_k c[k] x^k, k < 16: pairs, quads, octets (Estrin)
-ESAC_HD double lm_estrin16(const double (&c)[16], double x, double x2, double x4, double x8) {
+// sum_k c[k] y^k, k < 8: pairs, quads (Estrin)
+ESAC_HD double lm_estrin8(const double (&c)[8], double y, double y2, double y4) {
 #pragma clang fp contract(fast)
-    const double p0 = c[0] + c[1] * x, p1 = c[2] + c[3] * x, p2 = c[4] + c[5] * x, p3 = c[6] + c[7] * x;
-    const double p4 = c[8] + c[9] * x, p5 = c[10] + c[11] * x, p6 = c[12] + c[13] * x, p7 = c[14] + c[15] * x;
-    const double q0 = p0 + p1 * x2, q1 = p2 + p3 * x2, q2 = p4 + p5 * x2, q3 = p6 + p7 * x2;
-    return (q0 + q1 * x4) + (q2 + q3 * x4) * x8;
+    const double p0 = c[0] + c[1] * y, p1 = c[2] + c[3] * y, p2 = c[4] + c[5] * y, p3 = c[6] + c[7] * y;
+    return (p0 + p1 * y2) + (p2 + p3 * y2) * y4;
 }
 
 ESAC_HD void lm_pose_rotation(const double param[6], double R[9], LmTrig& tg) {
@@ -270,7 +269,7 @@ ESAC_HD void lm_pose_rotation(const double param[6], double R[9], LmTrig& tg) {
     const double x = rx * rx + ry * ry + rz * rz;
     tg.rx = rx; tg.ry = ry; tg.rz = rz; tg.x = x;
     tg.identity = x < DBL_EPSILON * DBL_EPSILON;
-    tg.series = x <= 10.0;
+    const bool series = x <= 10.0;
     if (tg.identity) {
         R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
         tg.A = 1;
@@ -278,12 +277,18 @@ ESAC_HD void lm_pose_rotation(const double param[6], double R[9], LmTrig& tg) {
         return;
     }
     double A, B;
-    if (tg.series) {
-        const double cA[16] = {1.00000000000000000e+00, -1.66666666666666657e-01, 8.33333333333333322e-03, -1.98412698412698413e-04, 2.75573192239858925e-06, -2.50521083854417202e-08, 1.60590438368216133e-10, -7.64716373181981641e-13, 2.81145725434552060e-15, -8.22063524662432950e-18, 1.95729410633912626e-20, -3.86817017063068354e-23, 6.44695028438447359e-26, -9.18368986379554601e-29, 1.13099628864477181e-31, -1.21612504155351811e-34};
-        const double cB[16] = {5.00000000000000000e-01, -4.16666666666666644e-02, 1.38888888888888894e-03, -2.48015873015873016e-05, 2.75573192239858883e-07, -2.08767569878681002e-09, 1.14707455977297245e-11, -4.77947733238738525e-14, 1.56192069685862253e-16, -4.11031762331216484e-19, 8.89679139245057408e-22, -1.61173757109611839e-24, 2.47959626322479723e-27, -3.27988923706983776e-30, 3.76998762881590539e-33, -3.80039075485474409e-36};
-        const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
-        A = lm_estrin16(cA, x, x2, x4, x8);
-        B = lm_estrin16(cB, x, x2, x4, x8);
+    if (series) {
+        // at a quarter of the angle (y = x / 16 <= 0.625: degree 7, next term 0.625^8 / 17! = 7e-17), then two angle
+        // doublings:  cos(t) = 1 - t^2 B(t),  A(2t) = A(t) cos(t),  B(2t) = A(t)^2 / 2
+        const double cA[8] = {1.00000000000000000e+00, -1.66666666666666657e-01, 8.33333333333333322e-03, -1.98412698412698413e-04,
+                              2.75573192239858925e-06, -2.50521083854417202e-08, 1.60590438368216133e-10, -7.64716373181981641e-13};
+        const double cB[8] = {5.00000000000000000e-01, -4.16666666666666644e-02, 1.38888888888888894e-03, -2.48015873015873016e-05,
+                              2.75573192239858883e-07, -2.08767569878681002e-09, 1.14707455977297245e-11, -4.77947733238738525e-14};
+        const double y = x * 0.0625, y2 = y * y, y4 = y2 * y2;
+        const double A4 = lm_estrin8(cA, y, y2, y4), B4 = lm_estrin8(cB, y, y2, y4);
+        const double A2 = A4 * (1. - y * B4), B2 = (0.5 * A4) * A4;
+        A = A2 * (1. - (x * 0.25) * B2);
+        B = (0.5 * A2) * A2;
     } else {  // (a NaN pose also lands here and stays NaN)
 #if defined(__HIP_DEVICE_COMPILE__)
         double itheta = __builtin_amdgcn_rsq(x);
@@ -319,14 +324,10 @@ ESAC_HD void lm_pose_left_jacobian(const LmTrig& tg, double (&Mw)[3][3]) {
         return;
     }
     const double rx = tg.rx, ry = tg.ry, rz = tg.rz, x = tg.x, A = tg.A, B = tg.B;
-    double C;
-    if (tg.series) {
-        const double cC[16] = {1.66666666666666657e-01, -8.33333333333333322e-03, 1.98412698412698413e-04, -2.75573192239858925e-06, 2.50521083854417202e-08, -1.60590438368216133e-10, 7.64716373181981641e-13, -2.81145725434552060e-15, 8.22063524662432950e-18, -1.95729410633912626e-20, 3.86817017063068354e-23, -6.44695028438447359e-26, 9.18368986379554601e-29, -1.13099628864477181e-31, 1.21612504155351811e-34, -1.15163356207719509e-37};
-        const double x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
-        C = lm_estrin16(cC, x, x2, x4, x8);
-    } else {
-        C = (1. - A) / x;
-    }
+    // C = (1 - A) / x: the cancellation in 1 - A costs C a relative 1e-16 / (x / 6), but C only ever multiplies r r^T
+    // (entries <= x), so J_l keeps an absolute 1e-16 at every x (a third polynomial here was 16 more constants and
+    // FMAs on a section every lane walks)
+    const double C = (1. - A) * fast_rcp(x);
     const double Cx = C * rx, Cy = C * ry, Cz = C * rz;
     // J_l = A I + B [r]x + C r r^T
     Mw[0][0] = A + Cx * rx;       Mw[0][1] = Cx * ry - B * rz;  Mw[0][2] = Cx * rz + B * ry;

@@ -145,6 +145,8 @@ __device__ __forceinline__ double pow10_int(int k) {
 __device__ __forceinline__ bool norm_greater(double a, double b) {
     if (!(a > b)) return false;
     if (a > b * (1.0 + 8.0 * DBL_EPSILON)) return true;
+    asm volatile("; norms a few ulp apart");  // (keeps the two square roots BEHIND the branch: as plain arithmetic they are
+                                              // if-converted and run on every pass, ~45 instructions)
     return sqrt(a) > sqrt(b);
 }
 // cvNorm(param, prevParam, CV_RELATIVE_L2) < FLT_EPSILON, i.e. sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < eps, dn = |param - prev|^2,

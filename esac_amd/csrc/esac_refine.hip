@@ -441,14 +441,30 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     constexpr bool SHARED = MODE != REFINE_SOLO;
     static_assert(!SHARED || (!GLOBAL_LIST && !SLOTS), "cooperating workgroups keep their slices' lists in LDS; winner refinement only");
     static_assert(MODE == REFINE_SOLO || MODE == REFINE_COOP, "esac_refine_team.hip holds the team kernel");
-    __shared__ Corr s_list[GLOBAL_LIST ? 1 : LDS_CAP];
-    __shared__ double s_part[MODE == REFINE_COOP ? 256 : 28 * (B / 64)];  // block reductions; the REFINE_COOP gather uses 8 x 32
-    __shared__ double s_tot[32];
-    __shared__ double s_best[B / 64];
-    __shared__ int s_besti[B / 64];
-    __shared__ int s_bestg[B / 64];
-    __shared__ int s_wcnt[B / 64];  // inliers each wavefront put into its region of the list
-    __shared__ double s_pow10[33];  // 10^-16 .. 10^16: the LM damping factors
+    // ONE allocation, the small arrays first: their addresses then fit the 16-bit offset field of the LDS instructions.
+    // (As separate variables they were laid out behind the 128 KB list, and every access to them materialised its own
+    // address first.)
+    struct Lds {
+        double part[MODE == REFINE_COOP ? 256 : 28 * (B / 64)];  // block reductions; the REFINE_COOP gather uses 8 x 32
+        double tot[32];
+        double pow10[34];  // 10^-16 .. 10^16: the LM damping factors
+        double best[B / 64];
+        int besti[B / 64];
+        int bestg[B / 64];
+        int wcnt[B / 64];  // inliers each wavefront put into its region of the list
+        int coop_dead;
+        int pad_[3];
+        Corr list[GLOBAL_LIST ? 1 : LDS_CAP];
+    };
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    Corr* const s_list = lds.list;
+    double* const s_part = lds.part;
+    double* const s_tot = lds.tot;
+    double* const s_best = lds.best;
+    int* const s_besti = lds.besti;
+    int* const s_bestg = lds.bestg;
+    int* const s_wcnt = lds.wcnt;
+    double* const s_pow10 = lds.pow10;
     static_assert(B == REFINE_B, "corr_region() assumes the refinement workgroup size");
     if (threadIdx.x < 33) s_pow10[threadIdx.x] = pow10_int((int)threadIdx.x - 16);  // (visible after the barriers of the winner pick)
     frame_view(a);
@@ -464,8 +480,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
 #endif
     CYC_BEGIN();
     if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
-    __shared__ int s_coop_dead;
-    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &s_coop_dead, false, nullptr, 0ull};
+    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull};
     int cell0 = 0, Pn = P;  // this workgroup's cells: [cell0, cell0 + Pn)
     if (SHARED) {
         coop_init(co, a, (int)gridDim.x, (int)blockIdx.x, 1L << 25);

@@ -172,6 +172,7 @@ __device__ __forceinline__ bool team_step(bool fresh, const double (&sums)[TEAM_
                                           double (&param)[6], double inv_f, double* stash, const double* s_pow10, double* s_part, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
+    const double lambda = s_pow10[lambda_lg10 + 16];  // (read here: behind the stash's stores it waits for all of them)
     double U21[21], g6[6], prev[6];
     if (fresh) {
 #pragma unroll
@@ -203,7 +204,6 @@ __device__ __forceinline__ bool team_step(bool fresh, const double (&sums)[TEAM_
     CYC_END(7);
     CYC_BEGIN();
     double dx[6];
-    const double lambda = s_pow10[lambda_lg10 + 16];
     if (!lm_solve6(U21, g6, lambda, dx)) lm_solve6_pinv(U21, g6, lambda, dx, s_part);
     double dn = 0, pn = 0;
 #pragma unroll
@@ -389,19 +389,35 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     if (!SLOTS && (blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
     const int slot = SLOTS ? (int)(blockIdx.x >> 6) * 8 + (int)(blockIdx.x & 7) : 0;
     if (SLOTS && slot >= a.bwd.n_sel[0]) return;
-    __shared__ double s_part[28 * (B / 64) > 84 ? 28 * (B / 64) : 84];  // block reductions; scratch of the pseudo-inverse step
-    __shared__ double s_tot[32];
-    __shared__ double s_x[TEAM_MAX * 32];  // exchanges of more than 8 members: the polled values, [member][value]
-    __shared__ double s_best[B / 64];
-    __shared__ int s_besti[B / 64];
-    __shared__ int s_bestg[B / 64];
-    __shared__ int s_coop_dead;
-    __shared__ int s_list[B];                        // folded selection: the contenders, ascending
-    __shared__ double s_rt[TEAM_SEL_CHUNK * 12];     // ... and the poses of a chunk of them
-    __shared__ double s_pow10[33];  // 10^-16 .. 10^16: the LM damping factors
-    __shared__ __attribute__((aligned(16))) double s_stash[(REFINE_B / 64) * TEAM_STASH];  // per wavefront: what a rejected trial needs again (team_step)
-    __shared__ char s_pad[TEAM_LDS_PAD];
-    if (a.team_stride < 0) s_pad[threadIdx.x] = 1;  // (never: keeps the allocation)
+    // ONE allocation, the arrays first: their addresses then fit the 16-bit offset field of the LDS instructions (one base
+    // register for all of them).  As separate variables they were laid out behind the 96 KB pad, and every access
+    // materialised its own address first -- an extra instruction per LDS access on a section every lane walks.
+    struct Lds {
+        double part[28 * (B / 64) > 84 ? 28 * (B / 64) : 84];  // block reductions; scratch of the pseudo-inverse step
+        double tot[32];
+        double stash[(REFINE_B / 64) * TEAM_STASH];  // per wavefront: what a rejected trial needs again (team_step)
+        double pow10[34];                            // 10^-16 .. 10^16: the LM damping factors
+        double x[TEAM_MAX * 32];                     // exchanges of more than 8 members: the polled values, [member][value]
+        double rt[TEAM_SEL_CHUNK * 12];              // folded selection: the poses of a chunk of contenders
+        double best[B / 64];
+        int besti[B / 64];
+        int bestg[B / 64];
+        int list[B];                                 // folded selection: the contenders, ascending
+        int coop_dead;
+        char pad[TEAM_LDS_PAD];                      // LDS nobody touches: one member per CU
+    };
+    __shared__ __attribute__((aligned(16))) Lds lds;
+    double* const s_part = lds.part;
+    double* const s_tot = lds.tot;
+    double* const s_x = lds.x;
+    double* const s_best = lds.best;
+    int* const s_besti = lds.besti;
+    int* const s_bestg = lds.bestg;
+    int* const s_list = lds.list;
+    double* const s_rt = lds.rt;
+    double* const s_pow10 = lds.pow10;
+    double* const s_stash = lds.stash;
+    if (a.team_stride < 0) lds.pad[threadIdx.x] = 1;  // (never: keeps the allocation)
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
     long long g_cyc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -411,7 +427,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     const long long cyc_start = clock64();
 #endif
     CYC_BEGIN();
-    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &s_coop_dead, false, nullptr, 0ull};
+    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull};
     if (SLOTS) {
         coop_init(co, a, 8, (int)(blockIdx.x & 63) >> 3, 1L << 22);
         co.gran = reinterpret_cast<u32x4*>(a.bwd.team_gran) + (size_t)slot * (2 * TEAM_MAX * 32);

@@ -432,23 +432,33 @@ ESAC_HD void lm_transform_t(const double acc[LM_NACC], const double (&Mw)[3][3],
     const double Avv[3][3] = {{acc[15], 0.0, acc[16]}, {0.0, acc[17], acc[18]}, {acc[16], acc[18], acc[19]}};
     // (X Tx)[i][:] = (X[i][1] t2 - X[i][2] t1,  X[i][2] t0 - X[i][0] t2,  X[i][0] t1 - X[i][1] t0)   (row x t, negated: -(t x row))
     // (Tx^T Y)[:][j] = -(t x Y[:][j]) = Y[:][j] x t
+    // (E = Awv + Tx^T Avv written out: Avv[0][1] = Avv[1][0] = 0 and Awv[2][2] = acc[14] = 0 are structural zeros, and a
+    // product with a literal 0.0 is an instruction the compiler may not drop)
     double E[3][3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        E[0][j] = Awv[0][j] + (Avv[1][j] * t2 - Avv[2][j] * t1);
-        E[1][j] = Awv[1][j] + (Avv[2][j] * t0 - Avv[0][j] * t2);
-        E[2][j] = Awv[2][j] + (Avv[0][j] * t1 - Avv[1][j] * t0);
-    }
+    E[0][0] = Awv[0][0] - Avv[2][0] * t1;
+    E[1][0] = Awv[1][0] + (Avv[2][0] * t0 - Avv[0][0] * t2);
+    E[2][0] = Awv[2][0] + Avv[0][0] * t1;
+    E[0][1] = Awv[0][1] + (Avv[1][1] * t2 - Avv[2][1] * t1);
+    E[1][1] = Awv[1][1] + Avv[2][1] * t0;
+    E[2][1] = Awv[2][1] - Avv[1][1] * t0;
+    E[0][2] = Awv[0][2] + (Avv[1][2] * t2 - Avv[2][2] * t1);
+    E[1][2] = Awv[1][2] + (Avv[2][2] * t0 - Avv[0][2] * t2);
+    E[2][2] = Avv[0][2] * t1 - Avv[1][2] * t0;
     double ET[3][3], AT[3][3];  // E Tx, Awv Tx
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         ET[i][0] = E[i][1] * t2 - E[i][2] * t1;
         ET[i][1] = E[i][2] * t0 - E[i][0] * t2;
         ET[i][2] = E[i][0] * t1 - E[i][1] * t0;
-        AT[i][0] = Awv[i][1] * t2 - Awv[i][2] * t1;
-        AT[i][1] = Awv[i][2] * t0 - Awv[i][0] * t2;
         AT[i][2] = Awv[i][0] * t1 - Awv[i][1] * t0;
     }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        AT[i][0] = Awv[i][1] * t2 - Awv[i][2] * t1;
+        AT[i][1] = Awv[i][2] * t0 - Awv[i][0] * t2;
+    }
+    AT[2][0] = Awv[2][1] * t2;
+    AT[2][1] = -(Awv[2][0] * t2);
     double B[3][3];
 #pragma unroll
     for (int i = 0; i < 3; i++)

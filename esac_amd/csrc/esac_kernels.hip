@@ -270,17 +270,24 @@ __global__ __launch_bounds__(1024) void k_pending_list(KArgs a) {
     a.samp_pending[s_base + s_wave[wave] + __popcll(m & ((1ull << lane) - 1ull))] = (int)blockIdx.y * a.N + h;
 }
 
-// SAMPLE_B = tries evaluated per round.  A single call wants latency (256 tries = 4 wavefronts per hypothesis:
-// nearly every hypothesis is accepted in round one, the other CUs are idle anyway); thousands of hypotheses
-// in flight (many experts, batched frames) want throughput (64 tries = one wavefront, no wasted solves).
-// QUAD: in the first rounds (SAMPLE_B tries) four lanes share a try, lane q evaluates the candidate of quartic root q (lengths +
-// alignment + 4th-point error, the long part of the solver) and the four agree on the winner through shuffles -- the
-// dependent chain of a try is one candidate long instead of up to four.  A hypothesis on a good map is accepted within
-// its first few dozen tries, so the single-frame launch, where latency is everything, ends after one or two short
-// rounds; a hypothesis that needs hundreds of tries (wrong expert) continues with one try per lane, the throughput shape.
-template <int SAMPLE_B, bool QUAD>
+// SAMPLE_B = lanes per hypothesis.  A single call wants latency (4 wavefronts per hypothesis: nearly every hypothesis
+// is accepted in round one, the other CUs are idle anyway); thousands of hypotheses in flight (many experts, batched
+// frames) want throughput (one wavefront, one try per lane, no wasted solves).
+// LPT = lanes per try in the first rounds (tries below SAMPLE_B): the (up to four) candidates of a try -- lengths +
+// alignment + 4th-point error per quartic root, the long part of the solver -- are dealt to LPT lanes, 4 / LPT each, and
+// the lanes agree on the winner through shuffles.  LPT = 4: the dependent chain of a try is one candidate long, 64 tries a
+// round at 256 lanes (config 3's shape: two hypotheses per CU).  LPT = 2 (the single frame, round 4): two candidates
+// per lane, 128 tries a round -- a hypothesis on a usable map is accepted at try ~15 on average and 1.8 % of them need
+// more than 64, so with 256 hypotheses three frames in four paid a second 64-try round (8.5 us); one in twenty needs a
+// second 128-try one.  The chip holds no more than this: the fp64 solver with its decision path needs ~445 registers,
+// one wavefront per SIMD, and 256 hypotheses x 4 wavefronts fill the 1024 SIMDs.
+// A hypothesis that needs hundreds of tries (wrong expert) continues with one try per lane, the throughput shape.
+template <int SAMPLE_B, int LPT>
 __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
+    static_assert(LPT == 1 || LPT == 2 || LPT == 4, "lanes per try");
+    constexpr int CPLN = 4 / LPT;  // candidates per lane in the shared rounds
     __shared__ int s_first[2][SAMPLE_B / 64];
+    __shared__ double s_pose[CPLN > 1 ? SAMPLE_B * 12 : 1];  // [value][lane]: the best candidate's pose so far, per lane
     frame_view(a);
     const int h = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -297,11 +304,11 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
 
     int parity = 0;
     for (int base = a.first_try, TRIES = 0; base < a.max_tries; base += TRIES, parity ^= 1) {
-        const bool quad = QUAD && base < SAMPLE_B;  // workgroup-uniform: the first SAMPLE_B tries go four lanes a try
-        TRIES = quad ? SAMPLE_B / 4 : SAMPLE_B;
-        const int t = base + (quad ? (int)threadIdx.x >> 2 : (int)threadIdx.x);
-        const int root = threadIdx.x & 3;  // quad round only
-        bool holder = !quad;               // the lane that carries the try's final state (pose or zero pose)
+        const bool quad = LPT > 1 && base < SAMPLE_B;  // workgroup-uniform: the first SAMPLE_B tries go LPT lanes a try
+        TRIES = quad ? SAMPLE_B / LPT : SAMPLE_B;
+        const int t = base + (quad ? (int)threadIdx.x / LPT : (int)threadIdx.x);
+        const int sub = threadIdx.x & (LPT - 1);  // shared rounds only: this lane evaluates roots sub, sub + LPT, ...
+        bool holder = !quad;                      // the lane that carries the try's final state (pose or zero pose)
         const bool active = t < a.max_tries;
         int cx[4] = {0, 0, 0, 0}, cy[4] = {0, 0, 0, 0};
         double rvec[3] = {0, 0, 0}, T[3] = {0, 0, 0};
@@ -314,29 +321,54 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
             gather_sample(a, map, P, rng, gh, (uint32_t)t, cx, cy, Pt, Pf, mu, mv);
             double Rp[9], Tp[3], reproj2 = 0;
             bool solved;
-            if (QUAD && quad) {
+            if (LPT > 1 && quad) {
                 P3PSetup S;
                 const bool ok = p3p_setup(Pt, mu, mv, cam, S);
-                const double x = root == 0 ? S.x[0] : root == 1 ? S.x[1] : root == 2 ? S.x[2] : S.x[3];
-                double reproj = 0;
-                const bool valid = ok && root < S.n && p3p_candidate(S, x, Pt, mu[3], mv[3], cam, Rp, Tp, reproj);
-                // every lane replays the sequential scan over the four candidates (same `>` rule, same NaN behaviour)
-                const int quad0 = lane & ~3;
+                // Step k: the lanes evaluate roots k * LPT .. k * LPT + LPT - 1 (this lane: root k * LPT + sub), exchange
+                // (valid, error) and continue the reference's sequential scan over the candidates (same `>` rule, same NaN
+                // behaviour) -- every lane carries the scan's state, and the lane whose candidate has just become the best
+                // keeps its pose: after the last step the winner's lane holds the winner's pose.
+                const int lane0 = lane & ~(LPT - 1);
                 bool have = false;
                 double min_reproj = 0;
                 int win = -1;
+#pragma nounroll
+                for (int k = 0; k < CPLN; k++) {
+                    const int root = k * LPT + sub;
+                    const double x = root == 0 ? S.x[0] : root == 1 ? S.x[1] : root == 2 ? S.x[2] : S.x[3];
+                    double R1[9], T1[3], rp = 0;
+                    const bool vk = ok && root < S.n && p3p_candidate(S, x, Pt, mu[3], mv[3], cam, R1, T1, rp);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const bool vi = __shfl((int)valid, quad0 + i) != 0;
-                    const double ri = __shfl(reproj, quad0 + i);
-                    if (vi && (!have || min_reproj > ri)) {
-                        have = true;
-                        min_reproj = ri;
-                        win = i;
+                    for (int j = 0; j < LPT; j++) {
+                        const bool vi = __shfl((int)vk, lane0 + j) != 0;
+                        const double ri = __shfl(rp, lane0 + j);
+                        if (vi && (!have || min_reproj > ri)) {
+                            have = true;
+                            min_reproj = ri;
+                            win = k * LPT + j;
+                        }
+                    }
+                    if (win == root) {  // (more than one step: the pose waits in LDS, not in 24 registers across the next solve)
+#pragma unroll
+                        for (int q = 0; q < 9; q++) {
+                            if (CPLN > 1) s_pose[q * SAMPLE_B + threadIdx.x] = R1[q];
+                            else Rp[q] = R1[q];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            if (CPLN > 1) s_pose[(9 + q) * SAMPLE_B + threadIdx.x] = T1[q];
+                            else Tp[q] = T1[q];
+                        }
                     }
                 }
-                solved = have && win == root;
-                holder = solved || (!have && root == 0);
+                solved = have && (win & (LPT - 1)) == sub;
+                if (CPLN > 1 && solved) {
+#pragma unroll
+                    for (int q = 0; q < 9; q++) Rp[q] = s_pose[q * SAMPLE_B + threadIdx.x];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) Tp[q] = s_pose[(9 + q) * SAMPLE_B + threadIdx.x];
+                }
+                holder = solved || (!have && sub == 0);
                 reproj2 = min_reproj;
             } else {
                 solved = p3p_4pt(Pt, mu, mv, cam, Rp, Tp, &reproj2);
@@ -349,7 +381,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
         const unsigned long long m = __ballot(accepted);
         if (lane == 0) {
             const int first_lane = __ffsll((long long)m) - 1;
-            s_first[parity][wave] = m ? base + (quad ? wave * 16 + (first_lane >> 2) : wave * 64 + first_lane) : 0x7fffffff;
+            s_first[parity][wave] = m ? base + (quad ? wave * (64 / LPT) + first_lane / LPT : wave * 64 + first_lane) : 0x7fffffff;
         }
         __syncthreads();
         int first = s_first[parity][0];
@@ -1306,10 +1338,10 @@ constexpr int ESAC_CHAIN_PER_HYP = 8;
         // registers).  Beyond that the workgroups queue up behind each other (1024 hypotheses: four ~12 us rounds back to
         // back, 51 us measured): two wavefronts per hypothesis (32 tries per round -- 93 % of the hypotheses of a usable
         // map are settled in it) put two hypotheses on a CU at a time.
-        if (total <= 256) hipLaunchKernelGGL((k_sample<256, true>), dim3(a.N, a.frames), dim3(256), 0, s, b);
-        else              hipLaunchKernelGGL((k_sample<128, true>), dim3(a.N, a.frames), dim3(128), 0, s, b);
+        if (total <= 256) hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, a.frames), dim3(256), 0, s, b);
+        else              hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else if (total <= 4096 && !handover) {
-        hipLaunchKernelGGL((k_sample<128, false>), dim3(a.N, a.frames), dim3(128), 0, s, b);
+        hipLaunchKernelGGL((k_sample<128, 1>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
         if (total <= ESAC_FIRST_WIDE_MAX) {
             hipLaunchKernelGGL(k_sample_first<32>, dim3((a.N + 1) / 2, a.frames), dim3(64), 0, s, b);
@@ -1326,7 +1358,7 @@ constexpr int ESAC_CHAIN_PER_HYP = 8;
         }
         if (b.first_try < a.max_tries) {
             if (exact) {
-                hipLaunchKernelGGL((k_sample<64, false>), dim3(a.N, a.frames), dim3(64), 0, s, b);  // every try solved in full
+                hipLaunchKernelGGL((k_sample<64, 1>), dim3(a.N, a.frames), dim3(64), 0, s, b);  // every try solved in full
             } else {
                 hipLaunchKernelGGL(k_pending_list, dim3((a.N + 1023) / 1024, a.frames), dim3(1024), 0, s, b);
                 // (the list stays in hypothesis order: expert-major and dealt to the XCDs, the full-resolution workload's

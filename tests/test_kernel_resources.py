@@ -63,7 +63,7 @@ def test_streaming_and_selection_kernels_stay_lean(tmp_path):
         assert u["ScratchSize"] == 0 and u["VGPRs"] <= 72, (name, u)   # 7 wavefronts per SIMD (the packed-fp32 form holds the pose as register pairs)
     sel = [v for n, v in k.items() if "k_select_rescore" in n]
     assert sel and all(u["ScratchSize"] == 0 and u["VGPRs"] <= 128 for u in sel)  # 1024-thread workgroups
-    quad = [v for n, v in k.items() if "k_sampleILi256ELb1" in n]
+    quad = [v for n, v in k.items() if "k_sampleILi256ELi2" in n]
     assert quad and quad[0]["ScratchSize"] == 0                         # the single-frame sampler runs from registers
     pre = [v for n, v in k.items() if "k_sample_prescreen" in n]
     assert pre and pre[0]["ScratchSize"] == 0 and pre[0]["VGPRs"] <= 256        # the fp64 screen: 2 wavefronts per SIMD

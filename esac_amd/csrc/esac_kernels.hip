@@ -9,7 +9,7 @@
 //   K4 k_refine        draw(argmax) + refineHyp + pose2trans       esac_util.h:378-454,505-548
 //
 // Mapping to CDNA4: K1 = one hypothesis per workgroup, a lane evaluates one sampling try with the whole P3P in fp64
-// registers (single frames: the four candidates of a try on four lanes; thousands of hypotheses: four hypotheses per
+// registers (single frames: the four candidates of a try on two lanes; thousands of hypotheses: four hypotheses per
 // wavefront for their first 16 tries), `ballot` picks the lowest accepted try (= the try a sequential loop would stop
 // at).  K2 = one hypothesis per workgroup, the H x W map streamed with 16-byte coalesced loads (x/y/z planes), ~30 fp32
 // VALU ops per cell, DPP wavefront reductions; no MFMA: there is no dense contraction anywhere on this path.
@@ -1309,7 +1309,7 @@ void launch_sample(const KArgs& a, hipStream_t s) {
     // of every sampling launch cost the headline call, which never appends to them, 5 us (0.2058 -> 0.2010 ms).
     KArgs b = a;
     b.handover = 0x7fffffff;
-    // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on four lanes at first)
+    // Few hypotheses in flight: latency.  A workgroup per hypothesis (the candidates of a try on two or four lanes at first)
     // settles a hypothesis of the right expert within its first round; with several experts the stragglers are handed to
     // the spread, screened search after `handover` tries (every wavefront of that launch works, rounds handed out in order).  Beyond ~10^3
     // hypotheses (several experts) a workgroup per hypothesis no longer fits the chip in one wave of workgroups: the
@@ -1334,10 +1334,11 @@ constexpr int ESAC_CHAIN_PER_HYP = 8;
     const int waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > wcap ? wcap : w8));
     if (total <= (handover ? ESAC_LATENCY_MAX : 1024)) {
         if (handover) b.handover = ESAC_HANDOVER;
-        // up to 256 hypotheses: four wavefronts each (64 tries per round, one workgroup per CU at this kernel's ~440
-        // registers).  Beyond that the workgroups queue up behind each other (1024 hypotheses: four ~12 us rounds back to
-        // back, 51 us measured): two wavefronts per hypothesis (32 tries per round -- 93 % of the hypotheses of a usable
-        // map are settled in it) put two hypotheses on a CU at a time.
+        // up to 256 hypotheses: four wavefronts each, two lanes per try (128 tries per round, one workgroup per CU at this
+        // kernel's ~445 registers: the chip is full).  Beyond that the workgroups queue up behind each other (1024
+        // hypotheses: four ~12 us rounds back to back, 51 us measured): two wavefronts per hypothesis, four lanes per try
+        // (32 tries per round -- 93 % of the hypotheses of a usable map are settled in it) put two hypotheses on a CU at a
+        // time.
         if (total <= 256) hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, a.frames), dim3(256), 0, s, b);
         else              hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else if (total <= 4096 && !handover) {

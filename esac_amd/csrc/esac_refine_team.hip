@@ -1,5 +1,5 @@
 // esac_refine_team.hip -- draw(argmax) + refineHyp + pose2trans of ONE frame on a grid of a few thousand cells, shared by a
-// TEAM of up to 8 workgroups on one XCD (round 4).
+// TEAM of workgroups on one XCD (round 4): 8 on the 60x80 grid, up to 32 on grids of up to 32768 cells.
 //
 // Reference: refineHyp esac_util.h:378-454 (the loop), cv::solvePnP(SOLVEPNP_ITERATIVE, useExtrinsicGuess) reached from
 // esac_util.h:426-436 (the re-fit: CvLevMarq, 6 parameters, max_iter 20, eps FLT_EPSILON), draw esac_util.h:505-530,
@@ -22,10 +22,18 @@
 //     accepted, ends the re-fit (iteration 20, or relative step < FLT_EPSILON) is known BEFORE the trial is evaluated
 //     (it depends on the step, not on the residual), so such a trial is evaluated as a full pass with the moments over
 //     the next set: accepted -- the common case -- it IS the next step's error image and first LM pass.  Rejected, the
-//     re-fit goes on with a larger lambda from the normal equations it already holds; nothing was overwritten (the sets
-//     are register masks).  ~24 rounds per frame instead of ~33, same accepted points, same decisions.
+//     re-fit goes on with a larger lambda from the normal equations of the last accepted point (the wavefront's stash in
+//     LDS, team_step); nothing was overwritten (the sets are register masks).  ~25 rounds per frame instead of ~33, same
+//     accepted points, same decisions.
 //   * ONE HOP PER ROUND between the members: refine_common.hpp, tagged granules.  The chain-rule matrices of the pose are
 //     computed while the exchange is in flight.
+//   * COUNTED IN INSTRUCTIONS.  A member runs one wavefront per SIMD, and such a wavefront issues one instruction every
+//     ~5.7 cycles whatever it is: a round is ~1,200 instructions + the hop, and two thirds of them are the section every
+//     lane walks alike (rotation, normal equations, 6x6 solve, accept / terminate logic).  Hence ONE step site, a loop
+//     that carries only the pose, the cells and a few scalars (no copies between the two register files around a pass),
+//     the arrays ahead of the pad in ONE LDS allocation (16-bit offsets: no address materialised per access),
+//     accumulators that die at their reduction, the series of the rotation at a quarter of the angle (16 constants of
+//     two scalar moves each instead of 48), the normal equations in units of f.  LAB_NOTES.md has the counts.
 //   * THE SELECTION IN THE PROLOGUE (a.fold_select: single frames of <= 256 hypotheses, the headline call).  softMax /
 //     entropy statistics of the fp32 scores, the band of contenders and their re-score in reference arithmetic
 //     (esac_util.h:235-260, 461-530 -- what k_select_rescore does in a launch of its own) run here: every member scores

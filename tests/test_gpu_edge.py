@@ -273,7 +273,7 @@ def test_two_phase_sampling_matches_oracle(engine, oracle, max_tries):
 
 def test_large_batch_equals_sequential_calls(engine):
     """The same through forward_batch: 48 frames x 128 hypotheses (two-phase sampling, 4-wavefront score kernel) ==
-    48 single calls (quad sampling, 8-wavefront score kernel) in everything that is decided exactly: winner, its exact
+    48 single calls (candidates of a try shared by lanes, 8-wavefront score kernel) in everything that is decided exactly: winner, its exact
     score, expert, refined pose, refinement trace.  (Selection probability and entropy are statistics of the fp32
     score stream, whose summation order follows the launch shape: equal to ~1e-6, not bit for bit.)"""
     B, N = 48, 128

@@ -195,11 +195,11 @@ def load_profile(config):
 # one-GPU stage times (ms) of the BASELINE workloads, from this round's bench lines (profiles/r04_bench_<cfg>.json): the inputs of
 # `expected_scaling`.  host = ms_per_step - sum of the stages (launches, boundaries, hand-off)
 EXPECTED_T1_MS = {
-    "cfg2": {"sample": 0.0173, "score": 0.0038, "select": 0.0004, "refine": 0.0842, "host": 0.021},
-    "cfg3": {"sample": 0.0756, "score": 0.0076, "select": 0.0102, "refine": 0.0873, "host": 0.005},
-    "cfg4": {"sample": 0.1140, "score": 0.0199, "select": 0.0105, "refine": 0.0741, "host": 0.017},
-    "cfg5a": {"sample": 1.6166, "score": 0.0688, "select": 0.0116, "refine": 0.1004, "host": 0.039},
-    "cfg5b": {"sample": 1.8170, "score": 2.5784, "select": 0.0331, "refine": 0.3825, "host": 0.163},
+    "cfg2": {"sample": 0.0172, "score": 0.0038, "select": 0.0004, "refine": 0.0835, "host": 0.022},
+    "cfg3": {"sample": 0.0761, "score": 0.0078, "select": 0.0102, "refine": 0.0872, "host": 0.005},
+    "cfg4": {"sample": 0.1132, "score": 0.0190, "select": 0.0104, "refine": 0.0715, "host": 0.022},
+    "cfg5a": {"sample": 1.6116, "score": 0.0669, "select": 0.0116, "refine": 0.0963, "host": 0.029},
+    "cfg5b": {"sample": 1.8210, "score": 2.5507, "select": 0.0331, "refine": 0.3770, "host": 0.127},
 }
 STAGE_OF = (("k_sample", "sample"), ("k_bucket", "score"), ("k_score", "score"), ("k_select", "select_rescore"),
             ("k_refine", "refine"))

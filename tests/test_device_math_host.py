@@ -342,6 +342,36 @@ def test_closed_form_lm_chain_equals_the_rodrigues_jacobian_chain(probe):
             np.testing.assert_allclose(K.reshape(3, 3), skew(pose[3:]) @ Jl, rtol=0, atol=5e-13)
 
 
+def test_pose_rotation_series_against_high_precision(probe):
+    """lm_pose_rotation / lm_pose_left_jacobian (lm_math.hpp: Taylor series at a quarter of the angle, two doublings,
+    C = (1 - A) / x) against 50-digit arithmetic over the whole series range |r|^2 <= 10 -- up to angle pi and beyond --
+    and on the trigonometric route past it: R and the left Jacobian of SO(3) to a few ulp of their largest entries."""
+    mpmath = pytest.importorskip("mpmath")
+    mpmath.mp.dps = 50
+    rng = np.random.default_rng(5)
+    worst_R = worst_J = 0.0
+    angles = np.concatenate([rng.uniform(0.0, np.sqrt(10.0), 300), [1e-7, 1e-3, np.pi, 3.1622, 3.1624, 3.5, 6.0]])
+    for th in angles:
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        pose = np.concatenate([axis * th, rng.normal(size=3)])
+        R, Mw, K = np.zeros(9), np.zeros(9), np.zeros(9)
+        probe.probe_pose_chain(_p(pose), _p(R), _p(Mw), _p(K))
+        r = [mpmath.mpf(float(v)) for v in pose[:3]]
+        x = r[0] * r[0] + r[1] * r[1] + r[2] * r[2]
+        t = mpmath.sqrt(x)
+        A, B, C = mpmath.sin(t) / t, (1 - mpmath.cos(t)) / x, (t - mpmath.sin(t)) / (t * x)
+        S = mpmath.matrix([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+        Rr = mpmath.eye(3) + A * S + B * (S * S)
+        Jl = mpmath.eye(3) + B * S + C * (S * S)
+        for i in range(3):
+            for j in range(3):
+                worst_R = max(worst_R, abs(float(mpmath.mpf(float(R[3 * i + j])) - Rr[i, j])))
+                worst_J = max(worst_J, abs(float(mpmath.mpf(float(Mw[3 * i + j])) - Jl[i, j])))
+    assert worst_R < 3e-15, worst_R
+    assert worst_J < 3e-15, worst_J
+
+
 def test_fp32_screen_never_rejects_an_accepted_try():
     """The one-sided contract of the sampling screen (esac_amd/csrc/p3p_screen.hpp: screen_setup + p3p_screen_roots, as
     k_sample_prescreen / k_sample_screened run it): on the kernels' own source compiled for the host, over 1.5e6 random tries on true-expert, garbage-expert, noise-free,

@@ -67,3 +67,44 @@ def test_streaming_and_selection_kernels_stay_lean(tmp_path):
     assert quad and quad[0]["ScratchSize"] == 0                         # the single-frame sampler runs from registers
     pre = [v for n, v in k.items() if "k_sample_prescreen" in n]
     assert pre and pre[0]["ScratchSize"] == 0 and pre[0]["VGPRs"] <= 256        # the fp64 screen: 2 wavefronts per SIMD
+
+
+def _isa_functions(source, tmp_path):
+    """hipcc -S of one source: {mangled kernel name: [instruction lines]}."""
+    asm = tmp_path / "k.s"
+    out = subprocess.run([HIPCC] + [f for f in B.FLAGS if f not in ("-shared", "-fPIC")] +
+                         ["-S", "--cuda-device-only", os.path.join(B.CSRC, source), "-o", str(asm)],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    funcs, cur = {}, None
+    for line in asm.read_text().splitlines():
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = funcs.setdefault(m.group(1), [])
+            continue
+        if line.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        s = line.strip()
+        if cur is not None and s and not s.startswith((";", ".")) and not s.endswith(":"):
+            cur.append(s)
+    return funcs
+
+
+def test_team_kernel_stays_within_its_instruction_budget(tmp_path):
+    """The team refinement is bound by its instruction COUNT (one wavefront per SIMD issues one instruction every ~5.7 cycles
+    whatever it is: LAB_NOTES.md, round 4).  Three things that once cost it a fifth of its time and show in the ISA:
+    an address materialised in front of every LDS access (arrays laid out behind the 96 KB pad), copies between the two
+    register files around every pass (the loop carried the normal equations), tied copies in front of DPP moves."""
+    f = _isa_functions("esac_refine_team.hip", tmp_path)
+    name = [n for n in f if "k_refine_teamILi3ELb0" in n]
+    assert len(name) == 1
+    ins = f[name[0]]
+    assert len(ins) < 11500, len(ins)                                   # 13,526 before the trims, 10,1xx after
+    lds_literals = [i for i in ins if re.match(r"v_mov_b32_e32 v\d+, 0x1[0-9a-f]{4}$", i)]
+    assert not lds_literals, lds_literals[:3]                           # LDS addresses fit the offset field
+    acc = [i for i in ins if i.startswith("v_accvgpr_")]
+    assert len(acc) < 400, len(acc)                                     # 1,092 before (most of them inside the loop)
+    dpp = [i for i in ins if i.startswith("v_mov_b32_dpp")]
+    tied = [i for i in dpp if re.match(r"v_mov_b32_dpp (v\d+), \1 ", i)]
+    assert len(tied) <= len(dpp) // 4, (len(tied), len(dpp))            # quad_perm / mirror moves read their source directly

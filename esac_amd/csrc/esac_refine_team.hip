@@ -22,18 +22,24 @@
 //     accepted, ends the re-fit (iteration 20, or relative step < FLT_EPSILON) is known BEFORE the trial is evaluated
 //     (it depends on the step, not on the residual), so such a trial is evaluated as a full pass with the moments over
 //     the next set: accepted -- the common case -- it IS the next step's error image and first LM pass.  Rejected, the
-//     re-fit goes on with a larger lambda from the normal equations of the last accepted point (the wavefront's stash in
-//     LDS, team_step); nothing was overwritten (the sets are register masks).  ~25 rounds per frame instead of ~33, same
+//     re-fit goes on with a larger lambda from the normal equations of the last accepted point (they stay in registers,
+//     team_step); nothing was overwritten (the sets are register masks).  ~25 rounds per frame instead of ~33, same
 //     accepted points, same decisions.
 //   * ONE HOP PER ROUND between the members: refine_common.hpp, tagged granules.  The chain-rule matrices of the pose are
 //     computed while the exchange is in flight.
-//   * COUNTED IN INSTRUCTIONS.  A member runs one wavefront per SIMD, and such a wavefront issues one instruction every
-//     ~5.7 cycles whatever it is: a round is ~1,200 instructions + the hop, and two thirds of them are the section every
-//     lane walks alike (rotation, normal equations, 6x6 solve, accept / terminate logic).  Hence ONE step site, a loop
-//     that carries only the pose, the cells and a few scalars (no copies between the two register files around a pass),
-//     the arrays ahead of the pad in ONE LDS allocation (16-bit offsets: no address materialised per access),
-//     accumulators that die at their reduction, the series of the rotation at a quarter of the angle (16 constants of
-//     two scalar moves each instead of 48), the normal equations in units of f.  LAB_NOTES.md has the counts.
+//   * COUNTED IN INSTRUCTIONS.  A member runs one wavefront per SIMD; such a wavefront issues one VALU instruction every
+//     ~4.8 cycles and waits 10 for a dependent fp64 result (scripts/dev/lat_probe.hip): a round is ~1,100 instructions + the
+//     hop + two LDS round trips, and it is the COUNT that binds.  Hence ONE step site, a loop that carries only the pose,
+//     the cells and a few registers, the arrays ahead of the pad in ONE LDS allocation (16-bit offsets: no address
+//     materialised per access), accumulators that die at their reduction, the series of the rotation at a quarter of the
+//     angle (16 constants of two scalar moves each instead of 48), the normal equations in units of f.
+//   * THE SERIAL SECTION DEALT TO LANES (round 5, lm_lanes.hpp).  Every lane of every wavefront used to compute all 27
+//     entries of the (rvec, tvec)-space normal equations and the whole 6x6 LDL^T alike (~350 instructions a round).  Now
+//     lane j of a 16-lane row holds column j: the totals of a pass are gathered per lane from LDS (6 loads instead of 27),
+//     the two 3x3-block products and a Gauss-Jordan elimination run on v_fmac_f64_dpp ... row_newbcast (a DPP broadcast
+//     folded into the FMA: 6 instructions for a row of outputs, 5 for an elimination step), the chain-rule matrices are
+//     formed column-wise in the lanes while the exchange is in flight, and what a rejected trial needs again is 26
+//     registers instead of an LDS stash.  Same-box A/B of the headline call: 0.1255-0.130 -> 0.1144-0.1155 ms.
 //   * THE SELECTION IN THE PROLOGUE (a.fold_select: single frames of <= 256 hypotheses, the headline call).  softMax /
 //     entropy statistics of the fp32 scores, the band of contenders and their re-score in reference arithmetic
 //     (esac_util.h:235-260, 461-530 -- what k_select_rescore does in a launch of its own) run here: every member scores
@@ -44,20 +50,41 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lm_lanes.hpp"
 #include "refine_common.hpp"
 
 namespace esac {
 
 constexpr int TEAM_CPL_MAX = 4;   // cells per lane a member can hold: slices of up to 1024 cells
 constexpr int TEAM_NSUM = 27;     // 24 moments | residual^2 over the running set | residual^2 over the next set | size of the next set
-constexpr int TEAM_STASH = 34;    // doubles per wavefront: U21, g6, prev (+1: 16-byte rows), see team_step
 constexpr int TEAM_LDS_PAD = 96 * 1024;  // LDS nobody touches: one member per CU (two would share its SIMDs)
 
 template <int CPL>
 struct TeamCells {
     double X[CPL], Y[CPL], Z[CPL], px[CPL], py[CPL];  // scene point and pixel position (float inputs, exact in double)
     int cell[CPL];                                     // grid cell, -1: none (ragged end of the slice)
+    unsigned live;                                     // bit p: cell p exists AND its scene point is finite.  A point that is not can
+                                                       // never be an inlier (its error is NaN: esac_util.h:358 then :404); it is kept
+                                                       // out of every set and its coordinates read 0 here, so that the 0/1 weights of a
+                                                       // pass never meet a NaN (0 * NaN would poison all 24 moments)
 };
+
+// What a lane keeps for the lane-dealt LM step (lm_lanes.hpp): loop-invariant registers
+struct LaneConst {
+    double hot[6];  // 1 in lane k of every 16-lane row
+    double keep;    // 1 in lanes 3..6 of every row
+    int off[6];     // byte offsets of this lane's X_0..2, Y_0..2 among the totals in LDS (lm_lane_slot)
+};
+struct LmLaneTable {
+    unsigned short off[16][6];
+};
+constexpr LmLaneTable lm_lane_table() {
+    LmLaneTable t{};
+    for (int l = 0; l < 16; l++)
+        for (int w = 0; w < 6; w++) t.off[l][w] = (unsigned short)(8 * lm_lane_slot(l, w));
+    return t;
+}
+__device__ const LmLaneTable LM_LANE_TABLE = lm_lane_table();
 
 // the decision band of `err < tau` on the fp64 squared error (see error_pass_impl in esac_refine.hip, second screen): the
 // reference rounds the projection to float before taking the difference, so its error differs from the fp64 value by
@@ -74,12 +101,13 @@ __device__ __forceinline__ TauBand make_band(const KArgs& a) {
 }
 
 // One pass at `param` (see the header).  in: run_set = the set the re-fit works on, use_next = moments over the next set
-// instead.  out: next_set, sums (totals over the team, identical in every thread of every member), Mw = chain-rule
-// matrix at param (the left Jacobian of SO(3), lm_math.hpp).
+// instead.  out: next_set; the 27 totals over the team in LDS (s_tot: [0, 27) the totals, [32, 59) their negatives, what
+// the lane-dealt step gathers from), tail = totals 24..26 (identical in every thread of every member); M, K = chain-rule
+// matrices at param, column j in lane j of every row (the left Jacobian of SO(3) and [t]x of it, lm_lanes.hpp).
 template <int CPL>
 __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& cl, const double (&param)[6], const Cam& cam, const TauBand& band,
-                                          unsigned run_set, bool use_next, unsigned& next_set, double (&sums)[TEAM_NSUM], double (&Mw)[3][3],
-                                          Coop& co, double* s_part, double* s_tot, double* s_x, long long* g_cyc) {
+                                          unsigned run_set, bool use_next, unsigned& next_set, double (&tail)[3], const LaneConst& lc, double (&M)[3],
+                                          double (&K)[3], Coop& co, double* s_part, double* s_tot, double* s_x, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
     double R[9];
@@ -89,7 +117,7 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
     CYC_BEGIN();
     bool on[CPL];
 #pragma unroll
-    for (int p = 0; p < CPL; p++) on[p] = cl.cell[p] >= 0;
+    for (int p = 0; p < CPL; p++) on[p] = (cl.live >> p) & 1u;
     LmTerms<CPL> q;  // x, y, 1/z, residual of every owned cell (all zero for a missing one)
     lm_point_terms<CPL>(R, param + 3, cam, cl.X, cl.Y, cl.Z, cl.px, cl.py, on, q);
     // (b) the next inlier set -- only where the pass is (also) an error image: an LM trial that cannot end its re-fit needs
@@ -139,6 +167,7 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
         }
     }
     // (a), (c): 0/1 weights the optimiser cannot see through (one basic block, no chain sunk under a branch)
+    double sums[TEAM_NSUM];
 #pragma unroll
     for (int k = 0; k < TEAM_NSUM; k++) sums[k] = 0;
     LmTerms<CPL> m;
@@ -164,55 +193,52 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
     // (publishing per WAVEFRONT -- no LDS round, four granules to poll per thread -- measured 4 % slower per pass)
     wave_totals28_to_lds<TEAM_NSUM>(sums, s_part);
     team_publish<TEAM_NSUM>(workgroup_total28<REFINE_B>(s_part), co);
-    lm_pose_left_jacobian(tg, Mw);  // while the exchange is in flight
-    team_collect<TEAM_NSUM>(sums, co, s_tot, s_x);
+    lm_lane_chain<double>(tg, param + 3, lc.hot, M, K);  // while the exchange is in flight
+    team_collect_lds<TEAM_NSUM, true>(co, s_tot, s_x);
+    tail[0] = s_tot[24];
+    tail[1] = s_tot[25];
+    tail[2] = s_tot[26];
     CYC_END(6);
     CYC_ADD(9, 1);
 }
 
-// One LM step, the only site: param = prev - solve(JtJ with diag *= 1 + lambda, JtErr).
-// fresh: `param` was accepted (or is the start of a re-fit) -- it becomes `prev`, the normal equations in (rvec, tvec)
-// space come from this pass's moments (chain-rule matrix Mw at that pose) and go to the wavefront's stash with it;
-// otherwise (a rejected trial) all three come back from the stash.  lambda = 10^lambda_lg10 from a table in LDS (the binary
-// exponentiation + division of pow10_int is ~600 cycles of dependent work).  Returns whether the new trial, if accepted,
-// ends the re-fit (iters: accepted iterations so far).
-__device__ __forceinline__ bool team_step(bool fresh, const double (&sums)[TEAM_NSUM], const Cam& cam, const double (&Mw)[3][3], int lambda_lg10, int iters,
-                                          double (&param)[6], double inv_f, double* stash, const double* s_pow10, double* s_part, long long* g_cyc) {
+// One LM step, the only site: param = prev - solve(JtJ with diag *= 1 + lambda, JtErr), dealt to the lanes of a row
+// (lm_lanes.hpp: ~190 instructions where every lane computing all 27 outputs of the transform and the whole LDL^T was ~350).
+// fresh: `param` was accepted (or is the start of a re-fit) -- it becomes `prev`, and the rows c[] of the normal equations
+// in (rvec, tvec) space are built from this pass's totals in LDS (per-lane gather) and the chain-rule columns M, K at
+// that pose; otherwise (a rejected trial) c[] and prev are what they were: they live in registers across rounds (12 + 12:
+// a lane holds one column, not the matrix -- round 4 kept U21 / g6 / prev in an LDS stash because 66 uniform registers
+// would not stay).  lambda = 10^lambda_lg10 from a table in LDS (the binary exponentiation + division of pow10_int is ~600
+// cycles of dependent work).  Returns whether the new trial, if accepted, ends the re-fit (iters: accepted iterations so far).
+__device__ __forceinline__ bool team_step(bool fresh, const LaneConst& lc, const double (&M)[3], const double (&K)[3], int lambda_lg10, int iters,
+                                          double (&param)[6], double (&prev)[6], double (&c)[6], double& dg, double inv_f, const double* s_tot,
+                                          const double* s_pow10, double* s_part, long long* g_cyc) {
     CYC_DECL;
     CYC_BEGIN();
-    const double lambda = s_pow10[lambda_lg10 + 16];  // (read here: behind the stash's stores it waits for all of them)
-    double U21[21], g6[6], prev[6];
+    const double lambda = s_pow10[lambda_lg10 + 16];
     if (fresh) {
 #pragma unroll
         for (int k = 0; k < 6; k++) prev[k] = param[k];
         // in units of the focal length: JtJ / f^2 and JtErr / f (the damping is relative, the pivot tests are relative: the
-        // step of these equations is f times the step -- six multiplications below instead of 27 here)
-        double acc[LM_NACC];
-        lm_moments_to_acc(sums, 1.0, acc);
-        lm_transform_t(acc, Mw, prev + 3, U21, g6);
-        if ((threadIdx.x & 63) == 0) {
+        // step of these equations is f times the step -- six multiplications below instead of 27 of the sums)
+        double X[3], Y[3];
+        const char* const base = reinterpret_cast<const char*>(s_tot);
 #pragma unroll
-            for (int k = 0; k < 21; k++) stash[k] = U21[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) stash[21 + k] = g6[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) stash[27 + k] = prev[k];
+        for (int k = 0; k < 3; k++) {
+            X[k] = *reinterpret_cast<const double*>(base + lc.off[k]);
+            Y[k] = *reinterpret_cast<const double*>(base + lc.off[3 + k]);
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 21; k++) U21[k] = stash[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) g6[k] = stash[21 + k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) prev[k] = stash[27 + k];
+        lm_lane_transform<double>(X, Y, M, K, lc.hot, lc.keep, c, dg);
     }
-    __builtin_amdgcn_wave_barrier();  // (the stash is per wavefront: its LDS traffic is ordered, nothing to wait for)
-    CYC_PIN(U21, 21);
-    CYC_PIN(g6, 6);
+    CYC_PIN(c, 6);
     CYC_END(7);
     CYC_BEGIN();
     double dx[6];
-    if (!lm_solve6(U21, g6, lambda, dx)) lm_solve6_pinv(U21, g6, lambda, dx, s_part);
+    if (!lm_lane_solve<double>(c, dg, lc.hot, lambda, dx)) {
+        double U21[21], g6[6];
+        lm_lane_to_u21<double>(c, U21, g6);
+        lm_solve6_pinv(U21, g6, lambda, dx, s_part);
+    }
     double dn = 0, pn = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
@@ -307,7 +333,7 @@ __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>&
                 const int i = cell0 + p * B + t;
                 if (i >= cell1) continue;
                 float X, Y, Z, px, py;
-                if (cells_loaded) {  // one expert: the map is the one in the registers
+                if (cells_loaded && ((cl.live >> p) & 1u)) {  // one expert: the map is the one in the registers (a non-finite point: as the reference reads it)
                     X = (float)cl.X[p]; Y = (float)cl.Y[p]; Z = (float)cl.Z[p]; px = (float)cl.px[p]; py = (float)cl.py[p];
                 } else {
                     const int row = i / a.W, col = i - row * a.W;
@@ -402,8 +428,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     // materialised its own address first -- an extra instruction per LDS access on a section every lane walks.
     struct Lds {
         double part[28 * (B / 64) > 84 ? 28 * (B / 64) : 84];  // block reductions; scratch of the pseudo-inverse step
-        double tot[32];
-        double stash[(REFINE_B / 64) * TEAM_STASH];  // per wavefront: what a rejected trial needs again (team_step)
+        double tot[LM_LANE_SLOTS];                   // an exchange's totals [0, 27) | zeros | their negatives [32, 59) | zeros (lm_lanes.hpp)
         double pow10[34];                            // 10^-16 .. 10^16: the LM damping factors
         double x[TEAM_MAX * 32];                     // exchanges of more than 8 members: the polled values, [member][value]
         double rt[TEAM_SEL_CHUNK * 12];              // folded selection: the poses of a chunk of contenders
@@ -424,7 +449,6 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     int* const s_list = lds.list;
     double* const s_rt = lds.rt;
     double* const s_pow10 = lds.pow10;
-    double* const s_stash = lds.stash;
     if (a.team_stride < 0) lds.pad[threadIdx.x] = 1;  // (never: keeps the allocation)
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
@@ -452,6 +476,20 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         team_publish<1>((double)(1ull << (6 * (xcc & 7))), co);
     }
     if (threadIdx.x < 33) s_pow10[threadIdx.x] = pow10_int((int)threadIdx.x - 16);  // (visible after the barrier of the winner pick)
+    if (threadIdx.x < LM_LANE_SLOTS) s_tot[threadIdx.x] = 0.0;  // the zero slots stay zero: an exchange writes [0, 27) and [32, 59)
+    // the lane-dealt LM step's constants of this lane (opaque to the optimiser: values to keep, not to rematerialise per round)
+    LaneConst lc;
+    {
+        const int l16 = (int)threadIdx.x & 15;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            lc.hot[k] = l16 == k ? 1.0 : 0.0;
+            lc.off[k] = (int)LM_LANE_TABLE.off[l16][k];
+            asm volatile("" : "+v"(lc.hot[k]), "+v"(lc.off[k]));
+        }
+        lc.keep = (l16 >= 3 && l16 <= 6) ? 1.0 : 0.0;
+        asm volatile("" : "+v"(lc.keep));
+    }
     const bool writer = co.g == 0;
     if (writer && !SLOTS)
         for (int i = threadIdx.x; i <= ESAC_MAX_REF_STEPS_K; i += B) a.inlier_counts[i] = -1;  // (drained by the barrier of the winner pick)
@@ -460,6 +498,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     // this lane's cells: with one expert the map is known before the winner is (one dependent load less on the way in)
     TeamCells<CPL> cl;
     auto load_cells = [&](const float* __restrict__ mx) {
+        cl.live = 0;
 #pragma unroll
         for (int p = 0; p < CPL; p++) {
             const int i = cell0 + p * B + (int)threadIdx.x;
@@ -467,9 +506,12 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
             const int ic = have ? i : cell0;
             cl.cell[p] = have ? i : -1;
             const int row = ic / a.W, col = ic - row * a.W;
-            cl.X[p] = have ? (double)mx[ic] : 0.0;
-            cl.Y[p] = have ? (double)mx[P + ic] : 0.0;
-            cl.Z[p] = have ? (double)mx[2 * P + ic] : 0.0;
+            const float fx = mx[ic], fy = mx[P + ic], fz = mx[2 * P + ic];
+            const bool fin = have && fabsf(fx) <= 3.0e38f && fabsf(fy) <= 3.0e38f && fabsf(fz) <= 3.0e38f;  // false for NaN / inf
+            if (fin) cl.live |= 1u << p;
+            cl.X[p] = fin ? (double)fx : 0.0;
+            cl.Y[p] = fin ? (double)fy : 0.0;
+            cl.Z[p] = fin ? (double)fz : 0.0;
             cl.px[p] = (double)(float)cell_pxi(a, col);  // Point2f of the integer pixel centre (esac_util.h:64-66, :180)
             cl.py[p] = (double)(float)cell_pyi(a, row);
         }
@@ -503,8 +545,12 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 
     // ---- refineHyp (esac_util.h:378-454) around ONE pass site
     const TauBand band = make_band(a);
-    double sums[TEAM_NSUM];
-    double Mw[3][3];
+    double sums[3];        // totals 24..26 of a pass: residual^2 over the running set / over the next set, size of the next set
+    double M[3], K[3];     // chain-rule columns at the pose of the pass (lane-dealt)
+    double c[6], dg = 0.0, prev[6];  // the normal equations' rows and diagonal (lane-dealt) and the point they were built at: what a
+                                     // rejected trial needs again
+#pragma unroll
+    for (int k = 0; k < 6; k++) c[k] = prev[k] = 0.0;
     unsigned run_set = 0, next_set = 0, acc_set = 0;  // sets as bit masks over this lane's cells: the running re-fit's, the one the last
                                                       // full pass found, the last ACCEPTED step's (inlierMap, esac_util.h:440)
     // The loop carries the pose (`param`), this lane's cells and a handful of scalars -- nothing else.  What only a REJECTED
@@ -515,7 +561,6 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     double param[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) param[k] = pose[k];
-    double* const stash = s_stash + (threadIdx.x >> 6) * TEAM_STASH;  // [0,21) U21, [21,27) g6, [27,33) prev
     int accepted = 0, last_inliers = 0, lm_total = 0, rstep = 0;
     unsigned best_inliers = 4;
     // LM state: lambda = 10^lambda_lg10, iterations of the running re-fit, |err|^2 at `prev`
@@ -527,18 +572,18 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     bool ends_refit = true;
     const double inv_f = 1.0 / cam.fx;
     for (;;) {
-        team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, Mw, co, s_part, s_tot, s_x, g_cyc);
+        team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, lc, M, K, co, s_part, s_tot, s_x, g_cyc);
         if (co.dead) break;  // an exchange timed out: the sums are garbage, the call reports it
         CYC_BEGIN();
         bool fresh = true;  // normal equations from this pass (else: state CHECK_ERR failed, retry from `prev` with a larger lambda)
-        if (in_refit && norm_greater(sums[24], prev_err2) && ++lambda_lg10 <= 16) {
+        if (in_refit && norm_greater(sums[0], prev_err2) && ++lambda_lg10 <= 16) {
             fresh = false;
         } else {
             if (in_refit) {
                 lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
                 ++iters;
                 if (!ends_refit) {  // state CALC_J at the accepted point
-                    prev_err2 = sums[24];
+                    prev_err2 = sums[0];
                 } else {  // the re-fit is done: its last trial is the refined pose, and this pass was its error image
                     lm_total += iters;
                     accepted++;
@@ -551,7 +596,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
             if (!in_refit) {
                 // error image at `param` (reproErrs, esac.cpp:169 / esac_util.h:445-452): next_set, its size, its normal equations
                 if (rstep >= a.max_ref_steps) break;  // the reference also evaluates the errors of its last re-fit
-                const int n_inl = (int)sums[26];
+                const int n_inl = (int)sums[2];
                 if (!SLOTS && writer && threadIdx.x == 0) a.inlier_counts[rstep] = n_inl;
                 if ((unsigned)n_inl <= best_inliers) break;  // converged (esac_util.h:417-419)
                 best_inliers = (unsigned)n_inl;
@@ -560,16 +605,16 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
                 in_refit = true;
                 lambda_lg10 = -3;
                 iters = 0;
-                prev_err2 = sums[25];
+                prev_err2 = sums[1];
             }
         }
         CYC_END(16);
-        ends_refit = team_step(fresh, sums, cam, Mw, lambda_lg10, iters, param, inv_f, stash, s_pow10, s_part, g_cyc);
+        ends_refit = team_step(fresh, lc, M, K, lambda_lg10, iters, param, prev, c, dg, inv_f, s_tot, s_pow10, s_part, g_cyc);
     }
     // the refined pose: the last accepted re-fit's (esac_util.h:439); a pass that ended the loop was evaluated AT it
     // (or at the initial pose when no re-fit was accepted; in_refit here only after a time-out: the point the trial left)
 #pragma unroll
-    for (int k = 0; k < 6; k++) pose[k] = in_refit ? stash[27 + k] : param[k];
+    for (int k = 0; k < 6; k++) pose[k] = in_refit ? prev[k] : param[k];
 
     // inlierMap of the last accepted step (esac_util.h:440), every member its cells; buffer 0 (result[31] names it)
     if (accepted > 0) {

@@ -255,15 +255,12 @@ __device__ __forceinline__ void team_publish(double own, const Coop& co) {
 // (member g >> 5, value g & 31; up to four 16-byte loads in flight), the values go through LDS (s_x: 32 x 32 doubles), thread
 // t adds members (t & 7), (t & 7) + 8, ... of value t >> 3, the same three DPP stages finish.  s_tot: >= 32 doubles nobody
 // else touches until the next workgroup barrier.
-template <int NV>
-__device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot, double* s_x = nullptr) {
+// team_collect_lds: the totals stay in LDS -- s_tot[k], and with NEG s_tot[32 + k] = -total (what the lane-dealt LM step
+// gathers per lane, lm_lanes.hpp) -- visible to every thread when it returns; team_collect reads all of them back.
+template <int NV, bool NEG>
+__device__ __forceinline__ void team_collect_lds(Coop& co, double* s_tot, double* s_x = nullptr) {
     static_assert(NV <= 32 && REFINE_B == 256 && TEAM_MAX <= 32, "poll layout");
-    if (co.dead) {  // (v is DEFINED on every way out: the caller's accumulators then die at its reduction and are
-                    // reduced in place -- left untouched here they stay live and every one of them is copied first)
-#pragma unroll
-        for (int kk = 0; kk < NV; kk++) v[kk] = 0.0;
-        return;
-    }
+    if (co.dead) return;
     const unsigned long long want = co.tag | (co.arrivals + 1ull);
     const u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
     const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
@@ -333,12 +330,25 @@ __device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* 
     val += dpp_move<0xB1>(val);   // lanes (0,1) (2,3) (4,5) (6,7)
     val += dpp_move<0x4E>(val);   // quads
     val += dpp_move<0x141>(val);  // all eight
-    if (j == 0 && k < NV) s_tot[k] = val;
+    if (j == 0 && k < NV) {
+        s_tot[k] = val;
+        if (NEG) s_tot[32 + k] = -val;
+    }
     barrier_lds();
     co.dead = *co.s_dead != 0;
+    co.arrivals += 1ull;
+}
+template <int NV>
+__device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot, double* s_x = nullptr) {
+    if (co.dead) {  // (v is DEFINED on every way out: the caller's accumulators then die at its reduction and are
+                    // reduced in place -- left untouched here they stay live and every one of them is copied first)
+#pragma unroll
+        for (int kk = 0; kk < NV; kk++) v[kk] = 0.0;
+        return;
+    }
+    team_collect_lds<NV, false>(co, s_tot, s_x);
 #pragma unroll
     for (int kk = 0; kk < NV; kk++) v[kk] = s_tot[kk];
-    co.arrivals += 1ull;
 }
 
 // ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties

@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "..", "..", "esac_amd", "csrc")
 
 
 def build(force=False):
-    deps = [SRC] + [os.path.join(CSRC, h) for h in ("pose_math.hpp", "lm_math.hpp", "bwd_math.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, h) for h in ("pose_math.hpp", "lm_math.hpp", "bwd_math.hpp", "lm_lanes.hpp")]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC",

@@ -4,6 +4,7 @@
 #include "../../esac_amd/csrc/pose_math.hpp"
 #include "../../esac_amd/csrc/lm_math.hpp"
 #include "../../esac_amd/csrc/bwd_math.hpp"
+#include "../../esac_amd/csrc/lm_lanes.hpp"
 using namespace esac;
 extern "C" {
 int probe_p3p(const double* obj, const double* img, double fx, double fy, double cx, double cy, double* rvec, double* tvec, double* Rout) {
@@ -76,6 +77,31 @@ double probe_transform_t_diff(const double* acc, const double* pose) {
     for (int k = 0; k < 21; k++) d = fmax(d, fabs(U1[k] - U2[k]) / mU);
     for (int k = 0; k < 6; k++) d = fmax(d, fabs(g1[k] - g2[k]) / mg);
     return d;
+}
+// The lane-dealt serial section of an LM round (lm_lanes.hpp, round 5) on the 16-lane row emulation: the 27 totals of a pass
+// (24 moments | ...) and a pose in, the (rvec, tvec)-space system it builds (U21, g6 through lm_lane_to_u21), the step of
+// its Gauss-Jordan solve and its pivot verdict out.  The test compares with lm_moments_to_acc + lm_transform + lm_solve6.
+int probe_lane_step(const double* sums27, const double* pose, double lambda, double* U21, double* g6, double* dx) {
+    double lds[64];
+    for (int k = 0; k < 64; k++) lds[k] = 0.0;
+    for (int k = 0; k < 27; k++) { lds[k] = sums27[k]; lds[32 + k] = -sums27[k]; }
+    Row16 X[3], Y[3], hot[6], keep, M[3], K[3], c[6], dg, U[21], g[6], d[6];
+    for (int l = 0; l < 16; l++) {
+        for (int k = 0; k < 3; k++) { X[k].l[l] = lds[lm_lane_slot(l, k)]; Y[k].l[l] = lds[lm_lane_slot(l, 3 + k)]; }
+        for (int k = 0; k < 6; k++) hot[k].l[l] = l == k ? 1.0 : 0.0;
+        keep.l[l] = (l >= 3 && l <= 6) ? 1.0 : 0.0;
+    }
+    double R[9];
+    LmTrig tg;
+    lm_pose_rotation(pose, R, tg);
+    lm_lane_chain<Row16>(tg, pose + 3, hot, M, K);
+    lm_lane_transform<Row16>(X, Y, M, K, hot, keep, c, dg);
+    lm_lane_to_u21<Row16>(c, U, g);
+    for (int k = 0; k < 21; k++) U21[k] = U[k].l[9];  // (any lane: uniform)
+    for (int k = 0; k < 6; k++) g6[k] = g[k].l[9];
+    const bool ok = lm_lane_solve<Row16>(c, dg, hot, lambda, d);
+    for (int k = 0; k < 6; k++) dx[k] = d[k].l[11];
+    return ok ? 1 : 0;
 }
 // closed-form chain (lm_pose_chain) vs the chain built from dR/drvec (lm_chain): max |difference| over R, Mw, K
 double probe_chain_diff(const double* pose) {

@@ -40,6 +40,7 @@ def probe():
     lib.probe_pose_chain.argtypes = [vp, vp, vp, vp]
     lib.probe_transform_t_diff.argtypes = [vp, vp]
     lib.probe_transform_t_diff.restype = d
+    lib.probe_lane_step.argtypes = [vp, vp, d, vp, vp, vp]
     return lib
 
 
@@ -193,6 +194,66 @@ def test_lm_transform_with_the_translation_folded_in(probe):
         pose = np.concatenate([rng.normal(size=3) * [1e-9, 0.3, 1.5][it % 3], rng.normal(size=3) * [0.1, 3.0][it % 2]])
         worst = max(worst, probe.probe_transform_t_diff(_p(acc), _p(pose)))
     assert worst < 1e-13, worst
+
+
+def test_lane_dealt_lm_step_equals_the_uniform_route(probe):
+    """lm_lanes.hpp (the team kernel's serial section dealt to the lanes of a DPP row: per-lane gather of the totals,
+    chain-rule columns, two 3x3-block products on row_newbcast FMAs, Gauss-Jordan over the lanes) on the host's 16-lane
+    emulation == lm_moments_to_acc + lm_transform + lm_solve6 on the same totals: the system to rounding, the step to
+    the conditioning of the solve, the pivot verdict on a rank-deficient system."""
+    rng = np.random.default_rng(33)
+    worst_sys = worst_dx = 0.0
+    for it in range(300):
+        # moments of a real point set, so that the normal matrix is SPD with the structure the kernels produce
+        n = [6, 40, 400][it % 3]
+        x, y = rng.normal(size=n) * 0.4, rng.normal(size=n) * 0.3
+        iz = 1.0 / rng.uniform(1.0, 6.0, size=n)
+        ex, ey = rng.normal(size=n) * 3.0, rng.normal(size=n) * 3.0
+        xx, yy, xy = x * x, y * y, x * y
+        r2, ox, oy = xx + yy, 1 + xx, 1 + yy
+        qq, p1, p2, iz2 = 1 + r2, x * iz, y * iz, iz * iz
+        mom = [x, y, r2, iz2, iz2 * x, iz2 * y, iz2 * r2, p1, p2, xy * iz, oy * iz, ox * iz, p2 * qq, p1 * qq, xy * (1 + qq),
+               xy * xy + oy * oy, xy * xy + ox * ox, xy * ex + oy * ey, ox * ex + xy * ey, x * ey - y * ex, iz * ex, iz * ey,
+               p1 * ex + p2 * ey, ex * ex + ey * ey]
+        sums = np.array([m.sum() for m in mom] + [1.0, 2.0, float(n)])
+        pose = np.concatenate([rng.normal(size=3) * [1e-9, 0.3, 1.5][it % 3], rng.normal(size=3) * [0.1, 3.0][it % 2]])
+        lam = 10.0 ** rng.integers(-6, 3)
+        U, g, dx = np.zeros(21), np.zeros(6), np.zeros(6)
+        ok = probe.probe_lane_step(_p(sums), _p(pose), float(lam), _p(U), _p(g), _p(dx))
+        # the uniform route on the same totals
+        acc = np.zeros(27)
+        f2m = {0: (15, 1), 1: (14, -1), 2: (0, -1), 3: (9, -1), 4: (10, -1), 5: (12, 1), 6: (16, 1), 7: (1, -1), 8: (11, 1), 9: (9, 1),
+               10: (13, -1), 11: (2, 1), 12: (8, -1), 13: (7, 1), 15: (3, 1), 16: (4, -1), 17: (3, 1), 18: (5, -1), 19: (6, 1),
+               20: (17, -1), 21: (18, 1), 22: (19, 1), 23: (20, 1), 24: (21, 1), 25: (22, -1)}
+        for a, (m, sg) in f2m.items():
+            acc[a] = sg * sums[m]
+        R, Mw, K = np.zeros(9), np.zeros(9), np.zeros(9)
+        probe.probe_pose_chain(_p(pose), _p(R), _p(Mw), _p(K))
+        Mw, K = Mw.reshape(3, 3), K.reshape(3, 3)
+        A6 = np.zeros((6, 6))
+        A6[:3, :3] = [[acc[0], acc[1], acc[2]], [acc[1], acc[6], acc[7]], [acc[2], acc[7], acc[11]]]
+        A6[:3, 3:] = [[acc[3], acc[4], acc[5]], [acc[8], acc[9], acc[10]], [acc[12], acc[13], acc[14]]]
+        A6[3:, :3] = A6[:3, 3:].T
+        A6[3:, 3:] = [[acc[15], 0, acc[16]], [0, acc[17], acc[18]], [acc[16], acc[18], acc[19]]]
+        M6 = np.block([[Mw, np.zeros((3, 3))], [K, np.eye(3)]])
+        Uref = M6.T @ A6 @ M6
+        gref = M6.T @ acc[20:26]
+        Um = np.zeros((6, 6))
+        Um[np.triu_indices(6)] = U
+        scale = np.abs(Uref).max()
+        worst_sys = max(worst_sys, np.abs(np.triu(Um) - np.triu(Uref)).max() / scale, np.abs(g - gref).max() / np.abs(gref).max())
+        Ad = Uref.copy()
+        Ad[np.diag_indices(6)] *= 1 + lam
+        ref = np.linalg.solve(Ad, gref)
+        assert ok == 1
+        worst_dx = max(worst_dx, np.abs(dx - ref).max() / np.abs(ref).max() / max(1.0, np.linalg.cond(Ad) * 1e-9))
+    assert worst_sys < 1e-13, worst_sys
+    assert worst_dx < 1e-8, worst_dx
+    # rank-deficient: all points on one viewing ray -> a pivot collapses once lambda is tiny: the verdict must be "not ok"
+    sums = np.zeros(27)
+    sums[[3, 23]] = [4.0, 1.0]
+    U, g, dx = np.zeros(21), np.zeros(6), np.zeros(6)
+    assert probe.probe_lane_step(_p(sums), _p(np.array([0.1, 0.2, 0.3, 0.0, 0.0, 1.0])), 1e-16, _p(U), _p(g), _p(dx)) == 0
 
 
 # ---------------------------------------------------------------- training path (bwd_math.hpp)

@@ -353,7 +353,8 @@ class Engine:
                 "workgroups": int(v[1]),
                 "xcd_census": [(int(v[2]) >> (8 * x)) & 255 for x in range(4)] + [(int(v[7]) >> (8 * x)) & 255 for x in range(4)],
                 "same_xcd": bool(v[3]),
-                "exchanges": int(v[4]), "timed_out": bool(v[5]), "team_fallbacks": int(v[6])}
+                "exchanges": int(v[4]), "timed_out": bool(v[5]), "team_fallbacks": int(v[6]) & 0x3fffffff,
+                "team_latched_off": bool(int(v[6]) & 0x40000000)}
 
     def set_timing(self, on, period=1):
         """Per-phase events on every `period`-th forward call (the next call is the first sampled one)."""

@@ -80,9 +80,13 @@ struct esac_hip_ctx {
     bool team_spread = false;             // ESAC_DEBUG_TEAM_SPREAD: the members are consecutive workgroups (one per XCD)
     unsigned long long refine_tag = 0;    // tag of the most recent shared (cooperative / team) refinement launch, 0: none yet
     long long team_fallbacks = 0;         // blocking calls whose team timed out and were refined again by one workgroup
+    int team_strikes = 0;                 // consecutive forward calls whose team timed out; at ESAC_TEAM_STRIKES the context stops asking
+    bool team_latched_off = false;        // ... for teams (a caller that keeps the GPU's CUs busy on another stream would otherwise pay the
+    long long solo_since_latch = 0;       // time-out on every frame); re-armed after ESAC_TEAM_REARM_CALLS calls or by esac_hip_set_refine_team
     bool fold_select = true;              // the team kernel may run the selection in its prologue (ESAC_FOLD_SELECT=0: measurement scripts)
-    int last_nsel = 0;                    // slots the most recent blocking esac_hip_backward refined (0: none yet)
-    bool slot_teams = true;               // training path: slots may be refined by teams (off after a time-out; ESAC_SLOT_TEAMS=0)
+    int last_nsel = 0;                    // slots the most recent blocking esac_hip_backward refined (0: none yet; reported, decides nothing)
+    bool slot_teams = true;               // training path: slots may be refined by teams (off after a time-out until
+                                          // esac_hip_set_refine_team re-arms it; ESAC_SLOT_TEAMS=0)
     long long slot_team_calls = 0, slot_team_fallbacks = 0;
     bool last_bwd_teams = false;          // the most recent esac_hip_backward refined its slots by teams
     BwdArgs bws{};  // training-path workspace (pointers only), sized for bN hypotheses, bP cells, bcap slots
@@ -103,6 +107,10 @@ extern "C" int esac_hip_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+
+constexpr int ESAC_SLOT_TEAMS_MAX = 32;  // training path: slots refined by teams when the call selects at most this many
+constexpr int ESAC_TEAM_STRIKES = 2;
+constexpr long long ESAC_TEAM_REARM_CALLS = 1000;
 
 static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.hyps_R,      c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.samp_count, c->ws.samp_pending, c->ws.fast_scores,
@@ -191,7 +199,10 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.hyps_R, (size_t)nN * 9);
     rc |= alloc(&c->ws.rt32, (size_t)nN * 12);
     rc |= alloc(&c->ws.status, (size_t)1);
-    rc |= alloc(&c->ws.coop_partials, (size_t)2 * ESAC_REFINE_COOP_MAX * 32);
+    // the exchange buffer of shared refinements: partial sums of cooperating workgroups [2][256][32] doubles, or the granules
+    // of up to ESAC_TEAM_BATCH_MAX teams (16 bytes each)
+    static_assert((size_t)ESAC_TEAM_BATCH_MAX * ESAC_TEAM_GRANULES * 2 >= (size_t)2 * ESAC_REFINE_COOP_MAX * 32, "exchange buffer");
+    rc |= alloc(&c->ws.coop_partials, (size_t)ESAC_TEAM_BATCH_MAX * ESAC_TEAM_GRANULES * 2);
     rc |= alloc(&c->ws.coop_counter, (size_t)2);
     rc |= alloc(&c->ws.refine_info, (size_t)8);
     rc |= alloc(&c->ws.sample_xy, (size_t)nN * 8);
@@ -228,7 +239,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     }
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
     HIP_OK(hipMemset(c->ws.coop_counter, 0, 2 * sizeof(unsigned long long)));  // [1]: tag of the last failed shared refinement (esac_hip_check)
-    HIP_OK(hipMemset(c->ws.coop_partials, 0, (size_t)2 * ESAC_REFINE_COOP_MAX * 32 * sizeof(double)));  // (also the team's granules)
+    HIP_OK(hipMemset(c->ws.coop_partials, 0, (size_t)ESAC_TEAM_BATCH_MAX * ESAC_TEAM_GRANULES * 2 * sizeof(double)));  // (also the teams' granules)
     HIP_OK(hipMemset(c->ws.refine_info, 0, 8 * sizeof(int)));
     HIP_OK(hipMemset(c->ws.samp_count, 0, (4 + 2 * 1024) * sizeof(int)));       // the screened chain leaves them at zero (esac_kernels.hip)
     HIP_OK(hipMemset(c->ws.hyps, 0, (size_t)nN * 6 * sizeof(double)));
@@ -363,8 +374,9 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     a.expert_base = p->expert_base;
     a.coop_max = c->coop_max;
     a.coop_extra = c->coop_stall ? 1 : 0;
-    a.team = c->team;
+    a.team = c->team_latched_off ? 0 : c->team;
     a.team_stride = c->team_spread ? 1 : 8;
+    a.solo = 0;
     a.samp_cap = (int)(((long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP) > 0x7fffffffLL ? 0x7fffffff : (long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP);
     a.flags = p->flags;
     c->epoch += 1.0;  // every call gets its own epoch: result hand-off word and the tag of the status word
@@ -532,13 +544,23 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             return 0;
         };
         if ((rc = wait_record(c->epoch))) return rc;
-        if (B == 1 && c->h_pin[33] == 3.0 && refine_team_members(a) > 0) {
-            // the team's members did not all become resident in time (a shared or partitioned GPU): the same refinement in
-            // one workgroup -- the hypotheses, scores and selection of this call are still in the workspace
+        bool team_failed = false;
+        for (int b = 0; b < B; b++) team_failed |= c->h_pin[(size_t)b * ESAC_PIN_DOUBLES + 33] == 3.0;
+        const bool was_team = refine_team_members(a) > 0;
+        if (team_failed && was_team) {
+            // the members of a team did not all become resident in time (a shared or partitioned GPU, or the caller's own
+            // kernels on another stream holding the CUs): the same refinement(s) in ONE workgroup each -- the hypotheses, scores
+            // and selection of this call are still in the workspace.  Twice in a row and the context stops asking for teams
+            // (every call would pay the time-out first) until it is re-armed.
             c->team_fallbacks++;
+            if (++c->team_strikes >= ESAC_TEAM_STRIKES && !c->team_latched_off) {
+                c->team_latched_off = true;
+                c->solo_since_latch = 0;
+            }
             c->epoch += 1.0;
             a.epoch = c->epoch;
             a.team = 0;
+            a.solo = 1;
             if (a.fold_select) {  // the selection was that kernel's too
                 a.fold_select = 0;
                 launch_select_rescore(a, s);
@@ -546,6 +568,11 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             c->refine_tag = launch_refine(a, s);
             if ((rc = check_launch("k_refine (one workgroup, after a team time-out)"))) return rc;
             if ((rc = wait_record(c->epoch))) return rc;
+        } else if (was_team) {
+            c->team_strikes = 0;
+        } else if (c->team_latched_off && ++c->solo_since_latch >= ESAC_TEAM_REARM_CALLS) {
+            c->team_latched_off = false;               // try a team again; one more time-out latches at once
+            c->team_strikes = ESAC_TEAM_STRIKES - 1;
         }
         __sync_synchronize();
         bool bad_assign = false;
@@ -782,10 +809,12 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
     if ((rc = check_launch("k_sample"))) return rc;
     launch_rescore_all(a, s);                                   // esac.cpp:295-316, reference arithmetic for every hypothesis
     if ((rc = check_launch("k_rescore(all)"))) return rc;
-    // Slot refinement by teams of 8 (esac_refine_team.hip) when the previous blocking call selected few enough
-    // hypotheses that every team has an XCD's CUs to itself (<= 32); a blocking call can refine again with one workgroup
-    // per slot should a team time out, an asynchronous one cannot and does not use teams.
-    bool use_teams = h_out && c->slot_teams && c->last_nsel > 0 && c->last_nsel <= 32;
+    // Slot refinement (esac.cpp:328-347): by teams of 8 (esac_refine_team.hip) when THIS call's selection holds few enough slots
+    // that every team has an XCD's CUs to itself (<= 32), one workgroup per slot otherwise.  The count is only known on the
+    // device, so both launches are issued and each returns at once when the other one's case applies (team_max_slots): the
+    // route is a function of the call's own inputs, not of what an earlier call on the context selected.  A blocking call can
+    // refine again with one workgroup per slot should a team time out; an asynchronous one cannot and does not use teams.
+    bool use_teams = h_out && c->slot_teams;
     for (int attempt = 0;; attempt++) {
         if ((rc = ensure_bws(c, p->N, P, cap))) return rc;
         a.bwd = c->bws;
@@ -798,15 +827,15 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
         a.bwd.cut = (double)loss_cut;
         for (int i = 0; i < 16; i++) a.bwd.gt[i] = gt[i];
         for (int i = 0; i < 6; i++) a.bwd.gt_pose[i] = gt_pose[i];
+        const bool teams = use_teams && refine_slots_can_team(a);
+        a.bwd.team_max_slots = teams ? ESAC_SLOT_TEAMS_MAX : 0;
         launch_bwd_select(a, s);                                    // esac.cpp:319-331
         if ((rc = check_launch("k_bwd_select"))) return rc;
-        const bool teams = use_teams && refine_slots_can_team(a);
         if (teams) {
-            launch_refine_slots_team(a, s);                         // esac.cpp:328-347, a team per slot
+            launch_refine_slots_team(a, s);                         // a team per slot, when n_sel <= team_max_slots
             c->slot_team_calls++;
-        } else {
-            launch_refine_slots(a, s);                              // esac.cpp:328-347
         }
+        launch_refine_slots(a, s);                                  // one workgroup per slot otherwise
         if ((rc = check_launch("k_refine(slots)"))) return rc;
         launch_bwd_loss(a, s);                                      // esac.cpp:354-362 + dLoss + softmax derivative
         if ((rc = check_launch("k_bwd_loss"))) return rc;
@@ -829,7 +858,7 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
             continue;
         }
         c->last_nsel = (int)h_out[1];
-        c->last_bwd_teams = teams;
+        c->last_bwd_teams = teams && c->last_nsel <= ESAC_SLOT_TEAMS_MAX;
         const int needed = (int)h_out[1];
         if (needed <= cap || attempt >= 1) break;  // one retry suffices: the second pass is sized by the true count
         cap = needed + 31 > worst ? worst : (needed + 31) / 32 * 32;
@@ -918,7 +947,7 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
             HIP_OK(hipDeviceSynchronize());
             int32_t info[8];
             HIP_OK(hipMemcpy(info, c->ws.refine_info, sizeof(info), hipMemcpyDeviceToHost));
-            info[6] = (int32_t)c->team_fallbacks;
+            info[6] = (int32_t)((c->team_fallbacks & 0x3fffffff) | (c->team_latched_off ? 0x40000000 : 0));
             memcpy(h_dst, info, sizeof(info));
             return 0;
         }
@@ -968,6 +997,9 @@ extern "C" int esac_hip_set_refine_team(esac_hip_ctx* c, int members) {
     if (!c) return fail(-1, "null context");
     if (members < 0 || members > ESAC_REFINE_TEAM_MAX) return fail(-4, "esac_hip_set_refine_team: %d members (0..%d)", members, ESAC_REFINE_TEAM_MAX);
     c->team = members < 2 ? 0 : members;
+    c->team_latched_off = false;  // an explicit request re-arms the forward teams and the training path's slot teams
+    c->team_strikes = 0;
+    c->slot_teams = true;
     return 0;
 }
 

@@ -17,6 +17,13 @@ constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the er
 constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refinement (one per CU: all must be resident)
 constexpr int ESAC_REFINE_TEAM_MAX_K = 32;   // ... on a small grid: a team on ONE XCD (its 32 CUs; esac_refine_team.hip)
 constexpr int ESAC_REFINE_TEAM_MIN_CELLS = 1024;  // smaller grids are refined by one workgroup (a pass is shorter than an exchange)
+constexpr int ESAC_TEAM_BATCH_MAX = 32;           // frames of a batch that are refined by teams of 8 (32 teams = the chip's 256 CUs at once)
+constexpr int ESAC_TEAM_GRANULES = 2 * ESAC_REFINE_TEAM_MAX_K * 32;  // 16-byte granules of one team's exchanges: [parity][member][value]
+// How long a team member waits at an exchange before it gives up, in ticks of the 100 MHz wall clock: all members become
+// resident within microseconds of each other or not at all (a shared / partitioned GPU, the caller's own kernels holding
+// the CUs), and a round is ~3 us -- 1 ms; the training path's slot teams drain group by group behind each other (a
+// refinement is ~0.1 ms): 8 ms
+constexpr long ESAC_TEAM_SPIN_LIMIT = 100000, ESAC_TEAM_SPIN_LIMIT_SLOTS = 800000;
 constexpr int ESAC_PIN_DOUBLES = 36;       // pinned host slot per frame: result record [32] + epoch word + status word + check word + pad
 // The pinned record is handed over WITHOUT a system-scope fence: the kernel stores the 34 words and a 35th that is a
 // checksum of them (one store instruction), the host accepts a slot once its epoch word is the call's and the check word
@@ -66,6 +73,9 @@ struct BwdArgs {
     int cap;
     // slot refinement by TEAMS (esac_refine_team.hip): 8 workgroups of one XCD per slot; 0 = one workgroup per slot
     int team;
+    int team_max_slots;              // the slot-team launch refines only when n_sel <= this, the one-workgroup-per-slot launch only when
+                                     // n_sel > this (0: no team launch): the route is a function of the call's own selection, decided
+                                     // on the device -- not of what an earlier call selected
     double* team_gran;               // [cap][2][32][32] granules (16 B each) of the slots' exchanges
     unsigned long long team_tag;     // tag of the slot-team launch: the downstream kernels skip their work when it failed
 };
@@ -127,6 +137,8 @@ struct KArgs {
     unsigned long long coop_tag;        // launch number << 20: tags the exchange granules and the failure word of THIS refinement launch
     int team;                           // members of a refinement team on small grids (0: one workgroup refines; esac_hip_set_refine_team)
     int team_stride;                    // the team's members are the workgroups blockIdx.x % team_stride == 0 (8: one XCD; 1: debug, spread)
+    int solo;                           // 1: launch_refine takes ONE workgroup per refinement whatever the shape (the retry after a shared
+                                        // refinement timed out: neither a team nor cooperating workgroups, both need co-residency again)
     int* refine_info;                   // [8] mode, members, XCD census (4 bits per XCD), same-XCD flag, exchanges, failed
     int fold_select;                    // the team kernel also runs the selection (softmax statistics, band of contenders, their exact
                                         // re-score) in its prologue: no k_select_rescore launch in front of it (refine_folds_select)

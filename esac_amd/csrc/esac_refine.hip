@@ -480,10 +480,11 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
 #endif
     CYC_BEGIN();
     if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
+    if (SLOTS && a.bwd.team_max_slots > 0 && a.bwd.n_sel[0] <= a.bwd.team_max_slots) return;  // few slots: the team launch refines them
     Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull};
     int cell0 = 0, Pn = P;  // this workgroup's cells: [cell0, cell0 + Pn)
     if (SHARED) {
-        coop_init(co, a, (int)gridDim.x, (int)blockIdx.x, 1L << 25);
+        coop_init(co, a, (int)gridDim.x, (int)blockIdx.x, a.coop_extra ? (1L << 12) : (1L << 25));  // polls: ~seconds; the stall test gives up after ~1 ms
         cell0 = co.g * a.coop_slice;
         Pn = P - cell0 < a.coop_slice ? P - cell0 : a.coop_slice;
     }
@@ -603,8 +604,8 @@ unsigned long long launch_refine(const KArgs& a, hipStream_t s) {
     const bool global_list = a.H * a.W > LDS_CAP;
     // 16-byte accesses: W % 4 == 0 keeps every row, plane (P % 4 == 0) and expert map 16-byte aligned
     const bool vec = (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.sc) & 15) == 0;
-    if (refine_team_members(a) > 0) return launch_refine_team(a, s);  // single frames on grids up to 32768 cells
-    const int slice = refine_coop_slice(a);
+    if (!a.solo && refine_team_members(a) > 0) return launch_refine_team(a, s);  // single frames (and small batches) on grids up to 32768 cells
+    const int slice = a.solo ? 0 : refine_coop_slice(a);
     if (slice > 0) {
         KArgs b = a;
         b.coop_slice = slice;

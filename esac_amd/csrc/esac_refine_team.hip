@@ -411,18 +411,29 @@ __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>&
     return win;
 }
 
-// SLOTS (training path, esac.cpp:328-347): one team of 8 per selection slot.  Blocks come in groups of 64 = 8 teams, one
+// TEAM_SLOTS (training path, esac.cpp:328-347): one team of 8 per selection slot.  Blocks come in groups of 64 = 8 teams, one
 // per XCD: block L is member (L % 64) / 8 of the team on XCD L % 8 of group L / 64, which refines slot (L / 64) * 8 + L % 8.
 // Every block of such a launch is a member; teams of slots beyond n_sel leave at once.  No winner pick, no selection, no
 // record: the refined pose goes to bwd.ref_hyps, the trace to bwd.map_info, the last accepted inlier set to buffer 0 of
 // the slot's maps.  Teams become resident in dispatch order, so a launch with more teams than the chip holds at once
 // (32) drains group by group; a team never waits for a later one.
-template <int CPL, bool SLOTS = false>
+// TEAM_FRAMES (esac_hip_forward_batch, round 5): the same block -> team mapping with FRAME (L / 64) * 8 + L % 8 of a batch of
+// at most ESAC_TEAM_BATCH_MAX frames in place of the slot -- every frame's winner gets what the single call's gets (8 CUs of
+// one XCD, the selection folded in for <= 256 hypotheses), each team with its own granules.
+enum : int { TEAM_SINGLE = 0, TEAM_SLOTS = 1, TEAM_FRAMES = 2 };
+template <int CPL, int MODE = TEAM_SINGLE>
 __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     constexpr int B = REFINE_B;
-    if (!SLOTS && (blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
-    const int slot = SLOTS ? (int)(blockIdx.x >> 6) * 8 + (int)(blockIdx.x & 7) : 0;
+    constexpr bool SLOTS = MODE == TEAM_SLOTS;
+    if (MODE == TEAM_SINGLE && (blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
+    const int slot = MODE != TEAM_SINGLE ? (int)(blockIdx.x >> 6) * 8 + (int)(blockIdx.x & 7) : 0;  // slot / frame of this block's team
     if (SLOTS && slot >= a.bwd.n_sel[0]) return;
+    if (SLOTS && a.bwd.n_sel[0] > a.bwd.team_max_slots) return;  // (many slots: one workgroup each is the better shape, launch_refine_slots does it)
+    if (MODE == TEAM_FRAMES) {
+        if (slot >= a.frames) return;
+        frame_view(a, slot);
+        if (slot != 0) a.refine_info = nullptr;  // the info words describe frame 0's refinement
+    }
     // ONE allocation, the arrays first: their addresses then fit the 16-bit offset field of the LDS instructions (one base
     // register for all of them).  As separate variables they were laid out behind the 96 KB pad, and every access
     // materialised its own address first -- an extra instruction per LDS access on a section every lane walks.
@@ -461,11 +472,14 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     CYC_BEGIN();
     Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull};
     if (SLOTS) {
-        coop_init(co, a, 8, (int)(blockIdx.x & 63) >> 3, 1L << 22);
-        co.gran = reinterpret_cast<u32x4*>(a.bwd.team_gran) + (size_t)slot * (2 * TEAM_MAX * 32);
+        coop_init(co, a, 8, (int)(blockIdx.x & 63) >> 3, ESAC_TEAM_SPIN_LIMIT_SLOTS);
+        co.gran = reinterpret_cast<u32x4*>(a.bwd.team_gran) + (size_t)slot * ESAC_TEAM_GRANULES;
         co.tag = a.bwd.team_tag;
+    } else if (MODE == TEAM_FRAMES) {
+        coop_init(co, a, 8, (int)(blockIdx.x & 63) >> 3, ESAC_TEAM_SPIN_LIMIT);
+        co.gran += (size_t)slot * ESAC_TEAM_GRANULES;
     } else {
-        coop_init(co, a, (int)gridDim.x / a.team_stride, (int)blockIdx.x / a.team_stride, 1L << 22);
+        coop_init(co, a, (int)gridDim.x / a.team_stride, (int)blockIdx.x / a.team_stride, ESAC_TEAM_SPIN_LIMIT);
     }
     co.expect = co.G;
     if (a.coop_extra && co.g == co.G - 1) return;  // ESAC_DEBUG_COOP_STALL: the last member never shows up
@@ -655,7 +669,10 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 // (four cells per lane); the device must hold the whole launch at once.
 int refine_team_members(const KArgs& a) {
     const int P = a.H * a.W;
-    if (a.team < 2 || P > TEAM_MAX * TEAM_CPL_MAX * REFINE_B || P < ESAC_REFINE_TEAM_MIN_CELLS || a.frames != 1 || !a.coop_partials) return 0;
+    if (a.team < 2 || P > TEAM_MAX * TEAM_CPL_MAX * REFINE_B || P < ESAC_REFINE_TEAM_MIN_CELLS || !a.coop_partials) return 0;
+    if (a.frames != 1) {  // a small batch: a team of 8 per frame (k_refine_team<CPL, TEAM_FRAMES>), all teams resident together
+        return a.frames <= ESAC_TEAM_BATCH_MAX && P <= 8 * TEAM_CPL_MAX * REFINE_B && a.coop_max >= 8 * ESAC_TEAM_BATCH_MAX ? 8 : 0;
+    }
     int G = (P + REFINE_B - 1) / REFINE_B;
     if (G > a.team) G = a.team;
     if (G > TEAM_MAX) G = TEAM_MAX;
@@ -676,13 +693,14 @@ unsigned long long launch_refine_slots_team(KArgs& a, hipStream_t s) {
     a.bwd.team = 8;
     const int P = a.H * a.W;
     const int cpl = ((P + 7) / 8 + REFINE_B - 1) / REFINE_B;
-    const int cap = a.N < a.bwd.cap ? a.N : a.bwd.cap;
+    int cap = a.N < a.bwd.cap ? a.N : a.bwd.cap;
+    if (cap > a.bwd.team_max_slots) cap = a.bwd.team_max_slots;  // (a selection of more slots is refined by launch_refine_slots)
     const dim3 grid((unsigned)((cap + 7) / 8) * 64), block(REFINE_B);
     switch (cpl) {
-        case 1: hipLaunchKernelGGL((k_refine_team<1, true>), grid, block, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_refine_team<2, true>), grid, block, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((k_refine_team<3, true>), grid, block, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_refine_team<4, true>), grid, block, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_refine_team<1, TEAM_SLOTS>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_refine_team<2, TEAM_SLOTS>), grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_refine_team<3, TEAM_SLOTS>), grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_refine_team<4, TEAM_SLOTS>), grid, block, 0, s, a); break;
     }
     return a.bwd.team_tag;
 }
@@ -701,6 +719,16 @@ unsigned long long launch_refine_team(const KArgs& a, hipStream_t s) {
     const int P = a.H * a.W;
     const int slice = (P + G - 1) / G;  // the largest member slice: floor((g+1) P / G) - floor(g P / G) <= ceil(P / G)
     const int cpl = (slice + REFINE_B - 1) / REFINE_B;
+    if (a.frames != 1) {  // a team of 8 per frame, eight teams per 64 blocks (one per XCD)
+        const dim3 grid((unsigned)((a.frames + 7) / 8) * 64), block(REFINE_B);
+        switch (cpl) {
+            case 1: hipLaunchKernelGGL((k_refine_team<1, TEAM_FRAMES>), grid, block, 0, s, b); break;
+            case 2: hipLaunchKernelGGL((k_refine_team<2, TEAM_FRAMES>), grid, block, 0, s, b); break;
+            case 3: hipLaunchKernelGGL((k_refine_team<3, TEAM_FRAMES>), grid, block, 0, s, b); break;
+            default: hipLaunchKernelGGL((k_refine_team<4, TEAM_FRAMES>), grid, block, 0, s, b); break;
+        }
+        return b.coop_tag;
+    }
     const dim3 grid(G * b.team_stride), block(REFINE_B);
     switch (cpl) {
         case 1: hipLaunchKernelGGL((k_refine_team<1>), grid, block, 0, s, b); break;

@@ -198,7 +198,7 @@ struct Coop {
     unsigned long long* failed;    // the launch tag of the most recent launch in which an exchange timed out (what the host reads)
     unsigned long long arrivals;   // exchanges passed so far (same in every thread of every workgroup)
     int expect;                    // workgroups an exchange waits for (= G; ESAC_DEBUG_COOP_STALL: G + 1, never reached)
-    long spin_limit;               // polls before an exchange gives up
+    long spin_limit;               // REFINE_COOP: polls before the barrier gives up; REFINE_TEAM: ticks of the 100 MHz wall clock
     int* s_dead;                   // LDS flag: an exchange of this launch timed out somewhere
     bool dead;                     // ... as every thread of the workgroup saw it after its last exchange (workgroup-uniform)
     u32x4* gran;                   // REFINE_TEAM: [2][TEAM_MAX][32] granules
@@ -220,7 +220,7 @@ __device__ __forceinline__ void coop_init(Coop& co, const KArgs& a, int G, int g
     co.failed = a.coop_counter + 1;
     co.tag = a.coop_tag;
     co.expect = G + a.coop_extra;
-    co.spin_limit = a.coop_extra ? (1L << 12) : spin_limit;  // ~seconds normally; the stall test gives up after ~1 ms
+    co.spin_limit = spin_limit;
     if (threadIdx.x == 0) *co.s_dead = 0;
 }
 
@@ -272,9 +272,18 @@ __device__ __forceinline__ void team_collect_lds(Coop& co, double* s_tot, double
         out = __longlong_as_double((long long)bits);
         return (tg ^ bits) == want;
     };
-    // another member gave up (its failure word carries this launch's tag): no point in waiting out the limit
+    // The wait is bounded in TIME (co.spin_limit ticks of the 100 MHz wall clock, ESAC_TEAM_SPIN_LIMIT: a poll is an L2 round
+    // trip whose duration depends on what else the chip is doing); the clock is first read when a poll has failed, then every
+    // 64 polls -- together with the failure word: another member gave up (it carries this launch's tag), no point in
+    // waiting out the limit.
+    long long t_first = 0;
     auto give_up = [&](long spins) {
-        return spins > co.spin_limit || ((spins & 255) == 0 && __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag);
+        if (spins == 1) {
+            t_first = wall_clock64();
+            return false;
+        }
+        if ((spins & 63) != 0) return false;
+        return wall_clock64() - t_first > co.spin_limit || __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag;
     };
     if (co.expect <= 8 || s_x == nullptr) {
         if (j < co.expect && k < NV) {

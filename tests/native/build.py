@@ -55,3 +55,15 @@ def build_screen_campaign(force=False):
         hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
         subprocess.check_call([hipcc] + product.FLAGS + [CAMPAIGN_SRC, "-o", CAMPAIGN_LIB])
     return CAMPAIGN_LIB
+
+
+FILLER_SRC = os.path.join(HERE, "filler.hip")
+FILLER_LIB = os.path.join(HERE, "libfiller.so")
+
+
+def build_filler(force=False):
+    """DEVICE build of the CU filler (filler.hip): workgroups that hold the CUs of one XCD and leave one by one."""
+    if force or not os.path.exists(FILLER_LIB) or os.path.getmtime(FILLER_SRC) > os.path.getmtime(FILLER_LIB):
+        hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", FILLER_SRC, "-o", FILLER_LIB])
+    return FILLER_LIB

@@ -347,22 +347,27 @@ def test_backward_rejects_sharded_calls_and_bad_pointers(engine):
         engine.backward_device(sc, torch.zeros(1, 3, 60, 79, device="cuda"), ha, np.eye(4, dtype=np.float32), 1.0, 100.0, 100.0, p)
 
 
-def test_slot_teams_equal_one_workgroup_per_slot(oracle):
-    """The training path refines its selected hypotheses ("slots") by TEAMS of 8 workgroups on one XCD each once a blocking
-    call has seen that few enough are selected (<= 32); the first call on a context, and every call after a team timed
-    out, uses one workgroup per slot.  Same frame, same key: expected loss, slot list, refined poses and the gradient
-    tensor of both routes against each other and against the oracle; then a team that never completes
-    (ESAC_DEBUG_COOP_STALL): the call refines again with one workgroup per slot, returns the same result, and teams stay
-    off on that context."""
-    eng = api.Engine(0)  # a context of its own: the shared one has long decided
+def test_slot_teams_equal_one_workgroup_per_slot(oracle, monkeypatch):
+    """The training path refines its selected hypotheses ("slots") by TEAMS of 8 workgroups on one XCD each when THE CALL ITSELF
+    selects few enough (<= 32, decided on the device: both launches are issued, one of them returns at once), one workgroup
+    per slot otherwise -- the route is a function of the call's inputs, so the first call on a context already takes it and
+    an identical second call returns the same bits.  Same frame, same key: expected loss, slot list, refined poses and the
+    gradient tensor of both routes against each other and against the oracle; then a team that never completes
+    (ESAC_DEBUG_COOP_STALL): the call refines again with one workgroup per slot, returns that route's result, and teams stay
+    off on that context until esac_hip_set_refine_team re-arms them."""
+    monkeypatch.setenv("ESAC_SLOT_TEAMS", "0")
+    solo = api.Engine(0)  # a context that never asks for slot teams
+    monkeypatch.delenv("ESAC_SLOT_TEAMS")
+    eng = api.Engine(0)   # a context of its own: the shared one may have latched
     f = S.make_frame(83)
     ha = S.gating_assignment(f, 96)
     gt = _gt(f)
     _run = lambda e, o, fr, a, seed, call: _run_both(e, o, fr, a, gt, seed=seed, call=call)
-    first = _run(eng, oracle, f, ha, 7, 3)
-    assert not eng.bwd_team_info()["teams"] and eng.bwd_team_info()["slots"] == int(first[0][1]) <= 32
-    solo_refs = eng.read(api.BUF_BWD_REF_HYPS).copy()
-    second = _run(eng, oracle, f, ha, 7, 3)
+    first = _run(solo, oracle, f, ha, 7, 3)
+    assert not solo.bwd_team_info()["teams"] and solo.bwd_team_info()["slots"] == int(first[0][1]) <= 32
+    _check(solo, *first)
+    solo_refs = solo.read(api.BUF_BWD_REF_HYPS).copy()
+    second = _run(eng, oracle, f, ha, 7, 3)  # the FIRST call on this context: teams at once
     info = eng.bwd_team_info()
     assert info["teams"] and info["team_calls"] == 1 and info["team_fallbacks"] == 0, info
     _check(eng, *second)
@@ -370,6 +375,8 @@ def test_slot_teams_equal_one_workgroup_per_slot(oracle):
     np.testing.assert_allclose(eng.read(api.BUF_BWD_REF_HYPS), solo_refs, rtol=0, atol=1e-8)
     scale = np.abs(first[1]).max()
     assert np.abs(second[1] - first[1]).max() <= 1e-3 * scale  # (sampled cells: the finite-difference path amplifies 1e-9 pose differences)
+    again = _run(eng, oracle, f, ha, 7, 3)
+    np.testing.assert_array_equal(again[1], second[1])  # same inputs, same key, same route: same bits, whatever ran before
     # a member that never shows up
     eng.set_debug(coop_stall=True)
     try:
@@ -379,7 +386,11 @@ def test_slot_teams_equal_one_workgroup_per_slot(oracle):
     info = eng.bwd_team_info()
     assert not info["teams"] and info["team_fallbacks"] == 1, info
     _check(eng, *third)
-    np.testing.assert_array_equal(third[1], first[1])  # one workgroup per slot again: bit for bit the first call
+    np.testing.assert_array_equal(third[1], first[1])  # one workgroup per slot: bit for bit the other context's result
     fourth = _run(eng, oracle, f, ha, 7, 3)
-    assert not eng.bwd_team_info()["teams"] and eng.bwd_team_info()["team_calls"] == 2  # (the stalled call counted, no call since)
+    assert not eng.bwd_team_info()["teams"] and eng.bwd_team_info()["team_calls"] == 3  # (the stalled call counted, no team call since)
     np.testing.assert_array_equal(fourth[1], first[1])
+    eng.set_refine_team(8)  # an explicit request re-arms the teams
+    fifth = _run(eng, oracle, f, ha, 7, 3)
+    assert eng.bwd_team_info()["teams"]
+    np.testing.assert_array_equal(fifth[1], second[1])

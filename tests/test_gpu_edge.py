@@ -178,32 +178,37 @@ def _same_record(batch_rec, single_rec, upto):
 
 
 def test_batched_forward_equals_sequential_calls(engine):
-    """esac_hip_forward_batch: frame b == the b-th of B consecutive single calls -- bit for bit when the single calls
-    refine in one workgroup like the frames of a batch do, to the rounding of the LM sums when a team refines them."""
-    B, N = 12, 96
-    frames = [S.make_frame(70 + b, E=2, true_expert=b % 2) for b in range(B)]
-    assigns = np.stack([S.gating_assignment(f, N, mode="gating") for f in frames])
-    coords = torch.from_numpy(np.stack([f["coords"] for f in frames])).cuda()
-    ha = torch.from_numpy(assigns).cuda()
-    scores_b = torch.empty(B, N, dtype=torch.float64, device="cuda")
-    p = engine.make_params(2, 60, 80, N, call=40)
-    res_b = engine.forward_batch(coords, ha, p, scores_out=scores_b)
+    """esac_hip_forward_batch: frame b == the b-th of B consecutive single calls, BIT FOR BIT on the same refinement route: a
+    batch of up to 32 frames refines every winner by a team of 8 like the single call does (round 5), a larger batch -- and
+    any batch with teams switched off -- by one workgroup per frame; across the two routes the records agree to the rounding
+    of the LM sums."""
     try:
-        for team in (0, api.REFINE_TEAM_DEFAULT):
+        # (N * B <= 2048 throughout: beyond that the fp32 score stream runs with 4 wavefronts per hypothesis instead of 8 --
+        # another summation order of the cells, so non-contender scores and the softmax statistics move in their last fp32 digit)
+        for B, team, N in ((12, api.REFINE_TEAM_DEFAULT, 96), (12, 0, 96), (35, api.REFINE_TEAM_DEFAULT, 48)):
+            frames = [S.make_frame(70 + b, E=2, true_expert=b % 2) for b in range(B)]
+            assigns = np.stack([S.gating_assignment(f, N, mode="gating") for f in frames])
+            coords = torch.from_numpy(np.stack([f["coords"] for f in frames])).cuda()
+            ha = torch.from_numpy(assigns).cuda()
+            scores_b = torch.empty(B, N, dtype=torch.float64, device="cuda")
+            p = engine.make_params(2, 60, 80, N, call=40)
             engine.set_refine_team(team)
-            for b in range(B):
-                q = engine.make_params(2, 60, 80, N, call=40 + b)
-                s1 = torch.empty(N, dtype=torch.float64, device="cuda")
-                r1 = engine.forward_device(coords[b], ha[b], q, scores_out=s1)
-                if team == 0:
-                    np.testing.assert_array_equal(res_b[b][:31], r1[:31])
-                else:
-                    _same_record(res_b[b], r1, 31)
-                    assert engine.refine_info()["mode"] == "team"
-                if team == 0:
-                    np.testing.assert_array_equal(scores_b[b].cpu().numpy(), s1.cpu().numpy())
-                else:  # the contenders' exact scores: another summation order of the cells
-                    np.testing.assert_allclose(scores_b[b].cpu().numpy(), s1.cpu().numpy(), rtol=1e-12, atol=0)
+            res_b = engine.forward_batch(coords, ha, p, scores_out=scores_b)
+            batch_teams = team != 0 and B <= 32
+            assert engine.refine_info()["mode"] == ("team" if batch_teams else "one_workgroup")
+            for single_team in (0, api.REFINE_TEAM_DEFAULT):
+                engine.set_refine_team(single_team)
+                for b in range(B if single_team == team else 4):
+                    q = engine.make_params(2, 60, 80, N, call=40 + b)
+                    s1 = torch.empty(N, dtype=torch.float64, device="cuda")
+                    r1 = engine.forward_device(coords[b], ha[b], q, scores_out=s1)
+                    assert engine.refine_info()["mode"] == ("team" if single_team else "one_workgroup")
+                    if (single_team != 0) == batch_teams:  # the same route: the same bits
+                        np.testing.assert_array_equal(res_b[b][:31], r1[:31], err_msg="B %d team %d single %d frame %d" % (B, team, single_team, b))
+                        np.testing.assert_array_equal(scores_b[b].cpu().numpy(), s1.cpu().numpy())
+                    else:  # the other summation order of the cells
+                        _same_record(res_b[b], r1, 31)
+                        np.testing.assert_allclose(scores_b[b].cpu().numpy(), s1.cpu().numpy(), rtol=1e-12, atol=0)
     finally:
         engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
     # module-level API, shared maps for every frame

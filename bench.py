@@ -192,15 +192,24 @@ def load_profile(config):
     return None
 
 
-# one-GPU stage times (ms) of the BASELINE workloads, from this round's bench lines (profiles/r04_bench_<cfg>.json): the inputs of
-# `expected_scaling`.  host = ms_per_step - sum of the stages (launches, boundaries, hand-off)
-EXPECTED_T1_MS = {
-    "cfg2": {"sample": 0.0172, "score": 0.0038, "select": 0.0004, "refine": 0.0835, "host": 0.022},
-    "cfg3": {"sample": 0.0761, "score": 0.0078, "select": 0.0102, "refine": 0.0872, "host": 0.005},
-    "cfg4": {"sample": 0.1132, "score": 0.0190, "select": 0.0104, "refine": 0.0715, "host": 0.022},
-    "cfg5a": {"sample": 1.6116, "score": 0.0669, "select": 0.0116, "refine": 0.0963, "host": 0.029},
-    "cfg5b": {"sample": 1.8210, "score": 2.5507, "select": 0.0331, "refine": 0.3770, "host": 0.127},
-}
+def one_gpu_stage_ms(config):
+    """One-GPU stage times (ms) of a BASELINE workload from the newest committed bench line of it (profiles/r*_bench_<cfg>.json, written by
+    this script on one GPU): the inputs of `expected_scaling`.  host = ms_per_step - sum of the stages (launches, boundaries, hand-off).
+    None when no such line is in the tree: no prediction is made then."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_%s.json" % config)), reverse=True):
+        try:
+            with open(path) as fh:
+                d = json.loads(fh.read().strip().splitlines()[-1])
+            st = {k["stage"]: k["avg_us"] * 1e-3 for k in d["kernels"]}
+            out = {"sample": st["sample"], "score": st["score"], "select": st["select_rescore"], "refine": st["refine"],
+                   "source": os.path.relpath(path, ROOT)}
+            out["host"] = max(0.0, d["ms_per_step"] - sum(out[k] for k in ("sample", "score", "select", "refine")))
+            return out
+        except Exception:
+            continue
+    return None
+
+
 STAGE_OF = (("k_sample", "sample"), ("k_bucket", "score"), ("k_score", "score"), ("k_select", "select_rescore"),
             ("k_refine", "refine"))
 # what bounds each stage (DESIGN.md section 5): the figures are op-count models, stated there
@@ -298,7 +307,9 @@ def main():
     n_local = n_total if world == 1 else None
     scores = torch.empty(n_total, dtype=torch.float64, device=dev) if world == 1 else None
     PHASE_EVERY = 16  # multi-GPU: the all-reduce / shard-build event pairs cost GPU time themselves, sample every 16th step
-    params = eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=0, **kw) if world == 1 else None
+    # the routes esac.forward() takes by default: ESAC_FLAG_AUTO_EXACT = every score in reference arithmetic where that is free
+    # (one expert, N*H*W <= 2^21: cfg2), the fp32 ranking stream + exact re-score of the contenders elsewhere
+    params = eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=0, exact_scores="auto", **kw) if world == 1 else None
     ar_timers = []
 
     def step(i):
@@ -306,7 +317,7 @@ def main():
         if world == 1:
             params.call = i  # per step only the call counter moves
             return eng.forward_device(d_coords[k], d_assign[k], params, scores_out=scores)
-        pk = dict(seed=BENCH_SEED, call=i, **kw)
+        pk = dict(seed=BENCH_SEED, call=i, exact_scores="auto", **kw)
         if owned:
             pk["total_experts"] = E
         if plans is not None:
@@ -367,29 +378,77 @@ def main():
         torch.cuda.synchronize()
         seed1305 = n_total * steps / (time.perf_counter() - t1)
         params.seed = BENCH_SEED
-    # the same K steps on the GUARANTEED routes (ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING: every score in reference
-    # arithmetic, the sampling loop try by try without the fp32 screen) -- what "score tensors identical" costs; never `value`
-    value_exact = None
+    # the same K steps on the OTHER score route: where `value` ran the guaranteed routes (ESAC_FLAG_AUTO_EXACT applies: cfg2) the
+    # fp32 ranking stream (`value_fast`); where it ran the ranking stream (cfg3) the guaranteed routes (`value_exact`:
+    # ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING) -- what "score tensors identical" costs there; never `value`
+    value_exact = value_fast = None
+    auto_applies = E == 1 and n_total * H * W <= (1 << 21)
     if world == 1 and config_name in ("cfg2", "cfg3") and not args.no_exact:
-        pe = eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=0, exact_scores=True, exact_sampling=True, **kw)
+        pe = eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=0, exact_scores=not auto_applies, exact_sampling=not auto_applies, **kw)
         ke = max(10, steps // (1 if config_name == "cfg2" else 4))
-        def step_exact(i):
+        def step_other(i):
             pe.call = i
             return eng.forward_device(d_coords[i % n_frames], d_assign[i % n_frames], pe, scores_out=scores)
         for i in range(min(warmup, 10)):
-            step_exact(i)
+            step_other(i)
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        t_other = time.perf_counter()
         for i in range(ke):
-            step_exact(warmup + i)
+            step_other(warmup + i)
         torch.cuda.synchronize()
-        te = time.perf_counter() - t1
-        value_exact = {"value": n_total * ke / te, "unit": "hypotheses/s", "ms_per_step": te / ke * 1e3, "steps": ke,
-                       "flags": "ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING",
-                       "note": "every hypothesis scored in the reference's float/double mix (score vector, probability, entropy = the reference's "
-                               "values to 1e-12), hypotheses sampled without the fp32 screen; never `value`"}
+        te = time.perf_counter() - t_other
+        leg = {"value": n_total * ke / te, "unit": "hypotheses/s", "ms_per_step": te / ke * 1e3, "steps": ke}
+        if auto_applies:
+            value_fast = dict(leg, flags="0", note="fp32 ranking stream (k_score_fast) + exact re-score of the contenders + selection folded into the "
+                                                   "refinement kernel: non-contender scores, probability and entropy are fp32-path values (|d| <= 2e-3); "
+                                                   "winner and pose identical; never `value`")
+        else:
+            value_exact = dict(leg, flags="ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING",
+                               note="every hypothesis scored in the reference's float/double mix (score vector, probability, entropy = the reference's "
+                                    "values to 1e-12), hypotheses sampled without the fp32 screen; never `value`")
+    # the multi-GPU call path on the ONE GPU of this box: the same K steps through forward_sharded(policy="range") in a one-rank RCCL
+    # group -- what a rank adds to the plain call (the collective, Python glue), with the collective really executing
+    sharded1 = None
+    if world == 1 and config_name == "cfg2" and not args.no_extras:
+        import socket
+        import torch.distributed as dist
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        try:
+            def step_sharded(i, timers=None):
+                return D.forward_sharded(eng, d_coords[i % n_frames], d_assign[i % n_frames],
+                                         dict(seed=BENCH_SEED, call=i, exact_scores="auto", **kw), policy="range", timers=timers)[1]
+            for i in range(max(warmup, 10)):
+                step_sharded(i)
+            torch.cuda.synchronize()
+            t_sh = time.perf_counter()
+            for i in range(steps):
+                step_sharded(warmup + i)
+            torch.cuda.synchronize()
+            t_sh = (time.perf_counter() - t_sh) / steps
+            tm = []
+            for i in range(min(steps, 64)):  # the collective's GPU time and the host's time in the call, event / clock brackets on their own pass
+                step_sharded(warmup + i, timers=tm)
+            torch.cuda.synchronize()
+            ar_gpu = [v[0].elapsed_time(v[1]) for n, v in tm if n == "allreduce"]
+            ar_host = [v for n, v in tm if n == "allreduce_host_ms"]
+            sharded1 = {"ms_per_step": t_sh * 1e3, "value": n_total / t_sh, "unit": "hypotheses/s", "steps": steps, "backend": "nccl (RCCL), 1 rank",
+                        "plain_ms_per_step": elapsed / steps * 1e3, "overhead_us": (t_sh - elapsed / steps) * 1e6,
+                        "allreduce_gpu_ms": float(np.median(ar_gpu)) if ar_gpu else None,
+                        "allreduce_host_call_ms": float(np.median(ar_host)) if ar_host else None,
+                        "zero_ms": 0.0, "pick_ms": 0.0,
+                        "note": "forward_sharded(policy='range') at world 1: the forward launches write scores and record into the exchange buffer, the "
+                                "record reaches the host from the refinement kernel itself (no pick launch at one rank), ONE RCCL all-reduce of "
+                                "N + 32 doubles runs on the launch stream; no memset (two buffers alternate, the pick of call i clears the buffer of "
+                                "call i + 1 when there are several ranks).  overhead_us = what the call adds to the plain one: the host's time "
+                                "inside dist.all_reduce + Python glue (the collective's GPU time overlaps the next call's launch)"}
+        finally:
+            dist.destroy_process_group()
     def _mean_ms(name):
-        v = [a.elapsed_time(b) for n, (a, b) in ar_timers if n == name]
+        v = [ev[0].elapsed_time(ev[1]) for n, ev in ar_timers if n == name]
         return float(np.mean(v)) if v else None
     allreduce_ms, shard_build_ms = _mean_ms("allreduce"), _mean_ms("shard")
 
@@ -429,6 +488,13 @@ def main():
             out["value_seed1305"] = seed1305
         if value_exact is not None:
             out["value_exact"] = value_exact
+        if value_fast is not None:
+            out["value_fast"] = value_fast
+        if sharded1 is not None:
+            out["sharded_world1"] = sharded1
+        out["score_route"] = ("every hypothesis scored in reference arithmetic (ESAC_FLAG_AUTO_EXACT applies: 1 expert, N*H*W <= 2^21) -- score vector, "
+                              "probability, entropy are the reference's values" if auto_applies else
+                              "fp32 ranking stream + exact re-score of the contenders (ESAC_FLAG_AUTO_EXACT does not apply to this shape)")
         if world == 1:
             out["refine"] = eng.refine_info()  # how the winner's refinement of the last step ran (ESAC_BUF_REFINE_INFO)
         if world > 1:
@@ -437,19 +503,19 @@ def main():
             # what the design predicts, so that a measured 1/2/4/8 curve can be checked against a model: the winner's
             # refinement runs on every rank (its local best), the collective and the pick are latency, only sampling + scoring
             # + selection divide by the rank count.  T1_* = one-GPU stage times of this workload (profiles/r04_bench_<cfg>.json).
-            t1 = EXPECTED_T1_MS.get(config_name)
-            ar = allreduce_ms if allreduce_ms is not None else 0.04
-            fixed = (t1["refine"] if t1 else None)
+            stage1 = one_gpu_stage_ms(config_name)
+            fixed = stage1["refine"] + stage1["host"] if stage1 else None
             out["expected_scaling"] = {
                 "model": "ms(N) = refine + host/boundaries + shard_build + all_reduce + pick + (sample + score + select) / N   [strong]; "
                          "weak scaling: the divisible part stays that of one GPU",
-                "one_gpu_stage_ms": t1, "all_reduce_ms_estimate": 0.04, "all_reduce_ms_measured": allreduce_ms, "shard_build_ms_measured": shard_build_ms,
-                "pick_ms_estimate": 0.01,
-                "predicted_ms_per_step": (None if not t1 else
-                                          fixed + t1["host"] + (shard_build_ms or 0.0) + ar + 0.01 +
-                                          (t1["sample"] + t1["score"] + t1["select"]) / (world if scaling == "strong" else 1)),
-                "note": "strong scaling of the many-expert workloads is bounded by the fixed part (Amdahl); no scaling curve has been measured by "
-                        "the builder (gpurun offers one GPU)"}
+                "one_gpu_stage_ms": stage1, "all_reduce_ms_measured": allreduce_ms, "shard_build_ms_measured": shard_build_ms,
+                "pick_ms_estimate": 0.005,
+                "predicted_ms_per_step": (None if not stage1 or allreduce_ms is None else
+                                          fixed + (shard_build_ms or 0.0) + allreduce_ms + 0.005 +
+                                          (stage1["sample"] + stage1["score"] + stage1["select"]) / (world if scaling == "strong" else 1)),
+                "note": "a MODEL next to the measurement, from the one-GPU stage times of the committed bench line named in one_gpu_stage_ms.source "
+                        "and THIS run's measured collective / shard-build times; strong scaling of the many-expert workloads is bounded by the "
+                        "fixed part (Amdahl); no scaling curve has been measured by the builder (gpurun offers one GPU)"}
             if out["expected_scaling"]["predicted_ms_per_step"]:
                 out["expected_scaling"]["predicted_value"] = n_total / (out["expected_scaling"]["predicted_ms_per_step"] * 1e-3)
         if world == 1:
@@ -491,7 +557,8 @@ def main():
             achieved_q = alg_bytes / (quoted_ms * 1e-3) / 1e9
             out["roofline"] = {
                 "kernel": "score stage (%s)" % ("k_bucket + k_score_tiled + k_score_tiled_reduce" if H * W >= 32768 and n_total >= 64 and W % 4 == 0
-                                                else "k_score_fast"),
+                                                else "k_rescore: every hypothesis in the reference's float/double mix, the route `value` takes at this shape "
+                                                     "(ESAC_FLAG_AUTO_EXACT); the fp32 stream k_score_fast is in fast_route" if auto_applies else "k_score_fast"),
                 "bound": "hbm" if not cache_resident else "hbm (nominal: the maps are L2-resident at this grid, the launch is latency/VALU-bound)",
                 # the live HIP-event figure and the committed rocprofv3 average of the same kernel differ by a dispatch / drain
                 # share (back-to-back launches hide part of it): `frac` is quoted on the LONGER of the two durations
@@ -516,6 +583,13 @@ def main():
                         "the fabric.  A fraction above 1 (`cache_served`) means the re-reads never leave L2 / the registers of the tile-"
                         "stationary kernel -- by design; the limiter is then VALU issue, see `valu` and DESIGN.md section 5",
             }
+            if auto_applies:
+                # the fp32 ranking stream on the same frames (the route of `value_fast`; what SURVEY 8d's bytes-per-hypothesis figure was written for)
+                pf = eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=0, **kw)
+                stf = stage_times(eng, d_coords, d_assign, pf, ((warmup + n_frames - 1) // n_frames) * n_frames, reps)
+                out["roofline"]["fast_route"] = {"kernel": "k_score_fast", "kernel_ms": stf["score"], "achieved": alg_bytes / (stf["score"] * 1e-3) / 1e9,
+                                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (stf["score"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                 "stage_us": {k: v * 1e3 for k, v in stf.items()}}
             out["profile_stale"] = bool(prof["stale"]) if prof else None  # committed rocprofv3 / PMC figures measured on other kernel sources?
             rf = out["roofline"]
             if rf["cache_served"]:
@@ -603,6 +677,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    # the JSON line is the LAST thing on stdout: what C libraries still hold in their stdio buffers (RCCL's version banner is
+    # printf'ed at init and flushed at exit when stdout is a pipe) goes nowhere
+    sys.stdout.flush()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
 
 
 if __name__ == "__main__":

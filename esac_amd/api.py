@@ -40,10 +40,11 @@ ABI_SYMBOLS = [
     "esac_hip_score_exact", "esac_hip_read", "esac_hip_write_hyps", "esac_hip_phase_ms", "esac_hip_set_timing",
     "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug", "esac_hip_check",
     "esac_hip_pick_record", "esac_hip_time_stages", "esac_hip_shard_balanced", "esac_hip_set_wait",
-    "esac_hip_set_refine_team",
+    "esac_hip_set_refine_team", "esac_hip_host_turn",
 ]
-ABI_VERSION = 4
+ABI_VERSION = 5
 FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS, FLAG_EXACT_SAMPLING, FLAG_SCORES_BY_INDEX = 1, 2, 4, 8, 16, 32
+FLAG_AUTO_EXACT = 64
 WAIT_SPIN, WAIT_YIELD, WAIT_BLOCK = 0, 1, 2
 DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL, DEBUG_TEAM_SPREAD = 1, 2, 4
 
@@ -100,11 +101,12 @@ def load_library():
         lib.esac_hip_set_debug.argtypes = [vp, i32]
         lib.esac_hip_score_span_ms.argtypes = [vp, vp, vp]
         lib.esac_hip_check.argtypes = [vp]
-        lib.esac_hip_pick_record.argtypes = [vp, vp, i32, vp, vp]
+        lib.esac_hip_pick_record.argtypes = [vp, vp, i32, vp, vp, vp, i32]
         lib.esac_hip_time_stages.argtypes = [vp, vp, vp, pp, vp, i32, vp]
         lib.esac_hip_shard_balanced.argtypes = [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
         lib.esac_hip_set_wait.argtypes = [vp, i32]
         lib.esac_hip_set_refine_team.argtypes = [vp, i32]
+        lib.esac_hip_host_turn.argtypes = [vp, vp]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
                 getattr(lib, name).restype = i32
@@ -135,6 +137,9 @@ class Engine:
         # the raw hipStream_t of torch's current stream: a private torch symbol (no Stream object on the per-call path)
         # with the public route as the fallback, resolved once
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._host_buf = (C.c_double * RES_DOUBLES)()  # host record of a blocking forward call
+        self._host_addr = C.addressof(self._host_buf)
+        self._host_np = np.frombuffer(self._host_buf, dtype=np.float64)
 
     def _call(self, fn, *args):
         """One C-ABI call with this engine's device current (the library calls hipSetDevice itself; the context
@@ -174,7 +179,9 @@ class Engine:
         p.max_tries, p.max_ref_steps, p.hyp_offset = int(max_tries), int(max_ref_steps), int(hyp_offset)
         p.rescore_margin = float(rescore_margin)
         p.d_hyp_index = None
-        p.flags = (FLAG_EXACT_SCORES if exact_scores else 0) | {"auto": 0, "tiled": FLAG_SCORE_TILED, "stream": FLAG_SCORE_STREAM}[score_shape] | \
+        # exact_scores: True / False, or "auto" = the guaranteed routes where they are free (ESAC_FLAG_AUTO_EXACT: what esac.forward asks for)
+        p.flags = (FLAG_AUTO_EXACT if exact_scores == "auto" else FLAG_EXACT_SCORES if exact_scores else 0) | \
+            {"auto": 0, "tiled": FLAG_SCORE_TILED, "stream": FLAG_SCORE_STREAM}[score_shape] | \
             (FLAG_PACK_MAPS if pack_maps else 0) | (FLAG_EXACT_SAMPLING if exact_sampling else 0) | (FLAG_SCORES_BY_INDEX if scores_by_index else 0)
         p.expert_base = int(expert_base)
         self._shape = (int(N), int(H), int(W))
@@ -196,13 +203,16 @@ class Engine:
     def forward_device(self, scene_coords, hyp_assign, params, scores_out=None, result_out=None, want_host=True):
         """scene_coords [E,3,H,W] f32 / hyp_assign [N] i64 on this device. Returns host result (np.float64[32]) or None."""
         sc, ha = self._dev_inputs(scene_coords, hyp_assign)
-        host = np.empty(RES_DOUBLES, np.float64) if want_host else None
-        self._call(self.lib.esac_hip_forward, sc.data_ptr(), ha.data_ptr(), C.byref(params), self._stream(),
-                   scores_out.data_ptr() if scores_out is not None else None,
-                   result_out.data_ptr() if result_out is not None else None,
-                   host.ctypes.data if want_host else None)
+        # (the library makes the context's GPU current itself: no torch device guard on this path; the host record goes
+        # through one preallocated buffer whose address is known -- numpy's .ctypes costs a microsecond per call)
+        rc = self.lib.esac_hip_forward(self.ctx, sc.data_ptr(), ha.data_ptr(), C.byref(params), self._stream(),
+                                       scores_out.data_ptr() if scores_out is not None else None,
+                                       result_out.data_ptr() if result_out is not None else None,
+                                       self._host_addr if want_host else None)
+        if rc != 0:
+            _check(rc, self.lib)
         self._keep = (sc, ha)  # keep inputs alive until the (possibly asynchronous) kernels have run
-        return host
+        return self._host_np.copy() if want_host else None
 
     def forward_batch(self, scene_coords, hyp_assign, params, scores_out=None, result_out=None, want_host=True):
         """B frames per launch set. scene_coords [B,E,3,H,W] (or [E,3,H,W] shared by all frames), hyp_assign [B,N];
@@ -297,13 +307,17 @@ class Engine:
                    out.ctypes.data)
         return dict(zip(("sample", "score", "select_rescore", "refine"), (float(v) for v in out)))
 
-    def pick_record(self, records, world):
+    def pick_record(self, records, world, zero=None):
         """Global winner among `world` per-rank records (device float64 [world*32], e.g. the tail of the all-reduced
-        exchange buffer): picked on the device, returned as np.float64[32]."""
+        exchange buffer): picked on the device, returned as np.float64[32].  zero: optional device float64 tensor the same
+        launch clears (the exchange buffer of the NEXT call)."""
         assert records.is_cuda and records.dtype == torch.float64 and records.is_contiguous() and records.numel() >= 32 * world
-        host = np.zeros(RES_DOUBLES, np.float64)
-        self._call(self.lib.esac_hip_pick_record, records.data_ptr(), int(world), self._stream(), host.ctypes.data)
-        return host
+        assert zero is None or (zero.is_cuda and zero.dtype == torch.float64 and zero.is_contiguous())
+        rc = self.lib.esac_hip_pick_record(self.ctx, records.data_ptr(), int(world), self._stream(), self._host_addr,
+                                           zero.data_ptr() if zero is not None else None, int(zero.numel()) if zero is not None else 0)
+        if rc != 0:
+            _check(rc, self.lib)
+        return self._host_np.copy()
 
     def shard_balanced(self, hyp_assign, world, rank, E, expert_base=0, index_out=None, assign_out=None, info_out=None):
         """This rank's share of the load-balanced split of `hyp_assign` (device int64 [N]), built on the device in one
@@ -356,6 +370,13 @@ class Engine:
                 "exchanges": int(v[4]), "timed_out": bool(v[5]), "team_fallbacks": int(v[6]) & 0x3fffffff,
                 "team_latched_off": bool(int(v[6]) & 0x40000000)}
 
+    def host_turn(self):
+        """Host-side stamps of the most recent blocking forward (esac_hip_host_turn), in microseconds after entry."""
+        out = np.zeros(8, np.float64)
+        _check(self.lib.esac_hip_host_turn(self.ctx, out.ctypes.data), self.lib)
+        return {"args_ready": out[0] * 1e-3, "sample_launched": out[1] * 1e-3, "score_launched": out[2] * 1e-3, "refine_launched": out[3] * 1e-3,
+                "record_landed": out[4] * 1e-3, "returned": out[5] * 1e-3, "entry_ns": out[6]}
+
     def set_timing(self, on, period=1):
         """Per-phase events on every `period`-th forward call (the next call is the first sampled one)."""
         _check(self.lib.esac_hip_set_timing(self.ctx, (max(1, int(period)) if on else 0)), self.lib)
@@ -376,7 +397,7 @@ class Engine:
 # The reference keeps a static RNG whose state advances from call to call
 # (thread_rand.cpp:4-5); here that state is (seed, call counter).
 _state = {"seed": 1305, "call": 0, "engines": {}, "last": None, "max_tries": 0, "max_ref_steps": -1, "fwd_cache": {},
-          "exact_scores": False, "exact_sampling": False}
+          "exact_scores": None, "exact_sampling": False}
 
 
 def set_seed(seed, call=0):
@@ -395,8 +416,11 @@ def set_limits(max_tries=0, max_ref_steps=-1):
 
 def set_exact_scores(on):
     """True: every hypothesis is scored in the reference's arithmetic (ESAC_FLAG_EXACT_SCORES), so the score vector of
-    last_result() and the record's probability / entropy are the reference's own values; the pose is the same either way."""
-    _state["exact_scores"] = bool(on)
+    last_result() and the record's probability / entropy are the reference's own values; the pose is the same either way.
+    False: the fp32 ranking stream + exact re-score of the contenders everywhere.  None (the default): exact where it is
+    free -- one expert, N * H * W <= 2^21, i.e. the reference's own 64- and 256-hypothesis configurations
+    (ESAC_FLAG_AUTO_EXACT) -- and the ranking stream elsewhere."""
+    _state["exact_scores"] = None if on is None else bool(on)
 
 
 def set_exact_sampling(on):
@@ -470,7 +494,8 @@ def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLengt
     p.inlier_thresh, p.inlier_alpha, p.inlier_beta = float(inlierThreshold), float(inlierAlpha), float(inlierBeta)
     p.max_reproj, p.sub_sampling = float(maxReproj), int(subSampling)
     p.max_tries, p.max_ref_steps = int(_state["max_tries"]), int(_state["max_ref_steps"])
-    p.flags = (FLAG_EXACT_SCORES if _state["exact_scores"] else 0) | (FLAG_EXACT_SAMPLING if _state["exact_sampling"] else 0)
+    p.flags = (FLAG_AUTO_EXACT if _state["exact_scores"] is None else FLAG_EXACT_SCORES if _state["exact_scores"] else 0) | \
+        (FLAG_EXACT_SAMPLING if _state["exact_sampling"] else 0)
     p.seed, p.call = _state["seed"] & (2**64 - 1), _state["call"] & (2**64 - 1)
     eng._shape = (int(N), int(H), int(W))
     _state["call"] += 1

@@ -6,6 +6,7 @@
 // (the StopWatch prints of esac.cpp:124,149,161,179).
 #include <hip/hip_runtime.h>
 #include <sched.h>
+#include <time.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -24,7 +25,8 @@ static_assert(ESAC_RES_SCORE == ESAC_RES_SCORE_K && ESAC_RES_HYP == ESAC_RES_HYP
                   ESAC_RES_CONTENDERS == ESAC_RES_CONTENDERS_K && ESAC_RES_LM_ITERS == ESAC_RES_LM_ITERS_K &&
                   ESAC_MAX_REF_STEPS == ESAC_MAX_REF_STEPS_K && ESAC_BWD_MAX_SLOTS == ESAC_BWD_SLOTS_K &&
                   ESAC_FLAG_EXACT_SCORES == ESAC_FLAG_EXACT_SCORES_K && ESAC_FLAG_EXACT_SAMPLING == ESAC_FLAG_EXACT_SAMPLING_K &&
-                  ESAC_FLAG_SCORES_BY_INDEX == ESAC_FLAG_SCORES_BY_INDEX_K && ESAC_REFINE_TEAM_MAX == ESAC_REFINE_TEAM_MAX_K,
+                  ESAC_FLAG_SCORES_BY_INDEX == ESAC_FLAG_SCORES_BY_INDEX_K && ESAC_REFINE_TEAM_MAX == ESAC_REFINE_TEAM_MAX_K &&
+                  (ESAC_FLAG_AUTO_EXACT & (ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING | ESAC_FLAG_SCORES_BY_INDEX)) == 0,
               "result layout drifted between include/esac_hip.h and esac_kernels.hpp");
 
 static thread_local char g_err[512] = "";
@@ -98,7 +100,14 @@ struct esac_hip_ctx {
     int tN = 0, tChunks = 0;
     long long tPart = 0;
     bool rt32_stale = false;  // esac_hip_write_hyps ran: the fp32 [R|t] rows are rebuilt by the next esac_hip_score
+    double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // esac_hip_host_turn: where the host's time of the most recent blocking forward went
 };
+
+static inline double now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e9 + (double)ts.tv_nsec;
+}
 
 extern "C" int esac_hip_abi_version(void) { return ESAC_HIP_ABI_VERSION; }
 extern "C" const char* esac_hip_last_error(void) { return g_err; }
@@ -462,39 +471,58 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
                         const esac_hip_params* p, int B, void* stream, double* d_scores_out, double* d_result_out,
                         double* h_result_out) {
     if (!c) return fail(-1, "null context");
+    const double t_entry = now_ns();
     DeviceGuard guard(c->device);
     KArgs a;
     int rc = make_args(c, d_sc, d_assign, p, &a, B, sc_frame_stride);
     if (rc) return rc;
+    c->host_ns[6] = t_entry;
+    c->host_ns[0] = now_ns() - t_entry;
     hipStream_t s = (hipStream_t)stream;
     a.scores_user = d_scores_out;
     a.result_user = d_result_out;
     a.result_pin = h_result_out ? c->d_pin : nullptr;
+    // ESAC_FLAG_AUTO_EXACT: the guaranteed routes where they are free (include/esac_hip.h)
+    if ((a.flags & ESAC_FLAG_AUTO_EXACT) && B == 1 && a.E == 1 && (long long)a.N * a.H * a.W <= ESAC_AUTO_EXACT_MAX_WORK)
+        a.flags |= ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING;
     // events and stamps cost GPU time themselves (an empty event pair reads ~5 us): sample every timing_period-th call
     const bool tm = c->timing && (c->timing_calls++ % c->timing_period) == 0;
     const bool exact = (a.flags & ESAC_FLAG_EXACT_SCORES) != 0;
-    // device-side span stamps: only the per-hypothesis stream (k_score_fast) writes them
+    // device-side span stamps: only the per-hypothesis stream (k_score_fast) writes them, and k_select_rescore reduces them --
+    // a call whose selection runs in the refinement kernel's prologue keeps ITS launch sequence under timing (the phase
+    // events then bracket what an untimed call runs) and takes no stamps
     if (!tm || a.partials || exact) a.tstamps = nullptr;
+    if (a.tstamps) {
+        KArgs probe = a;
+        probe.tstamps = nullptr;
+        if (c->fold_select && refine_folds_select(probe)) a.tstamps = nullptr;
+    }
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
     c->rt32_stale = false;
     mark_sampling(c, a);
     launch_sample(a, s);
     if ((rc = check_launch("k_sample"))) return rc;
+    c->host_ns[1] = now_ns() - t_entry;
     if (tm) HIP_OK(hipEventRecord(c->ev[1], s));
     // ESAC_FLAG_EXACT_SCORES: every hypothesis scored in the reference's arithmetic (esac_util.h:235-260), softmax
     // statistics from those scores -- the score vector, probability and entropy are then the reference's own values
     if (exact) launch_rescore_all(a, s);
     else       launch_score(a, s);
     if ((rc = check_launch(exact ? "k_rescore(all)" : "k_score_fast"))) return rc;
+    c->host_ns[2] = now_ns() - t_entry;
     if (tm) HIP_OK(hipEventRecord(c->ev[2], s));
     // a single frame of <= 256 hypotheses that a team refines: the selection runs in that kernel's prologue
-    a.fold_select = c->fold_select && refine_folds_select(a) ? 1 : 0;
-    if (exact)               launch_stats_exact(a, s);
-    else if (!a.fold_select) launch_select_rescore(a, s);
+    a.fold_select = !c->fold_select ? 0 : refine_folds_select(a) ? 1 : refine_folds_exact_stats(a) ? 2 : 0;
+    if (exact) {
+        if (a.fold_select != 2) launch_stats_exact(a, s);
+    } else if (!a.fold_select) {
+        launch_select_rescore(a, s);
+    }
     if ((rc = check_launch(exact ? "k_stats_exact" : "k_select_rescore"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
     c->refine_tag = launch_refine(a, s);
     if ((rc = check_launch("k_refine"))) return rc;
+    c->host_ns[3] = now_ns() - t_entry;
     if (tm) {
         HIP_OK(hipEventRecord(c->ev[4], s));
         // an EMPTY interval: what two adjacent hipEventRecord calls measure with nothing in between,
@@ -544,6 +572,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             return 0;
         };
         if ((rc = wait_record(c->epoch))) return rc;
+        c->host_ns[4] = now_ns() - t_entry;
         bool team_failed = false;
         for (int b = 0; b < B; b++) team_failed |= c->h_pin[(size_t)b * ESAC_PIN_DOUBLES + 33] == 3.0;
         const bool was_team = refine_team_members(a) > 0;
@@ -562,8 +591,9 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             a.team = 0;
             a.solo = 1;
             if (a.fold_select) {  // the selection was that kernel's too
+                if (a.fold_select == 2) launch_stats_exact(a, s);
+                else                    launch_select_rescore(a, s);
                 a.fold_select = 0;
-                launch_select_rescore(a, s);
             }
             c->refine_tag = launch_refine(a, s);
             if ((rc = check_launch("k_refine (one workgroup, after a team time-out)"))) return rc;
@@ -587,6 +617,13 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         if (bad_assign)
             return fail(-10, "hypAssignment holds a value outside [0,%d) (device-resident tensor; such hypotheses were scored against expert 0)", p->E);
     }
+    c->host_ns[5] = now_ns() - t_entry;
+    return 0;
+}
+
+extern "C" int esac_hip_host_turn(esac_hip_ctx* c, double out_ns[8]) {
+    if (!c || !out_ns) return fail(-1, "esac_hip_host_turn: null argument");
+    for (int k = 0; k < 8; k++) out_ns[k] = c->host_ns[k];
     return 0;
 }
 
@@ -604,13 +641,16 @@ extern "C" int esac_hip_time_stages(esac_hip_ctx* c, const float* d_sc, const in
     hipStream_t s = (hipStream_t)stream;
     c->rt32_stale = false;
     mark_sampling(c, a);
+    if ((a.flags & ESAC_FLAG_AUTO_EXACT) && a.E == 1 && (long long)a.N * a.H * a.W <= ESAC_AUTO_EXACT_MAX_WORK)
+        a.flags |= ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING;
     const bool exact = (a.flags & ESAC_FLAG_EXACT_SCORES) != 0;
-    a.fold_select = c->fold_select && refine_folds_select(a) ? 1 : 0;  // as esac_hip_forward would run it: stage 2 is then part of stage 3 (reads 0)
+    // as esac_hip_forward would run it: stage 2 is then part of stage 3 (reads 0)
+    a.fold_select = !c->fold_select ? 0 : refine_folds_select(a) ? 1 : refine_folds_exact_stats(a) ? 2 : 0;
     auto stage = [&](int k) {
         switch (k) {
             case 0: launch_sample(a, s); break;
             case 1: if (exact) launch_rescore_all(a, s); else launch_score(a, s); break;
-            case 2: if (exact) launch_stats_exact(a, s); else if (!a.fold_select) launch_select_rescore(a, s); break;
+            case 2: if (exact) { if (a.fold_select != 2) launch_stats_exact(a, s); } else if (!a.fold_select) launch_select_rescore(a, s); break;
             default: c->refine_tag = launch_refine(a, s); break;
         }
     };
@@ -635,13 +675,15 @@ extern "C" int esac_hip_time_stages(esac_hip_ctx* c, const float* d_sc, const in
 }
 
 // Multi-GPU exchange (esac_amd/distributed.py): winner among the per-rank records of the all-reduced buffer.
-extern "C" int esac_hip_pick_record(esac_hip_ctx* c, const double* d_records, int world, void* stream, double* h_record_out) {
-    if (!c || !d_records || !h_record_out || world < 1) return fail(-1, "esac_hip_pick_record: bad argument");
+extern "C" int esac_hip_pick_record(esac_hip_ctx* c, const double* d_records, int world, void* stream, double* h_record_out, double* d_zero,
+                                    int n_zero) {
+    if (!c || !d_records || !h_record_out || world < 1 || n_zero < 0 || (n_zero > 0 && !d_zero))
+        return fail(-1, "esac_hip_pick_record: bad argument");
     DeviceGuard guard(c->device);
     hipStream_t s = (hipStream_t)stream;
     c->epoch += 1.0;
     const double want = c->epoch;
-    launch_pick_record(d_records, world, c->d_pin, want, s);
+    launch_pick_record(d_records, world, c->d_pin, want, d_zero, n_zero, s);
     int rc = check_launch("k_pick_record");
     if (rc) return rc;
     volatile double* word = c->h_pin + 32;

@@ -1137,7 +1137,12 @@ __global__ __launch_bounds__(B) void k_stats_exact(KArgs a) {
 // hypothesis; ESAC_RES_VALID = slot 31 marks a real one).  Global winner = highest exact score, lowest GLOBAL hypothesis
 // index on ties (esac_util.h:519 "first max") -- picked here and handed to the host through pinned memory, like the
 // single-GPU record.  One wavefront.
-__global__ __launch_bounds__(64) void k_pick_record(const double* __restrict__ records, int world, double* __restrict__ pin, double epoch) {
+// zero / n_zero: optional -- the OTHER exchange buffer of the caller's pair, cleared here for the next call (the caller
+// alternates between two buffers, so no call starts with a memset of its own: esac_amd/distributed.py).
+__global__ __launch_bounds__(256) void k_pick_record(const double* __restrict__ records, int world, double* __restrict__ pin, double epoch,
+                                                     double* __restrict__ zero, int n_zero) {
+    for (int i = threadIdx.x; i < n_zero; i += 256) zero[i] = 0.0;
+    if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     double bs = -INFINITY, bh = INFINITY;
     int br = -1;
@@ -1169,8 +1174,8 @@ __global__ __launch_bounds__(64) void k_pick_record(const double* __restrict__ r
         *reinterpret_cast<volatile double*>(pin + 32) = epoch;
     }
 }
-void launch_pick_record(const double* records, int world, double* pin, double epoch, hipStream_t s) {
-    hipLaunchKernelGGL(k_pick_record, dim3(1), dim3(64), 0, s, records, world, pin, epoch);
+void launch_pick_record(const double* records, int world, double* pin, double epoch, double* zero, int n_zero, hipStream_t s) {
+    hipLaunchKernelGGL(k_pick_record, dim3(1), dim3(256), 0, s, records, world, pin, epoch, zero, n_zero);
 }
 
 // ================================================================= multi-GPU: load-balanced shard of the hypotheses

@@ -140,8 +140,10 @@ struct KArgs {
     int solo;                           // 1: launch_refine takes ONE workgroup per refinement whatever the shape (the retry after a shared
                                         // refinement timed out: neither a team nor cooperating workgroups, both need co-residency again)
     int* refine_info;                   // [8] mode, members, XCD census (4 bits per XCD), same-XCD flag, exchanges, failed
-    int fold_select;                    // the team kernel also runs the selection (softmax statistics, band of contenders, their exact
-                                        // re-score) in its prologue: no k_select_rescore launch in front of it (refine_folds_select)
+    int fold_select;                    // 1: the team kernel also runs the selection (softmax statistics, band of contenders, their exact
+                                        // re-score) in its prologue: no k_select_rescore launch in front of it (refine_folds_select);
+                                        // 2: ESAC_FLAG_EXACT_SCORES -- every score is exact already, the prologue only takes the softmax
+                                        // statistics and the argmax: no k_stats_exact launch (refine_folds_exact_stats)
     // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
     int* order;           // [N] hypothesis at sorted position pos (sorted by expert)
     float* rt_sorted;     // [N,12] rt32 rows in sorted order
@@ -173,7 +175,7 @@ int tiled_sub_tiles(int P);
 void launch_select_rescore(const KArgs& a, hipStream_t s);
 void launch_rescore_all(const KArgs& a, hipStream_t s);
 void launch_stats_exact(const KArgs& a, hipStream_t s);
-void launch_pick_record(const double* records, int world, double* pin, double epoch, hipStream_t s);
+void launch_pick_record(const double* records, int world, double* pin, double epoch, double* zero, int n_zero, hipStream_t s);
 void launch_shard_balanced(const int64_t* assign, int N, int E, int world, int rank, int expert_base, int32_t* index_out,
                            int64_t* assign_out, int32_t* info_out, hipStream_t s);
 int refine_coop_capacity();              // resident workgroups of the cooperative refinement kernel on the current device
@@ -183,6 +185,7 @@ unsigned long long launch_refine(const KArgs& a, hipStream_t s);  // returns the
 unsigned long long launch_refine_team(const KArgs& a, hipStream_t s);  // esac_refine_team.hip; requires refine_team_members(a) > 0
 unsigned long long next_refine_tag();
 bool refine_folds_select(const KArgs& a);  // the refinement launch of this call can (and will) do the selection itself
+bool refine_folds_exact_stats(const KArgs& a);  // ... the softmax statistics of the exact scores (ESAC_FLAG_EXACT_SCORES)
 // training path (esac_backward.hip, esac_refine.hip)
 void launch_refine_slots(const KArgs& a, hipStream_t s);
 bool refine_slots_can_team(const KArgs& a);            // grid fits a team of 8 (1024 .. 8192 cells)

@@ -411,6 +411,81 @@ __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>&
     return win;
 }
 
+// ---- ESAC_FLAG_EXACT_SCORES, folded (a.fold_select == 2; N <= REFINE_B: one hypothesis per thread): k_rescore has scored every
+// hypothesis in reference arithmetic -- softMax / entropy over those scores (esac_util.h:461-497) and draw's argmax
+// (esac_util.h:512-529, first global index on ties), what k_stats_exact + refine_pick_winner do in a launch of their own.
+// Every member computes the same from the same scores; no exchange.
+__device__ __forceinline__ int team_select_exact(const KArgs& a, bool writer, double* s_part, double* s_tot, double* s_best, int* s_besti, int* s_bestg,
+                                                 double& win_score, int& nc_out, RecordInputs& rec_in) {
+    constexpr int B = REFINE_B;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const double sc = t < a.N ? a.scores[t] : -INFINITY;
+    double m = sc;  // fmax ignores NaN, as k_stats_exact
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if (lane == 0) s_best[wave] = m;
+    __syncthreads();
+    m = fmax(fmax(s_best[0], s_best[1]), fmax(s_best[2], s_best[3]));
+    double acc[2] = {0, 0};
+    if (t < a.N) {
+        const double d = sc - m;
+        const double ex = exp(d);
+        acc[0] = ex;
+        acc[1] = ex * d;
+    }
+    block_sum<2, B>(acc, s_part, s_tot);
+    const double entropy = log2(acc[0]) - acc[1] / (acc[0] * 0.6931471805599453);  // -sum p log2 p, p = exp(d) / S
+    nc_out = a.N;
+    if (writer && t == 0) {
+        a.n_contenders[0] = a.N;
+        a.stats[0] = m;
+        a.stats[1] = acc[0];
+        a.stats[2] = entropy;
+    }
+    double bs = t < a.N ? sc : -INFINITY;
+    int bi = t < a.N && sc > -INFINITY ? t : 0x7fffffff, bg = bi == 0x7fffffff ? 0x7fffffff : global_hyp(a, t);
+    if (!(bs > -INFINITY)) {  // NaN or -inf: never the maximum (refine_pick_winner: `s > bs` is false for it)
+        bs = -INFINITY;
+        bi = bg = 0x7fffffff;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(bs, o);
+        const int oi = __shfl_xor(bi, o);
+        const int og = __shfl_xor(bg, o);
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        s_best[wave] = bs;
+        s_besti[wave] = bi;
+        s_bestg[wave] = bg;
+    }
+    __syncthreads();
+    bs = s_best[0];
+    bi = s_besti[0];
+    bg = s_bestg[0];
+#pragma unroll
+    for (int w = 1; w < B / 64; w++) {
+        const double os = s_best[w];
+        const int oi = s_besti[w];
+        const int og = s_bestg[w];
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    const int win = bi == 0x7fffffff ? 0 : bi;
+    win_score = a.scores[win];
+    rec_in = RecordInputs{exp(win_score - m) / acc[0], entropy, a.status[0]};
+    return win;
+}
+
 // TEAM_SLOTS (training path, esac.cpp:328-347): one team of 8 per selection slot.  Blocks come in groups of 64 = 8 teams, one
 // per XCD: block L is member (L % 64) / 8 of the team on XCD L % 8 of group L / 64, which refines slot (L / 64) * 8 + L % 8.
 // Every block of such a launch is a member; teams of slots beyond n_sel leave at once.  No winner pick, no selection, no
@@ -538,6 +613,9 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     if (SLOTS) {
         win = a.bwd.sel[slot];
         __syncthreads();  // (s_pow10, s_coop_dead)
+    } else if (a.fold_select == 2) {
+        __syncthreads();  // (s_pow10, s_coop_dead)
+        win = team_select_exact(a, writer, s_part, s_tot, s_best, s_besti, s_bestg, win_score, nc, rec_in);
     } else if (a.fold_select) {
         __syncthreads();  // (s_pow10, s_coop_dead)
         team_collect<1>(census, co, s_tot, s_x);
@@ -554,7 +632,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
     if (a.E != 1) load_cells(a.sc + (size_t)e * 3 * P);
-    if (SLOTS || !a.fold_select) team_collect<1>(census, co, s_tot, s_x);
+    if (SLOTS || a.fold_select != 1) team_collect<1>(census, co, s_tot, s_x);
     CYC_END(1);
 
     // ---- refineHyp (esac_util.h:378-454) around ONE pass site
@@ -709,6 +787,11 @@ unsigned long long launch_refine_slots_team(KArgs& a, hipStream_t s) {
 // default score route (ESAC_FLAG_EXACT_SCORES has statistics of its own), no device-side span stamps to reduce.
 bool refine_folds_select(const KArgs& a) {
     return refine_team_members(a) > 0 && a.N <= REFINE_B && !(a.flags & ESAC_FLAG_EXACT_SCORES_K) && !a.tstamps;
+}
+// ESAC_FLAG_EXACT_SCORES: the scores are final when the refinement starts; their softmax statistics and argmax are a few
+// reductions over <= 256 values -- in the team kernel's prologue instead of a launch of their own (k_stats_exact)
+bool refine_folds_exact_stats(const KArgs& a) {
+    return refine_team_members(a) > 0 && a.N <= REFINE_B && (a.flags & ESAC_FLAG_EXACT_SCORES_K) != 0;
 }
 
 unsigned long long launch_refine_team(const KArgs& a, hipStream_t s) {

@@ -21,6 +21,8 @@ range (every rank needs every map); `policy="expert"` (expert e on rank e % worl
 comparison -- it does not balance (cfg4 on 4 ranks: 3992 of 4096 hypotheses on one rank).  The payload is (N_total + 32*world) * 8 bytes
 (<= 133 KB at N = 16384, 8 ranks): latency-bound, xGMI bandwidth is irrelevant.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -88,14 +90,14 @@ def pack_local(scores_local, record_local, n_total, global_index, rank, world):
     return buf
 
 
-def pick_global(buf, n_total, world, engine=None):
+def pick_global(buf, n_total, world, engine=None, zero=None):
     """(scores_global [n_total], winning record [32]) from the all-reduced buffer.  With a device buffer and an engine
-    the pick runs on the device (esac_hip_pick_record: one launch, the record lands in pinned host memory); a CPU
-    buffer (gloo tests) is scanned on the host."""
+    the pick runs on the device (esac_hip_pick_record: one launch, the record lands in pinned host memory; the same launch
+    clears `zero`, the exchange buffer of the next call); a CPU buffer (gloo tests) is scanned on the host."""
     scores = buf[:n_total]
     if engine is not None and buf.is_cuda:
         try:
-            return scores, engine.pick_record(buf[n_total:], world)
+            return scores, engine.pick_record(buf[n_total:], world, zero=zero)
         except RuntimeError as exc:
             if "no rank produced" in str(exc):
                 raise RuntimeError("esac: no rank produced a hypothesis")
@@ -116,8 +118,34 @@ def pick_global(buf, n_total, world, engine=None):
 _buffers = {}
 
 
+class _Exchange:
+    """The all-reduce payload of one (device, N, world): TWO persistent buffers that alternate call by call.  A rank's kernels
+    write only its own slots, the all-reduce then fills every slot -- so a buffer must be all-zero outside the rank's slots
+    when a call starts.  Instead of a memset in front of every call, the winner-pick launch that ends call i clears the
+    buffer call i + 1 will use (esac_hip_pick_record's d_zero): a call is the forward launches, the collective and the pick,
+    nothing else.  (The score view returned by call i therefore also survives call i + 1.)"""
+
+    def __init__(self, dev, n_total, world):
+        self.bufs = [torch.zeros(n_total + world * RES_DOUBLES, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.turn = 0
+
+    def take(self):
+        """(this call's buffer, the next call's buffer)"""
+        cur, nxt = self.bufs[self.turn], self.bufs[self.turn ^ 1]
+        self.turn ^= 1
+        return cur, nxt
+
+
+def _exchange(dev, n_total, world):
+    key = ("pair", str(dev), n_total, world)
+    ex = _buffers.get(key)
+    if ex is None:
+        ex = _buffers[key] = _Exchange(dev, n_total, world)
+    return ex
+
+
 def _exchange_buffer(dev, n_total, world):
-    """Persistent all-reduce payload per (device, N, world): no allocation on the per-frame path."""
+    """One persistent all-reduce payload per (device, N, world) for the index-list policies (zeroed by the caller per call)."""
     key = (str(dev), n_total, world)
     buf = _buffers.get(key)
     if buf is None:
@@ -146,13 +174,16 @@ def _shard_params(engine, E, H, W, n, lo, params_kw):
     return p
 
 
-def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, world, buf):
-    """Rank `rank`'s part of the exchange for contiguous-range sharding: zero `buf`, run the forward path on
-    hypotheses [lo, hi) with the kernels writing scores and record into this rank's slots of `buf`."""
+def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, world, buf, zero=True, want_host=False):
+    """Rank `rank`'s part of the exchange for contiguous-range sharding: run the forward path on hypotheses [lo, hi) with
+    the kernels writing scores and record into this rank's slots of `buf` (zeroed first unless the caller knows it is:
+    forward_sharded's alternating pair).  want_host: also hand the rank's own record back (a blocking call)."""
     n_total = int(hyp_assign_full.shape[0])
     E, _, H, W = scene_coords.shape
     lo, hi = shard_range(n_total, rank, world)
-    buf.zero_()
+    if zero:
+        buf.zero_()
+    rec = None
     if hi > lo:
         dev = engine.device
         ha_dev = hyp_assign_full if hyp_assign_full.is_cuda else hyp_assign_full.to(dev)
@@ -162,9 +193,9 @@ def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, wor
         rec0 = n_total + rank * RES_DOUBLES
         # the refinement kernel writes the record itself, incl. the "this rank contributed" marker in its last slot
         # (ESAC_RES_VALID, the convention pack_local follows for the index-list path)
-        engine.forward_device(scene_coords, ha_dev[lo:hi], p, scores_out=buf[lo:hi], result_out=buf[rec0:rec0 + RES_DOUBLES],
-                              want_host=False)
-    return buf
+        rec = engine.forward_device(scene_coords, ha_dev[lo:hi], p, scores_out=buf[lo:hi], result_out=buf[rec0:rec0 + RES_DOUBLES],
+                                    want_host=want_host)
+    return (buf, rec) if want_host else buf
 
 
 def _all_reduce_sum(buf, group, timers=None):
@@ -175,12 +206,15 @@ def _all_reduce_sum(buf, group, timers=None):
     if timers is not None and buf.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
+    t_host = time.perf_counter() if timers is not None else 0.0
     if buf.is_cuda and dist.get_backend(group) == "gloo":
         host = buf.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         buf.copy_(host)
     else:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if timers is not None:
+        timers.append(("allreduce_host_ms", (time.perf_counter() - t_host) * 1e3))  # the host's time inside the call (enqueue)
     if ev is not None:
         ev[1].record()
         timers.append(("allreduce", ev))
@@ -214,11 +248,21 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
     E, _, H, W = scene_coords.shape
     dev = engine.device
     if policy == "range":
-        # the returned score vector is a view of the persistent buffer: valid until the next call on this device
-        buf = contribute_range(engine, scene_coords, ha_full, params_kw, rank, world, _exchange_buffer(dev, n_total, world))
-        if dist.is_initialized():  # (also in a one-rank group: the collective's dtype / stream path is then the one N ranks take)
+        # the returned score vector is a view of a persistent buffer: valid until the call after the next on this device
+        buf, nxt = _exchange(dev, n_total, world).take()
+        if world == 1:
+            # one rank: its record IS the winner -- the refinement kernel hands it to the host itself (no pick launch, no second
+            # wait); the collective still runs (a one-rank RCCL all-reduce on the launch stream: the dtype / stream path N ranks take)
+            _, rec = contribute_range(engine, scene_coords, ha_full, params_kw, 0, 1, buf, zero=False, want_host=True)
+            if dist.is_initialized():
+                _all_reduce_sum(buf, group, timers)
+            if rec is None:
+                raise RuntimeError("esac: no rank produced a hypothesis")
+            return buf[:n_total], rec
+        contribute_range(engine, scene_coords, ha_full, params_kw, rank, world, buf, zero=False)
+        if dist.is_initialized():
             _all_reduce_sum(buf, group, timers)  # the one collective of this path
-        return pick_global(buf, n_total, world, engine)
+        return pick_global(buf, n_total, world, engine, zero=nxt)
     if policy == "balanced":
         return _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, group, maps, timers)
     if policy != "expert":
@@ -264,16 +308,20 @@ _balanced_ws = {}
 
 def _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, group, maps, timers):
     """policy "balanced": contribute_balanced, one all-reduce, device-side pick."""
-    buf = contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps, timers)
+    n_total = int(ha_full.shape[0])
+    buf, nxt = _exchange(engine.device, n_total, world).take()
+    contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps, timers, buf=buf)
     if dist.is_initialized():  # (also in a one-rank group: the collective's dtype / stream path is then the one N ranks take)
         _all_reduce_sum(buf, group, timers)  # the one collective of this path
-    return pick_global(buf, int(ha_full.shape[0]), world, engine)
+    return pick_global(buf, n_total, world, engine, zero=nxt)
 
 
-def contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps="full", timers=None):
+def contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps="full", timers=None, buf=None):
     """Rank `rank`'s part of the exchange under policy "balanced": device-built shard (one launch), forward launches
-    writing scores by GLOBAL index and the record into this rank's slot of the persistent exchange buffer (returned).
-    Per frame: a memset, the shard kernel, the forward chain -- no host round trip, no allocation, no scatter.
+    writing scores by GLOBAL index and the record into this rank's slot of the exchange buffer (returned).
+    Per frame: the shard kernel and the forward chain -- no host round trip, no allocation, no scatter; `buf`: a buffer the
+    caller knows to be zero outside this rank's slots (forward_sharded's alternating pair), else a persistent one that is
+    cleared here first.
     maps="owned": `scene_coords` holds only the maps of this rank's expert range [first, last] =
     params_kw["expert_range"] (plan_balanced on the histogram), `total_experts` = E."""
     dev = engine.device
@@ -302,8 +350,9 @@ def contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts,
         ws = _balanced_ws[key] = (torch.empty(max(n_local, 1), dtype=torch.int32, device=dev),
                                  torch.empty(max(n_local, 1), dtype=torch.int64, device=dev),
                                  torch.empty(4, dtype=torch.int32, device=dev))
-    buf = _exchange_buffer(dev, n_total, world)
-    buf.zero_()
+    if buf is None:
+        buf = _exchange_buffer(dev, n_total, world)
+        buf.zero_()
     if n_local > 0:
         ev = None
         if timers is not None:

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESAC_HIP_ABI_VERSION 4
+#define ESAC_HIP_ABI_VERSION 5
 
 /* reference compile-time constants (esac.cpp:44-45) */
 #define ESAC_MAX_SAMPLING_TRIES 1000000
@@ -92,6 +92,15 @@ typedef struct esac_hip_params {
 /* d_scores_out is indexed by GLOBAL hypothesis index (d_hyp_index[i], or hyp_offset + i) instead of by local position:
  * a multi-GPU shard writes its scores straight into its slots of the exchange buffer. */
 #define ESAC_FLAG_SCORES_BY_INDEX 32
+/* Take the two guaranteed routes (ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING) WHERE THEY ARE FREE: a single frame of ONE
+ * expert with N * H * W <= 2^21 (BASELINE configs[0] / [1]: 64 or 256 hypotheses on the 60x80 grid).  There the exact score of
+ * every hypothesis is one ~10 us launch on the whole chip, its softmax statistics run in the refinement kernel's prologue and
+ * the sampler has no screened stage anyway: the call costs what the default route costs (bench.py: `value` runs with this flag,
+ * `value_fast` without it) and the score vector, ESAC_RES_PROB and ESAC_RES_ENTROPY are the reference's own values.  Everywhere
+ * else the flag changes nothing (several experts, many hypotheses, large maps, batches: the fp32 ranking stream + exact re-score of
+ * the contenders is several times faster there).  esac.forward() of the Python module sets it unless told otherwise. */
+#define ESAC_FLAG_AUTO_EXACT 64
+#define ESAC_AUTO_EXACT_MAX_WORK (1 << 21) /* N * H * W up to which ESAC_FLAG_AUTO_EXACT applies */
 
 #define ESAC_DEFAULT_MARGIN 1e-3f
 
@@ -203,8 +212,11 @@ int esac_hip_forward_batch(esac_hip_ctx* ctx, int B, const float* d_scene_coords
  * all-zero records for ranks without hypotheses (ESAC_RES_VALID marks real ones).  Picks the global winner -- highest
  * exact score, lowest global hypothesis index on ties (esac_util.h:519) -- on the device and delivers it to
  * h_record_out (blocking, through pinned memory).  -11: no rank contributed a record.
+ * d_zero / n_zero: optional (NULL / 0) device doubles the same launch sets to 0 -- a caller that alternates between two
+ * exchange buffers hands over the one the NEXT call will use, so that no call starts with a memset of its own.
  */
-int esac_hip_pick_record(esac_hip_ctx* ctx, const double* d_records, int world, void* stream, double* h_record_out);
+int esac_hip_pick_record(esac_hip_ctx* ctx, const double* d_records, int world, void* stream, double* h_record_out, double* d_zero,
+                         int n_zero);
 
 /*
  * Load-balanced multi-GPU shard, built on the device (new; SURVEY.md 8e: "a load-balanced assignment from the
@@ -288,6 +300,13 @@ int esac_hip_score_span_ms(esac_hip_ctx* ctx, float* mean_ms, int* launches);
  * Blocking.  out_ms[0..3]. */
 int esac_hip_time_stages(esac_hip_ctx* ctx, const float* d_scene_coords, const int64_t* d_hyp_assign,
                          const esac_hip_params* p, void* stream, int reps, float out_ms[4]);
+/* Where the HOST's time of the most recent blocking esac_hip_forward / _batch on this context went (CLOCK_MONOTONIC, always
+ * recorded: six clock reads, ~0.15 us): out_ns[0..5] = nanoseconds after entry at which the argument block was ready, the
+ * sampling / score / refinement launch calls had returned, the result record had landed in pinned memory, and the call
+ * returned; out_ns[6] = the entry time itself (absolute, for the caller's own stamps around the call); out_ns[7] unused.
+ * What remains of a step beyond the kernels' own durations -- the "host turn" -- is [1] + the gap to the first kernel's
+ * start + ([5] - [4]) + the caller's own time between calls (scripts/dev/host_turn.py puts them side by side). */
+int esac_hip_host_turn(esac_hip_ctx* ctx, double out_ns[8]);
 /* enable/disable the per-phase events (off by default: zero overhead).  enabled = k > 1 samples every k-th forward
  * call only, starting with the next one (the events themselves cost GPU time: an empty pair reads ~5 us). */
 int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);

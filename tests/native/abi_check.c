@@ -38,6 +38,7 @@ int main(int argc, char** argv) {
     int (*p_esac_hip_backward)(esac_hip_ctx*, const float*, float*, const int64_t*, const float*, float, float, float,
                                const esac_hip_params*, void*, double*);
     int (*p_esac_hip_read)(esac_hip_ctx*, int, void*, size_t);
+    int (*p_esac_hip_host_turn)(esac_hip_ctx*, double*);
     RESOLVE(esac_hip_abi_version);
     RESOLVE(esac_hip_last_error);
     RESOLVE(esac_hip_device_count);
@@ -47,6 +48,7 @@ int main(int argc, char** argv) {
     RESOLVE(esac_hip_forward_batch);
     RESOLVE(esac_hip_backward);
     RESOLVE(esac_hip_read);
+    RESOLVE(esac_hip_host_turn);
     if (p_esac_hip_abi_version() != ESAC_HIP_ABI_VERSION) return 3;
     if (sizeof(esac_hip_params) != 104) {
         fprintf(stderr, "sizeof(esac_hip_params) = %zu\n", sizeof(esac_hip_params));
@@ -121,6 +123,20 @@ int main(int argc, char** argv) {
         return 15;
     }
     printf("backward ok: expected loss %.3e over %d refined hypotheses\n", out[0], (int)out[1]);
+    if (argc > 3 && strcmp(argv[3], "time") == 0) {
+        /* where the host's time of a blocking call goes WITHOUT Python or torch in the process (scripts/dev/host_turn.py is
+         * the same split under them): mean over 300 calls */
+        double acc[6] = {0, 0, 0, 0, 0, 0}, st[8];
+        for (int i = 0; i < 340; i++) {
+            p.call = (uint64_t)(100 + i);
+            if (p_esac_hip_forward(ctx, (const float*)d_sc, (const int64_t*)d_assign, &p, NULL, NULL, NULL, res) != 0) return 17;
+            p_esac_hip_host_turn(ctx, st);
+            if (i >= 40)
+                for (int k = 0; k < 6; k++) acc[k] += st[k];
+        }
+        printf("host turn, plain C caller (us): args %.2f | launch sample %.2f | score %.2f | refine %.2f | record landed after %.2f | returned %.2f\n",
+               acc[0] / 300e3, (acc[1] - acc[0]) / 300e3, (acc[2] - acc[1]) / 300e3, (acc[3] - acc[2]) / 300e3, acc[4] / 300e3, acc[5] / 300e3);
+    }
     hipFree_(d_grad); hipFree_(d_sc); hipFree_(d_assign);
     free(sc);
     p_esac_hip_destroy(ctx);

@@ -114,6 +114,49 @@ def test_drop_in_module(oracle):
     assert esac.get_rng_state() == (1305, 6)
 
 
+@pytest.mark.parametrize("N", [64, 256])
+def test_default_route_returns_the_reference_score_tensors_at_config1_and_2(oracle, N):
+    """`esac.forward` as the reference's scripts call it (nothing set): at BASELINE configs[0] / [1] -- one expert, 64 / 256
+    hypotheses, 60x80 grid -- ESAC_FLAG_AUTO_EXACT applies, so the score vector, the winner's selection probability and the
+    entropy of the distribution are the REFERENCE'S values (esac_util.h:235-260, 461-497), not fp32-path figures; the refinement
+    team takes the softmax statistics in its prologue (no k_stats_exact launch) -- same values as the explicit flag."""
+    import esac
+    for k in range(3):
+        f = S.make_frame(20 + k)
+        ha = S.gating_assignment(f, N)
+        out_pose = torch.zeros(4, 4)
+        esac.set_exact_scores(None)  # the default
+        esac.set_seed(1305, 30 + k)
+        esac.forward(torch.from_numpy(f["coords"]), torch.from_numpy(ha), out_pose, 0, 0, f["focal"], f["ppx"], f["ppy"], 10.0, 100.0, 0.5, 100.0, 8)
+        last = esac.last_result()
+        ref = oracle.forward(f["coords"], ha, seed=1305, call=30 + k)
+        np.testing.assert_allclose(last["scores"].cpu().numpy(), ref["scores"], rtol=1e-12, atol=1e-10)
+        rec = last["result"]
+        assert int(rec[api.RES_HYP]) == ref["winner"] and int(rec[api.RES_CONTENDERS]) == N
+        assert abs(rec[api.RES_PROB] - ref["probs"][ref["winner"]]) <= 1e-10 * max(1.0, ref["probs"][ref["winner"]])
+        assert abs(rec[api.RES_ENTROPY] - ref["entropy"]) <= 1e-10 * max(1.0, abs(ref["entropy"]))
+        eng = api.engine()
+        info = eng.refine_info()
+        assert info["mode"] == "team"
+        # the explicit flag (k_stats_exact in a launch of its own when the fold is off): the same record
+        sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+        p = eng.make_params(1, 60, 80, N, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], seed=1305, call=30 + k, exact_scores=True, exact_sampling=True)
+        rec2 = eng.forward_device(sc, hat, p)
+        np.testing.assert_array_equal(rec2[:31], rec[:31])
+        # opting out: the fp32 ranking stream -- same winner and pose, fp32-path statistics
+        esac.set_exact_scores(False)
+        try:
+            esac.set_seed(1305, 30 + k)
+            pose2 = torch.zeros(4, 4)
+            esac.forward(torch.from_numpy(f["coords"]), torch.from_numpy(ha), pose2, 0, 0, f["focal"], f["ppx"], f["ppy"], 10.0, 100.0, 0.5, 100.0, 8)
+            fast = esac.last_result()["result"]
+            assert int(fast[api.RES_HYP]) == ref["winner"] and int(fast[api.RES_CONTENDERS]) < N
+            np.testing.assert_allclose(pose2.numpy(), out_pose.numpy(), rtol=0, atol=1e-6)
+            assert abs(fast[api.RES_PROB] - rec[api.RES_PROB]) <= 1e-3
+        finally:
+            esac.set_exact_scores(None)
+
+
 def test_parity_sweep_over_frame_kinds(engine, oracle):
     """96 frames of four kinds (plain, multi-expert gating, heavy noise + 50 % outliers, odd grid with a shifted crop):
     winner, accepted refinement steps, per-step inlier counts, inlier map and LM iteration count identical to the

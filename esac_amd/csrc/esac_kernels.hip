@@ -1407,7 +1407,11 @@ constexpr int ESAC_SELECT_B = 1024;  // threads of the single-frame variant (A/B
 }
 void launch_rescore_all(const KArgs& a, hipStream_t s) {
     const int grid = a.N < 4096 ? a.N : 4096;  // bulk exact scoring: 4 wavefronts per hypothesis are enough
-    hipLaunchKernelGGL(k_rescore<256>, dim3(grid, a.frames), dim3(256), 0, s, a);
+    // few hypotheses (a single frame of <= 256: the guaranteed route of the headline call): a cell is ~120 DEPENDENT fp64
+    // operations (IEEE division, sqrt, exp), and with one wavefront per SIMD every one of them waits out its 10 cycles --
+    // 16 wavefronts per hypothesis put four on every SIMD, whose chains interleave (9.8 -> 5.x us at 256 hypotheses)
+    if ((long long)a.N * a.frames <= 256) hipLaunchKernelGGL(k_rescore<1024>, dim3(grid, a.frames), dim3(1024), 0, s, a);
+    else                                  hipLaunchKernelGGL(k_rescore<256>, dim3(grid, a.frames), dim3(256), 0, s, a);
 }
 
 }  // namespace esac

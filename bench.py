@@ -210,15 +210,17 @@ def one_gpu_stage_ms(config):
     return None
 
 
-STAGE_OF = (("k_sample", "sample"), ("k_bucket", "score"), ("k_score", "score"), ("k_select", "select_rescore"),
-            ("k_refine", "refine"))
+STAGE_OF = (("k_sample", "sample"), ("k_bucket", "score"), ("k_score", "score"), ("k_rescore", "score"), ("k_select", "select_rescore"),
+            ("k_stats_exact", "select_rescore"), ("k_refine", "refine"))
 # what bounds each stage: the figures are op-count models, stated there
 OWN_BOUND = {
     "sample": "fp64 VALU issue (P3P in registers; 4.9 cycles per wave-instruction measured)",
-    "score": "fp32 VALU issue + transcendental rate (3.0 / 8.7 cycles per wave-instruction measured); HBM only feeds it",
+    "score": "fp32 VALU issue + transcendental rate (3.0 / 8.7 cycles per wave-instruction measured); HBM only feeds it "
+             "(where ESAC_FLAG_AUTO_EXACT applies -- cfg2 -- the stage is k_rescore: dependent fp64 chains, 16 wavefronts per hypothesis)",
     "select_rescore": "latency: one launch, a few fp64 re-scores",
-    "refine": "a chain of ~25 dependent rounds: fp64 latency of the serial section every lane walks (pose chain, normal equations, 6x6 solve) + one "
-              "exchange between the 8 workgroups of the team per round (single frames on 60x80-sized grids); fp64 VALU issue of ONE CU elsewhere",
+    "refine": "a chain of ~25 dependent rounds, each bound by the instruction COUNT of one wavefront per SIMD (points + 24 moments, wavefront reduction, "
+              "the LM step dealt to the lanes of a DPP row) + one exchange between the 8 workgroups of the team (an L2 hop and two LDS round trips) "
+              "(single frames and batches of <= 32 on 60x80-sized grids); fp64 VALU issue of ONE CU elsewhere",
 }
 
 

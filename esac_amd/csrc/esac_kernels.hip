@@ -824,7 +824,9 @@ __device__ __forceinline__ f32x2 soft_inlier_fast2(const PoseF& p, float fx, flo
     const f32x2 db = __builtin_elementwise_fma(splat2(py - cy), zc, -(splat2(fy) * yc));
     const f32x2 d2n = __builtin_elementwise_fma(da, da, db * db);
     const f32x2 q = __builtin_elementwise_fma(d2n, zc * zc, splat2(1e-36f));
-    const f32x2 er = d2n * f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+    // (q - q: 0, or NaN when d2n zc^2 overflowed -- a hypothesis far beyond the scene: rsq(inf) = 0 would read err = 0, a perfect
+    // inlier; the NaN ends in the clamp below like the rcp + sqrt form did.  One packed add per pair of cells.)
+    const f32x2 er = __builtin_elementwise_fma(d2n, f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)}, q - q);
     const f32x2 err = {fminf(er.x, max_reproj), fminf(er.y, max_reproj)};
     const f32x2 arg = (err - splat2(tau)) * splat2(beta_log2e);
     const f32x2 den = splat2(1.0f) + f32x2{__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};

@@ -184,7 +184,9 @@ __device__ __forceinline__ f32x2 soft_inlier_tile2(const PoseU& p, f32x2 X, f32x
     const f32x2 db = __builtin_elementwise_fma(splat2(py), zc, -vn);
     const f32x2 d2n = __builtin_elementwise_fma(da, da, db * db);
     const f32x2 q = __builtin_elementwise_fma(d2n, zc * zc, splat2(1e-36f));
-    const f32x2 er = d2n * f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)};
+    // (q - q: 0, or NaN when d2n zc^2 overflowed -- a hypothesis far beyond the scene: rsq(inf) = 0 would read err = 0, a perfect
+    // inlier; the NaN ends in the clamp below like the rcp + sqrt form did.  One packed add per pair of cells.)
+    const f32x2 er = __builtin_elementwise_fma(d2n, f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)}, q - q);
     const f32x2 err = {fminf(er.x, kmax), fminf(er.y, kmax)};
     const f32x2 ex = {__builtin_amdgcn_exp2f(NEG ? -err.x : err.x), __builtin_amdgcn_exp2f(NEG ? -err.y : err.y)};
     const f32x2 den = __builtin_elementwise_fma(ex, splat2(c0), splat2(1.0f));

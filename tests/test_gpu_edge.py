@@ -94,6 +94,30 @@ def test_tie_goes_to_first_index(engine):
     assert int(res[api.RES_CONTENDERS]) >= N - 7
 
 
+@pytest.mark.parametrize("shape", ["stream", "tiled"])
+def test_fast_score_of_a_hypothesis_far_beyond_the_scene(engine, shape):
+    """The fp32 ranking stream forms err = d2n * rsq(d2n * zc^2): for a hypothesis whose camera sits ~1e10 m from the scene the
+    product overflows fp32, rsq(inf) = 0, and every cell would read err = 0 -- a perfect inlier, the maximal score, for the
+    worst hypothesis of the set.  It must read the clamped error maxReproj instead (score ~ 0), in both score shapes."""
+    f = S.make_frame(35)
+    N = 64
+    ha = S.gating_assignment(f, N)
+    sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+    p = engine.make_params(1, 60, 80, N, score_shape=shape)
+    engine.forward_device(sc, hat, p)
+    hyps = engine.read(api.BUF_HYPS)
+    good = float(np.max(engine.read(api.BUF_SCORES)))
+    far = hyps.copy()
+    far[5, 3:] = [1.0e9, -2.0e9, 1.0e10]   # zc ~ 1e10, d2n ~ (300 zc)^2: d2n zc^2 ~ 1e45
+    far[9, 3:] = [0.0, 0.0, -3.0e10]
+    engine.write_hyps(far)
+    engine.score(sc, hat, p)
+    engine.select(sc, hat, p)
+    scores = engine.read(api.BUF_SCORES)
+    assert scores[5] < 1e-3 * good and scores[9] < 1e-3 * good, (scores[5], scores[9], good)
+    assert int(np.argmax(scores)) not in (5, 9)
+
+
 def test_cpu_tensors_strides_and_expand(oracle):
     """Drop-in call with CPU tensors, a non-contiguous coordinate tensor and the stride-0 expand()
     assignment of --expertselection (test_esac.py:171-173)."""

@@ -418,8 +418,8 @@ def main():
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
         sock.close()
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
         try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
             def step_sharded(i, timers=None):
                 return D.forward_sharded(eng, d_coords[i % n_frames], d_assign[i % n_frames],
                                          dict(seed=BENCH_SEED, call=i, exact_scores="auto", **kw), policy="range", timers=timers)[1]
@@ -447,8 +447,11 @@ def main():
                                 "N + 32 doubles runs on the launch stream; no memset (two buffers alternate, the pick of call i clears the buffer of "
                                 "call i + 1 when there are several ranks).  overhead_us = what the call adds to the plain one: the host's time "
                                 "inside dist.all_reduce + Python glue (the collective's GPU time overlaps the next call's launch)"}
+        except Exception as exc:  # an extra leg must never break the contract line
+            sharded1 = {"error": "%s: %s" % (type(exc).__name__, exc)}
         finally:
-            dist.destroy_process_group()
+            if dist.is_initialized():
+                dist.destroy_process_group()
     def _mean_ms(name):
         v = [ev[0].elapsed_time(ev[1]) for n, ev in ar_timers if n == name]
         return float(np.mean(v)) if v else None

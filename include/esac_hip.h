@@ -149,15 +149,16 @@ enum {
     ESAC_BUF_BWD_PATH2 = 18,       /* double[k,3,H,W] the same for path II; k = bytes / (3*H*W*8) <= #slots     */
     ESAC_BUF_BWD_TEAM_INFO = 20,   /* int32[4] training path: [0] 1 when the slots of the most recent esac_hip_backward were refined by
                                       teams of 8 workgroups (one XCD each) instead of one workgroup per slot -- blocking calls
-                                      whose predecessor selected <= 32 hypotheses, grids of 1024..8192 cells; [1] such calls so
+                                      that THEMSELVES select <= 32 hypotheses (decided on the device), grids of 1024..8192 cells; [1] calls that issued the team launch so
                                       far; [2] of them, calls in which a team timed out and the slots were refined again by one
                                       workgroup each (teams stay off on this context afterwards); [3] slots of the last call */
     ESAC_BUF_REFINE_INFO = 19      /* int32[8] how the most recent winner refinement ran (refineHyp, esac_util.h:378-454):
                                       [0] 0 one workgroup, 1 cooperating workgroups (grids beyond one LDS list), 2 a team on
                                       one XCD (small grids); [1] workgroups sharing it; [2] XCD census of a team: byte x = members
                                       that ran on XCD x, x = 0..3, [7] the same for XCDs 4..7; [3] 1 when all members shared one
-                                      XCD; [4] exchanges between them; [5] 1 when an exchange timed out; [6] blocking calls on this
-                                      context so far whose team timed out and were refined again by one workgroup               */
+                                      XCD; [4] exchanges between them; [5] 1 when an exchange timed out; [6] bits 0..29: blocking calls on this
+                                      context so far whose team timed out and were refined again by one workgroup, bit 30: the
+                                      context has stopped asking for teams (two time-outs in a row; esac_hip_set_refine_team)   */
 };
 
 /* Hypotheses that take part in the training expectation: selection probability >= PROB_THRESH = 0.001
@@ -328,7 +329,14 @@ int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
  * them (2..ESAC_REFINE_TEAM_MAX = the CUs of an XCD; default ESAC_REFINE_TEAM_DEFAULT: measured 8 = 19 > 10, 12, 16 at 60x80),
  * never more than give every lane of a member one cell (ceil(H*W / 256)) and never fewer than a member's lanes can hold
  * the cells of (ceil(H*W / 1024): four per lane); 0 or 1: one workgroup refines, as on every other shape.
- * Results do not depend on the setting beyond the rounding of the LM sums (every discrete output is identical). */
+ * Results do not depend on the setting beyond the rounding of the LM sums (every discrete output is identical).
+ * esac_hip_forward_batch with up to 32 frames gives every frame's winner a team of 8 (all 32 teams are resident together);
+ * larger batches refine with one workgroup per frame.
+ * A member waits at most 1 ms (wall clock) for the others at an exchange: a team whose members do not all become resident
+ * (a shared / partitioned GPU) gives up, the blocking call refines again in ONE workgroup and returns that result; two such
+ * calls in a row and the context stops asking for teams (ESAC_BUF_REFINE_INFO[6] bit 30) -- every call would pay the wait
+ * first -- until 1000 further calls have passed or this function is called again (it re-arms the training path's slot
+ * teams too). */
 #define ESAC_REFINE_TEAM_MAX 32
 #define ESAC_REFINE_TEAM_DEFAULT 8
 int esac_hip_set_refine_team(esac_hip_ctx* ctx, int members);

@@ -343,7 +343,10 @@ def main():
     gpu_poses = {}
     sync()
     t0 = time.perf_counter()
+    trace = [] if os.environ.get("ESAC_BENCH_TRACE") else None
     for i in range(steps):  # the timed region: EXACTLY the K steps, nothing else
+        if trace is not None:
+            trace.append(time.perf_counter())
         r = step(warmup + i)
         lm_iters += r[api.RES_LM_ITERS]
         ref_steps += r[api.RES_REF_STEPS]
@@ -351,6 +354,9 @@ def main():
             gpu_poses[(warmup + i) % n_frames] = (r[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4).copy(), int(r[api.RES_HYP]), warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
+    if trace is not None:
+        trace.append(time.perf_counter())
+        sys.stderr.write("step durations (us): " + " ".join("%.1f" % ((b - a) * 1e6) for a, b in zip(trace[:-1], trace[1:])) + "\n")
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)

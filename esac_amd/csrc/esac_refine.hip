@@ -373,7 +373,7 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
     for (int k = 0; k < 6; k++) param[k] = prev[k] = pose[k];
     double U21[21], g6[6];    // normal equations at `prev` (state CALC_J)
     double U21t[21], g6t[6];  // ... at the point just evaluated
-    double prev_err2 = 0;  // |err|^2 at `prev`: CvLevMarq's norms are compared on their squares (refine_common.hpp: norm_greater)
+    double prev_err2 = 0;  // |err|^2 at `prev`: CvLevMarq's norms are compared on their squares (refine_common.hpp: trial_rejected)
     int lambda_lg10 = -3, iters = 0;
     bool have_base = false;
     for (;;) {
@@ -386,19 +386,25 @@ __device__ __forceinline__ int lm_refit(ListPtr list, int n, double pose[6], con
         if (!have_base) {
             have_base = true;  // iters == 0: prevErrNorm = |err(initial pose)|
             accept = true;
-        } else if (norm_greater(err2, prev_err2) && ++lambda_lg10 <= 16) {
-            accept = false;  // state CHECK_ERR failed: retry from `prev` with a larger lambda
         } else {
-            lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
+            // does this trial, if accepted, end the re-fit?  (a function of the step alone: iteration 20, or
+            // cvNorm(param, prevParam, CV_RELATIVE_L2) < eps) -- such a trial is not sent up the lambda ladder over a
+            // last-bit difference of the two error norms (refine_common.hpp: trial_rejected)
             double dn = 0, pn = 0;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
                 dn += (param[k] - prev[k]) * (param[k] - prev[k]);
                 pn += prev[k] * prev[k];
             }
-            ++iters;
-            if (iters >= 20 || relative_step_below_eps(dn, pn)) break;  // cvNorm(param, prevParam, CV_RELATIVE_L2) < eps
-            accept = true;
+            const bool would_end = iters + 1 >= 20 || relative_step_below_eps(dn, pn);
+            if (trial_rejected(err2, prev_err2, would_end) && ++lambda_lg10 <= 16) {
+                accept = false;  // state CHECK_ERR failed: retry from `prev` with a larger lambda
+            } else {
+                lambda_lg10 = lambda_lg10 - 1 > -16 ? lambda_lg10 - 1 : -16;
+                ++iters;
+                if (would_end) break;
+                accept = true;
+            }
         }
         if (accept) {  // state CALC_J at the accepted point
             prev_err2 = err2;

@@ -234,7 +234,9 @@ __device__ __forceinline__ bool team_step(bool fresh, const LaneConst& lc, const
     CYC_END(7);
     CYC_BEGIN();
     double dx[6];
+    if (!fresh) CYC_ADD(17, 1);  // (profiling build: rejected trials ...
     if (!lm_lane_solve<double>(c, dg, lc.hot, lambda, dx)) {
+        CYC_ADD(18, 1);          // ... and pseudo-inverse steps of the frame)
         double U21[21], g6[6];
         lm_lane_to_u21<double>(c, U21, g6);
         lm_solve6_pinv(U21, g6, lambda, dx, s_part);
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         if (co.dead) break;  // an exchange timed out: the sums are garbage, the call reports it
         CYC_BEGIN();
         bool fresh = true;  // normal equations from this pass (else: state CHECK_ERR failed, retry from `prev` with a larger lambda)
-        if (in_refit && norm_greater(sums[0], prev_err2) && ++lambda_lg10 <= 16) {
+        if (in_refit && trial_rejected(sums[0], prev_err2, ends_refit) && ++lambda_lg10 <= 16) {
             fresh = false;
         } else {
             if (in_refit) {

@@ -96,7 +96,8 @@ constexpr int LM_NP = 2;              // correspondences per lane in flight in a
 
 // Section cycle counters (clock64 = shader clock), enabled with -DESAC_PROFILE_CYCLES; index:
 // 0 total, 1 argmax, 2 error image + compaction, 3 pose2trans + result record, 4 rodrigues+chain, 5 point loop, 6 block_sum,
-// 7 transform, 8 solve, 9 number of passes, 10-15 error-pass sub-sections, 16 LM accept / reject / termination logic
+// 7 transform, 8 solve, 9 number of passes, 10-15 error-pass sub-sections, 16 LM accept / reject / termination logic,
+// 17 rejected LM trials, 18 pseudo-inverse steps (team kernel: counts, not cycles)
 #ifdef ESAC_PROFILE_CYCLES
 #define CYC_DECL long long cyc_t0_
 #define CYC_BEGIN() cyc_t0_ = clock64()
@@ -138,16 +139,26 @@ __device__ __forceinline__ double pow10_int(int k) {
     return k < 0 ? 1.0 / r : r;
 }
 
-// sqrt(a) > sqrt(b) -- CvLevMarq compares error NORMS -- without the square roots unless a and b are a few ulp apart
-// (a double-precision square root is ~40 dependent instructions on the serial section of every pass).  sqrt is monotone
-// and correctly rounded: a <= b (or a NaN) can never give a larger root, and a relative gap of 8 eps separates the roots
-// by more than their rounding.
-__device__ __forceinline__ bool norm_greater(double a, double b) {
-    if (!(a > b)) return false;
-    if (a > b * (1.0 + 8.0 * DBL_EPSILON)) return true;
+// CvLevMarq's CHECK_ERR: is the trial's error norm larger than the one at the last accepted point (then the trial is rejected
+// and repeated with 10 x lambda)?  sqrt(err2) > sqrt(prev2), decided without the square roots unless the two are a few ulp
+// apart (a double-precision square root is ~40 dependent instructions on the serial section of every pass; sqrt is monotone
+// and correctly rounded: err2 <= prev2 (or a NaN) can never give a larger root, and a relative gap of 8 eps separates the
+// roots by more than their rounding).
+// A trial that ENDS its re-fit if accepted (iteration 20, or a relative step below FLT_EPSILON: the re-fit has converged) is
+// treated differently inside that band.  There the two error norms agree to a few ulp and `>` is decided by the last bit of two sums
+// of thousands of terms -- a coin the reference's arithmetic and this one's do not share.  A rejection sends CvLevMarq up
+// the lambda ladder (x10 a round) until the step has shrunk below the noise: up to 14 more rounds (35 us of the headline
+// call, measured: scripts/dev/call8_probe.py) that end at a point within the size of that last step -- ~1e-9 rad / m -- of
+// the trial, with the same iteration count (rejected trials do not count) and the re-fit over either way.  Inside the band
+// (err <= prev (1 + 8 eps)) such a trial is therefore ACCEPTED; a clear increase is rejected as ever, and trials that do
+// not end their re-fit keep the reference's comparison (an acceptance there would change lambda's course).
+__device__ __forceinline__ bool trial_rejected(double err2, double prev2, bool ends_refit) {
+    if (!(err2 > prev2)) return false;
+    if (err2 > prev2 * (1.0 + 8.0 * DBL_EPSILON)) return true;
+    if (ends_refit) return false;
     asm volatile("; norms a few ulp apart");  // (keeps the two square roots BEHIND the branch: as plain arithmetic they are
                                               // if-converted and run on every pass, ~45 instructions)
-    return sqrt(a) > sqrt(b);
+    return sqrt(err2) > sqrt(prev2);
 }
 // cvNorm(param, prevParam, CV_RELATIVE_L2) < FLT_EPSILON, i.e. sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < eps, dn = |param - prev|^2,
 // pn = |prev|^2: decided on the squares wherever the answer is clear of the threshold by 1e-9 (relative), by the

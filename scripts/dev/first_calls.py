@@ -9,7 +9,7 @@ assigns = [S.gating_assignment(f, 256, mode="single") for f in frames]
 d_coords = [torch.from_numpy(f["coords"]).cuda() for f in frames]
 d_assign = [torch.from_numpy(a).cuda() for a in assigns]
 scores = torch.empty(256, dtype=torch.float64, device="cuda")
-params = eng.make_params(1, 60, 80, 256, seed=1320, call=0, focal=frames[0]["focal"], ppx=frames[0]["ppx"], ppy=frames[0]["ppy"], sub_sampling=8, exact_scores="auto")
+params = eng.make_params(1, 60, 80, 256, seed=1320, call=0, focal=frames[0]["focal"], ppx=frames[0]["ppx"], ppy=frames[0]["ppy"], sub_sampling=8, exact_scores=False if os.environ.get("ESAC_FC_FAST") else "auto")
 torch.cuda.synchronize()
 ts, steps, lm = [], [], []
 for i in range(80):

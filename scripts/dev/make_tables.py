@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Markdown tables for DESIGN.md / BASELINE.md from the committed bench lines and kernel profiles of a round.
-python scripts/dev/make_tables.py [round, default r04] [dir, default profiles]"""
+python scripts/dev/make_tables.py [round, default r05] [dir, default profiles]"""
 import json
 import os
 import sys
 
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 d = sys.argv[2] if len(sys.argv) > 2 else "profiles"
 
 
@@ -39,6 +39,12 @@ for name, label in (("cfg2", "cfg2: 1 expert, 256 hyp, 60×80 (`value`, 400 step
         extra.append("seed 1305: %.3f M" % (b["value_seed1305"] / 1e6))
     if b.get("value_exact"):
         extra.append("exact routes: %.3f M (%.4f ms)" % (b["value_exact"]["value"] / 1e6, b["value_exact"]["ms_per_step"]))
+    if b.get("value_fast"):
+        extra.append("fp32 ranking route: %.3f M (%.4f ms)" % (b["value_fast"]["value"] / 1e6, b["value_fast"]["ms_per_step"]))
+    if b.get("sharded_world1") and b["sharded_world1"].get("ms_per_step"):
+        sw = b["sharded_world1"]
+        extra.append("sharded call path at world 1: %.4f ms (+%.1f us over the plain call; all-reduce %.1f us on the GPU, %.1f us of host time in the call)" % (
+            sw["ms_per_step"], sw["overhead_us"], (sw.get("allreduce_gpu_ms") or 0) * 1e3, (sw.get("allreduce_host_call_ms") or 0) * 1e3))
     if b.get("batched"):
         extra.append("batched %d frames: %.1f M" % (b["batched"]["frames_per_launch"], b["batched"]["value"] / 1e6))
     if b.get("training"):
@@ -51,7 +57,7 @@ for name, label in (("cfg2", "cfg2: 1 expert, 256 hyp, 60×80 (`value`, 400 step
     rows.append("%s roofline: bound %s achieved %.4g %s frac %.3f; hbm_nominal %s; traffic %s; valu frac %s; issue-bound frac %s; stale %s" % (
         name, str(rf.get("bound"))[:24], rf.get("achieved", 0), rf.get("unit"), rf.get("frac", 0), (rf.get("hbm_nominal") or {}).get("frac"),
         rf.get("traffic"), (rf.get("valu") or {}).get("frac"), (rf.get("valu") or {}).get("frac_of_issue_bound_rocprofv3"), b.get("profile_stale")))
-for b in ("batch16", "batch256"):
+for b in ("batch16", "batch32", "batch256"):
     x = load(b)
     if x and x.get("batched"):
         rows.append("%s — %d frames per launch: %.1f M hypotheses/s" % (b, x["batched"]["frames_per_launch"], x["batched"]["value"] / 1e6))

@@ -474,11 +474,10 @@ def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLengt
     eng = engine(dev)
     E, _, H, W = sceneCoordinates.shape
     N = hypAssignment.shape[0]
-    ha_host_check = hypAssignment if not hypAssignment.is_cuda else None
-    if ha_host_check is not None:
-        lo, hi = int(ha_host_check.min()), int(ha_host_check.max())
-        if lo < 0 or hi >= E:
-            raise RuntimeError("esac.forward: hypAssignment values must lie in [0,%d), found [%d,%d]" % (E, lo, hi))
+    if not hypAssignment.is_cuda:
+        lo, hi = torch.aminmax(hypAssignment)
+        if int(lo) < 0 or int(hi) >= E:
+            raise RuntimeError("esac.forward: hypAssignment values must lie in [0,%d), found [%d,%d]" % (E, int(lo), int(hi)))
     # parameter block and score buffer are kept per SHAPE; the scalar fields are rewritten per call (a per-frame focal
     # length -- Aachen, Dubrovnik -- must not evict anything)
     key = (eng.device.index, E, H, W, N)
@@ -486,9 +485,34 @@ def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLengt
     if cached is None:
         if len(_state["fwd_cache"]) > 16:
             _state["fwd_cache"].clear()
-        cached = (eng.make_params(E, H, W, N), torch.empty(N, dtype=torch.float64, device=eng.device))
+        cached = [eng.make_params(E, H, W, N), torch.empty(N, dtype=torch.float64, device=eng.device), None]
         _state["fwd_cache"][key] = cached
-    p, scores = cached
+    p, scores = cached[0], cached[1]
+    if not sceneCoordinates.is_cuda or not hypAssignment.is_cuda:
+        # the reference's convention (test_esac.py:187 `.cpu()`): CPU tensors in.  They go through PINNED staging buffers kept per
+        # shape -- one host copy (which also resolves strides and the stride-0 expand() of --expertselection) and an asynchronous
+        # H2D on the launch stream, instead of a pageable-memory transfer and a device allocation per call.  The call is
+        # blocking, so the buffers are free again when it returns.
+        if cached[2] is None:
+            cached[2] = (torch.empty((E, 3, H, W), dtype=torch.float32, pin_memory=True), torch.empty((E, 3, H, W), dtype=torch.float32, device=eng.device),
+                         torch.empty(N, dtype=torch.int64, pin_memory=True), torch.empty(N, dtype=torch.int64, device=eng.device), None)
+        pin_sc, dev_sc, pin_ha, dev_ha = cached[2][:4]
+        with torch.cuda.device(eng.device):
+            if not sceneCoordinates.is_cuda:
+                pin_sc.copy_(sceneCoordinates)
+                dev_sc.copy_(pin_sc, non_blocking=True)
+                sceneCoordinates = dev_sc
+            if not hypAssignment.is_cuda:
+                if E == 1:
+                    # one expert: the kernels never read the assignment vector (device_common.hpp:expert_of), and the host check
+                    # above has seen that it holds nothing but zeros -- no transfer
+                    if cached[2][4] is None:
+                        cached[2] = cached[2][:4] + (torch.zeros(N, dtype=torch.int64, device=eng.device),)
+                    hypAssignment = cached[2][4]
+                else:
+                    pin_ha.copy_(hypAssignment)
+                    dev_ha.copy_(pin_ha, non_blocking=True)
+                    hypAssignment = dev_ha
     p.shift_x, p.shift_y = int(shiftX), int(shiftY)
     p.focal, p.ppx, p.ppy = float(focalLength), float(ppointX), float(ppointY)
     p.inlier_thresh, p.inlier_alpha, p.inlier_beta = float(inlierThreshold), float(inlierAlpha), float(inlierBeta)
@@ -500,8 +524,11 @@ def forward(sceneCoordinates, hypAssignment, outPose, shiftX, shiftY, focalLengt
     eng._shape = (int(N), int(H), int(W))
     _state["call"] += 1
     res = eng.forward_device(sceneCoordinates, hypAssignment, p, scores_out=scores)
-    pose = torch.from_numpy(res[RES_POSE:RES_POSE + 16].astype(np.float32).reshape(4, 4))
-    outPose.copy_(pose)  # in place, caller-owned (esac.cpp:184-187)
+    # in place, caller-owned (esac.cpp:184-187)
+    if not outPose.is_cuda and outPose.is_contiguous():
+        outPose.numpy()[:] = res[RES_POSE:RES_POSE + 16].reshape(4, 4)
+    else:
+        outPose.copy_(torch.from_numpy(res[RES_POSE:RES_POSE + 16].astype(np.float32).reshape(4, 4)))
     _state["last"] = {"scores": scores, "result": res, "winner": int(res[RES_HYP]), "expert": int(res[RES_EXPERT])}
     return int(res[RES_EXPERT])
 

@@ -41,7 +41,9 @@ ABI_SYMBOLS = [
     "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug", "esac_hip_check",
     "esac_hip_pick_record", "esac_hip_time_stages", "esac_hip_shard_balanced", "esac_hip_set_wait",
     "esac_hip_set_refine_team", "esac_hip_host_turn",
+    "esac_hip_comm_unique_id", "esac_hip_comm_init", "esac_hip_comm_destroy", "esac_hip_allreduce_sum",
 ]
+COMM_ID_BYTES = 128
 ABI_VERSION = 5
 FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS, FLAG_EXACT_SAMPLING, FLAG_SCORES_BY_INDEX = 1, 2, 4, 8, 16, 32
 FLAG_AUTO_EXACT = 64
@@ -107,6 +109,10 @@ def load_library():
         lib.esac_hip_set_wait.argtypes = [vp, i32]
         lib.esac_hip_set_refine_team.argtypes = [vp, i32]
         lib.esac_hip_host_turn.argtypes = [vp, vp]
+        lib.esac_hip_comm_unique_id.argtypes = [vp, C.c_size_t]
+        lib.esac_hip_comm_init.argtypes = [vp, i32, i32, vp, C.c_size_t]
+        lib.esac_hip_comm_destroy.argtypes = [vp]
+        lib.esac_hip_allreduce_sum.argtypes = [vp, vp, C.c_size_t, vp]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
                 getattr(lib, name).restype = i32
@@ -140,6 +146,7 @@ class Engine:
         self._host_buf = (C.c_double * RES_DOUBLES)()  # host record of a blocking forward call
         self._host_addr = C.addressof(self._host_buf)
         self._host_np = np.frombuffer(self._host_buf, dtype=np.float64)
+        self._comm = None  # (nranks, rank) once comm_init has run
 
     def _call(self, fn, *args):
         """One C-ABI call with this engine's device current (the library calls hipSetDevice itself; the context
@@ -369,6 +376,28 @@ class Engine:
                 "same_xcd": bool(v[3]),
                 "exchanges": int(v[4]), "timed_out": bool(v[5]), "team_fallbacks": int(v[6]) & 0x3fffffff,
                 "team_latched_off": bool(int(v[6]) & 0x40000000)}
+
+    # -- the multi-GPU score exchange straight on RCCL (esac_hip_comm_*; distributed.py bootstraps the id)
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        _check(self.lib.esac_hip_comm_unique_id(buf, COMM_ID_BYTES), self.lib)
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(self.lib.esac_hip_comm_init(self.ctx, int(nranks), int(rank), buf, COMM_ID_BYTES), self.lib)
+        self._comm = (int(nranks), int(rank))
+
+    def comm_destroy(self):
+        _check(self.lib.esac_hip_comm_destroy(self.ctx), self.lib)
+        self._comm = None
+
+    def allreduce_sum(self, buf):
+        """In-place all-reduce(SUM) of a device float64 tensor over this engine's RCCL communicator, on the current stream."""
+        rc = self.lib.esac_hip_allreduce_sum(self.ctx, buf.data_ptr(), int(buf.numel()), self._stream())
+        if rc != 0:
+            _check(rc, self.lib)
 
     def host_turn(self):
         """Host-side stamps of the most recent blocking forward (esac_hip_host_turn), in microseconds after entry."""

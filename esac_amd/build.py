@@ -19,6 +19,9 @@ HEADERS = sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.hp
 # -ffp-contract=off: the fp64 "exact" kernels follow IEEE op-by-op like the CPU
 # code they are compared with; the fp32 streaming kernel asks for FMAs explicitly.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# RCCL for the multi-GPU score exchange (esac_hip_allreduce_sum).  librccl.so.1 resolves to the copy the process already holds
+# (torch's, under Python) or to ROCm's own.
+LINK = ["-L/opt/rocm/lib", "-lrccl"]
 
 
 def source_hash():
@@ -49,7 +52,7 @@ def needs_build():
 def build_hip(force=False, verbose=False):
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH + ".tmp"]
+    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + LINK + ["-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -59,7 +62,7 @@ def build_hip(force=False, verbose=False):
 
 def build_variant(out_path, extra_flags=()):
     """The same sources with extra compiler flags into another file (measurement scripts: ESAC_HIP_LIB=<out_path>)."""
-    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out_path]
+    cmd = [_hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, s) for s in SOURCES] + LINK + ["-o", out_path]
     subprocess.check_call(cmd)
     return out_path
 

@@ -5,6 +5,7 @@
 // kernel launches on the caller's stream, optional per-phase hipEvent timers
 // (the StopWatch prints of esac.cpp:124,149,161,179).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 #include <sched.h>
 #include <time.h>
 #include <stdarg.h>
@@ -101,6 +102,8 @@ struct esac_hip_ctx {
     long long tPart = 0;
     bool rt32_stale = false;  // esac_hip_write_hyps ran: the fp32 [R|t] rows are rebuilt by the next esac_hip_score
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // esac_hip_host_turn: where the host's time of the most recent blocking forward went
+    ncclComm_t comm = nullptr;  // esac_hip_comm_init: this context's rank in an RCCL communicator (the multi-GPU score exchange)
+    int comm_ranks = 0, comm_rank = 0;
 };
 
 static inline double now_ns() {
@@ -176,6 +179,7 @@ extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     free_ws(c);
     free_bws(c);
     if (c->sc4) (void)hipFree(c->sc4);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -705,6 +709,54 @@ extern "C" int esac_hip_pick_record(esac_hip_ctx* c, const double* d_records, in
     __sync_synchronize();
     memcpy(h_record_out, (const void*)c->h_pin, ESAC_RES_DOUBLES * sizeof(double));
     if (c->h_pin[33] == 2.0) return fail(-11, "esac_hip_pick_record: no rank produced a hypothesis");
+    return 0;
+}
+
+// ---- the one collective of the multi-GPU path, straight on RCCL (esac_amd/distributed.py bootstraps the id over the caller's
+// process group; the per-frame data path then never enters torch.distributed, whose enqueue of a collective costs the host
+// 20-27 us a call: bench.py sharded_world1)
+#define NCCL_OK(expr)                                                                                \
+    do {                                                                                             \
+        ncclResult_t _r = (expr);                                                                    \
+        if (_r != ncclSuccess) return fail(-300 - (int)_r, "%s: %s", #expr, ncclGetErrorString(_r)); \
+    } while (0)
+extern "C" int esac_hip_comm_unique_id(void* out, size_t bytes) {
+    if (!out || bytes < sizeof(ncclUniqueId)) return fail(-1, "esac_hip_comm_unique_id: need %zu bytes", sizeof(ncclUniqueId));
+    ncclUniqueId id;
+    NCCL_OK(ncclGetUniqueId(&id));
+    memcpy(out, &id, sizeof(id));
+    return 0;
+}
+extern "C" int esac_hip_comm_init(esac_hip_ctx* c, int nranks, int rank, const void* unique_id, size_t bytes) {
+    if (!c || !unique_id || bytes < sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(-1, "esac_hip_comm_init: bad argument");
+    DeviceGuard guard(c->device);
+    if (c->comm) {
+        (void)ncclCommDestroy(c->comm);
+        c->comm = nullptr;
+    }
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    NCCL_OK(ncclCommInitRank(&c->comm, nranks, id, rank));
+    c->comm_ranks = nranks;
+    c->comm_rank = rank;
+    return 0;
+}
+extern "C" int esac_hip_comm_destroy(esac_hip_ctx* c) {
+    if (!c) return fail(-1, "null context");
+    if (c->comm) {
+        DeviceGuard guard(c->device);
+        (void)ncclCommDestroy(c->comm);
+        c->comm = nullptr;
+        c->comm_ranks = 0;
+    }
+    return 0;
+}
+extern "C" int esac_hip_allreduce_sum(esac_hip_ctx* c, double* d_buf, size_t count, void* stream) {
+    if (!c || !d_buf) return fail(-1, "esac_hip_allreduce_sum: null argument");
+    if (!c->comm) return fail(-13, "esac_hip_allreduce_sum: no communicator (esac_hip_comm_init)");
+    DeviceGuard guard(c->device);
+    NCCL_OK(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream));
     return 0;
 }
 

@@ -198,16 +198,48 @@ def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, wor
     return (buf, rec) if want_host else buf
 
 
-def _all_reduce_sum(buf, group, timers=None):
-    """The one collective.  RCCL ("nccl") reduces the device buffer in place; a gloo group (CPU tests, or several
-    ranks sharing one GPU) gets the 1-2 KB payload staged through the host.  `timers`: optional list that receives
-    ("allreduce", (start, end)) CUDA event pairs around the collective (bench.py splits its time out of the step)."""
+_native = {"off": False}
+
+
+def native_comm(engine, group=None):
+    """This engine's rank in an RCCL communicator of the LIBRARY's own (esac_hip_comm_init), mirroring `group`: rank 0 makes the
+    unique id, one broadcast over the torch.distributed group hands it round (control plane, once), every rank joins.  From then on
+    the per-frame collective is one C call that enqueues ncclAllReduce on the launch stream -- torch.distributed's own enqueue
+    of a collective costs the host 20-27 us per call (bench.py: sharded_world1).  Only for backend "nccl" (one rank per GPU);
+    None when the group is gloo (CPU tests, several ranks sharing one GPU), when ESAC_NATIVE_RCCL=0, or when joining failed (the
+    torch.distributed all-reduce -- RCCL as well -- then carries the exchange)."""
+    import os
+    if _native["off"] or os.environ.get("ESAC_NATIVE_RCCL", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
+        return None
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if engine._comm == (world, rank):
+        return engine
+    try:
+        box = [engine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        engine.comm_init(world, rank, box[0])
+        return engine
+    except Exception as exc:  # keep the exchange alive on the torch.distributed route
+        import warnings
+        warnings.warn("esac: RCCL communicator of the library could not be set up (%s); using torch.distributed.all_reduce" % exc)
+        _native["off"] = True
+        return None
+
+
+def _all_reduce_sum(buf, group, timers=None, engine=None):
+    """The one collective: all-reduce(SUM) of the device buffer in place, over RCCL -- through the library's own communicator
+    (native_comm) when there is one, else through torch.distributed ("nccl" IS RCCL on ROCm); a gloo group (CPU tests, or
+    several ranks sharing one GPU) gets the 1-2 KB payload staged through the host.  `timers`: optional list that receives
+    ("allreduce", (start, end)) CUDA event pairs around the collective and the host's time in the call (bench.py)."""
     ev = None
     if timers is not None and buf.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     t_host = time.perf_counter() if timers is not None else 0.0
-    if buf.is_cuda and dist.get_backend(group) == "gloo":
+    nat = native_comm(engine, group) if engine is not None and buf.is_cuda else None
+    if nat is not None:
+        nat.allreduce_sum(buf)
+    elif buf.is_cuda and dist.get_backend(group) == "gloo":
         host = buf.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         buf.copy_(host)
@@ -255,13 +287,13 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
             # wait); the collective still runs (a one-rank RCCL all-reduce on the launch stream: the dtype / stream path N ranks take)
             _, rec = contribute_range(engine, scene_coords, ha_full, params_kw, 0, 1, buf, zero=False, want_host=True)
             if dist.is_initialized():
-                _all_reduce_sum(buf, group, timers)
+                _all_reduce_sum(buf, group, timers, engine)
             if rec is None:
                 raise RuntimeError("esac: no rank produced a hypothesis")
             return buf[:n_total], rec
         contribute_range(engine, scene_coords, ha_full, params_kw, rank, world, buf, zero=False)
         if dist.is_initialized():
-            _all_reduce_sum(buf, group, timers)  # the one collective of this path
+            _all_reduce_sum(buf, group, timers, engine)  # the one collective of this path
         return pick_global(buf, n_total, world, engine, zero=nxt)
     if policy == "balanced":
         return _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, group, maps, timers)
@@ -298,7 +330,7 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
         if owned:
             record[2] = record[2] * world + rank  # local map index -> global expert id (esac.cpp:189 returns it)
     if dist.is_initialized():  # (also in a one-rank group: the collective's dtype / stream path is then the one N ranks take)
-        _all_reduce_sum(buf, group, timers)  # the one collective of this path
+        _all_reduce_sum(buf, group, timers, engine)  # the one collective of this path
     return pick_global(buf, n_total, world, engine)
 
 
@@ -312,7 +344,7 @@ def _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, r
     buf, nxt = _exchange(engine.device, n_total, world).take()
     contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps, timers, buf=buf)
     if dist.is_initialized():  # (also in a one-rank group: the collective's dtype / stream path is then the one N ranks take)
-        _all_reduce_sum(buf, group, timers)  # the one collective of this path
+        _all_reduce_sum(buf, group, timers, engine)  # the one collective of this path
     return pick_global(buf, n_total, world, engine, zero=nxt)
 
 

@@ -220,6 +220,19 @@ int esac_hip_pick_record(esac_hip_ctx* ctx, const double* d_records, int world, 
                          int n_zero);
 
 /*
+ * The ONE collective of the multi-GPU path -- all-reduce(SUM) of the exchange buffer [N scores | world x 32-double records] over
+ * RCCL / xGMI -- issued by the library itself on the launch stream (new).  esac_hip_comm_unique_id: rank 0 makes an RCCL unique
+ * id (ESAC_COMM_ID_BYTES bytes) and hands it to every rank by whatever means the caller has (esac_amd/distributed.py: one
+ * broadcast over the torch.distributed process group, once); esac_hip_comm_init: every rank joins with it (collective,
+ * blocking); esac_hip_allreduce_sum: in place on `stream`, asynchronous.  -13: no communicator on this context.
+ */
+#define ESAC_COMM_ID_BYTES 128
+int esac_hip_comm_unique_id(void* out_id, size_t bytes);
+int esac_hip_comm_init(esac_hip_ctx* ctx, int nranks, int rank, const void* unique_id, size_t bytes);
+int esac_hip_comm_destroy(esac_hip_ctx* ctx);
+int esac_hip_allreduce_sum(esac_hip_ctx* ctx, double* d_buf, size_t count, void* stream);
+
+/*
  * Load-balanced multi-GPU shard, built on the device (new; SURVEY.md 8e: "a load-balanced assignment from the
  * hypAssignment histogram", test_esac.py:178).  The hypotheses are ordered by (expert, index) -- the stable counting sort
  * of d_hyp_assign [N] -- and rank r of `world` takes the sorted positions [r*N/world, (r+1)*N/world) (remainder to the

@@ -16,9 +16,15 @@ from esac_amd import synthetic as S
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("native", [True, False])
 @pytest.mark.parametrize("policy", ["range", "expert", "balanced"])
-def test_forward_sharded_world1_matches_plain(engine, policy):
+def test_forward_sharded_world1_matches_plain(engine, policy, native, monkeypatch):
+    """native: the collective is the LIBRARY's own ncclAllReduce (esac_hip_comm_init / esac_hip_allreduce_sum, id bootstrapped over
+    the torch.distributed group); else torch.distributed.all_reduce on the same RCCL."""
     import torch.distributed as dist
+    monkeypatch.setenv("ESAC_NATIVE_RCCL", "1" if native else "0")
+    if not native:
+        engine.comm_destroy()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -36,6 +42,7 @@ def test_forward_sharded_world1_matches_plain(engine, policy):
         scores_g, best = D.forward_sharded(engine, sc, hat, kw, policy=policy, timers=timers)
         # the ONE collective has run -- a one-rank RCCL all-reduce(SUM) of the real float64 exchange buffer on the launch stream
         assert [n for n, _ in timers].count("allreduce") == 1
+        assert (engine._comm == (1, 0)) == native
         p = engine.make_params(3, 60, 80, 192, **kw)
         res = engine.forward_device(sc, hat, p)
         assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]) and int(best[api.RES_EXPERT]) == int(res[api.RES_EXPERT])

@@ -214,16 +214,25 @@ def native_comm(engine, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if engine._comm == (world, rank):
         return engine
+    why = None
     try:
         box = [engine.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         engine.comm_init(world, rank, box[0])
-        return engine
     except Exception as exc:  # keep the exchange alive on the torch.distributed route
-        import warnings
-        warnings.warn("esac: RCCL communicator of the library could not be set up (%s); using torch.distributed.all_reduce" % exc)
-        _native["off"] = True
-        return None
+        why = str(exc)
+    # every rank takes the same route: one rank that could not join sends all of them to torch.distributed (once, control plane)
+    joined = torch.tensor([0 if why else 1], dtype=torch.int32, device=engine.device)
+    dist.all_reduce(joined, op=dist.ReduceOp.MIN, group=group)
+    if int(joined.item()) == 1:
+        return engine
+    import warnings
+    warnings.warn("esac: RCCL communicator of the library could not be set up on every rank (%s); using torch.distributed.all_reduce"
+                  % (why or "another rank failed"))
+    if why is None:
+        engine.comm_destroy()
+    _native["off"] = True
+    return None
 
 
 def _all_reduce_sum(buf, group, timers=None, engine=None):

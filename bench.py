@@ -448,6 +448,7 @@ def main():
                         "allreduce_gpu_ms": float(np.median(ar_gpu)) if ar_gpu else None,
                         "allreduce_host_call_ms": float(np.median(ar_host)) if ar_host else None,
                         "zero_ms": 0.0, "pick_ms": 0.0,
+                        "exchange": "esac_hip_allreduce_sum (the library's own RCCL communicator)" if eng._comm else "torch.distributed.all_reduce",
                         "note": "forward_sharded(policy='range') at world 1: the forward launches write scores and record into the exchange buffer, the "
                                 "record reaches the host from the refinement kernel itself (no pick launch at one rank), ONE RCCL all-reduce of "
                                 "N + 32 doubles runs on the launch stream; no memset (two buffers alternate, the pick of call i clears the buffer of "
@@ -456,6 +457,8 @@ def main():
         except Exception as exc:  # an extra leg must never break the contract line
             sharded1 = {"error": "%s: %s" % (type(exc).__name__, exc)}
         finally:
+            if eng._comm:
+                eng.comm_destroy()
             if dist.is_initialized():
                 dist.destroy_process_group()
     def _mean_ms(name):
@@ -510,6 +513,8 @@ def main():
             out["refine"] = eng.refine_info()  # how the winner's refinement of the last step ran (ESAC_BUF_REFINE_INFO)
         if world > 1:
             out["allreduce_ms"] = allreduce_ms
+            out["exchange"] = ("esac_hip_allreduce_sum (the library's own RCCL communicator)" if eng._comm else
+                               "torch.distributed.all_reduce (%s)" % ("gloo: ranks share one GPU" if one_device else "RCCL"))
             out["shard_build_ms"] = shard_build_ms  # esac_hip_shard_balanced, inside the timed step (policy balanced)
             # what the design predicts, so that a measured 1/2/4/8 curve can be checked against a model: the winner's
             # refinement runs on every rank (its local best), the collective and the pick are latency, only sampling + scoring

@@ -5,7 +5,8 @@
 // kernel launches on the caller's stream, optional per-phase hipEvent timers
 // (the StopWatch prints of esac.cpp:124,149,161,179).
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the entry points are bound by dlopen (rccl() below)
 #include <sched.h>
 #include <time.h>
 #include <stdarg.h>
@@ -124,6 +125,38 @@ constexpr int ESAC_SLOT_TEAMS_MAX = 32;  // training path: slots refined by team
 constexpr int ESAC_TEAM_STRIKES = 2;
 constexpr long long ESAC_TEAM_REARM_CALLS = 1000;
 
+// RCCL, bound at the first esac_hip_comm_* call (see "the one collective of the multi-GPU path" below)
+struct Rccl {
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+};
+static const Rccl& rccl() {
+    static const Rccl bound = [] {
+        Rccl r;
+        void* h = nullptr;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return r;
+        r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+        r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
+        r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+        r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(h, "ncclAllReduce"));
+        r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(h, "ncclGetErrorString"));
+        r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_reduce && r.error_string;
+        return r;
+    }();
+    return bound;
+}
+static void drop_comm(esac_hip_ctx* c) {
+    if (c->comm) (void)rccl().comm_destroy(c->comm);  // a communicator exists only if RCCL was bound
+    c->comm = nullptr;
+    c->comm_ranks = 0;
+}
+
 static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.hyps_R,      c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.samp_count, c->ws.samp_pending, c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.sel_partials, c->ws.sel_arrived, c->ws.stats,
@@ -179,7 +212,7 @@ extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     free_ws(c);
     free_bws(c);
     if (c->sc4) (void)hipFree(c->sc4);
-    if (c->comm) (void)ncclCommDestroy(c->comm);
+    drop_comm(c);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -714,49 +747,47 @@ extern "C" int esac_hip_pick_record(esac_hip_ctx* c, const double* d_records, in
 
 // ---- the one collective of the multi-GPU path, straight on RCCL (esac_amd/distributed.py bootstraps the id over the caller's
 // process group; the per-frame data path then never enters torch.distributed, whose enqueue of a collective costs the host
-// 20-27 us a call: bench.py sharded_world1)
-#define NCCL_OK(expr)                                                                                \
-    do {                                                                                             \
-        ncclResult_t _r = (expr);                                                                    \
-        if (_r != ncclSuccess) return fail(-300 - (int)_r, "%s: %s", #expr, ncclGetErrorString(_r)); \
+// 20-27 us a call: bench.py sharded_world1).  RCCL is bound at the first esac_hip_comm_* call, not at link time: a single-GPU
+// process never maps the 570 MB library, and one that already holds a copy (torch ships its own librccl.so.1) gets that copy.
+#define RCCL_BOUND() \
+    if (!rccl().ok) return fail(-14, "RCCL is not available in this process (librccl.so.1 could not be loaded)")
+#define NCCL_OK(expr)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t _r = (expr);                                                                           \
+        if (_r != ncclSuccess) return fail(-300 - (int)_r, "%s: %s", #expr, rccl().error_string(_r));       \
     } while (0)
 extern "C" int esac_hip_comm_unique_id(void* out, size_t bytes) {
     if (!out || bytes < sizeof(ncclUniqueId)) return fail(-1, "esac_hip_comm_unique_id: need %zu bytes", sizeof(ncclUniqueId));
+    RCCL_BOUND();
     ncclUniqueId id;
-    NCCL_OK(ncclGetUniqueId(&id));
+    NCCL_OK(rccl().get_unique_id(&id));
     memcpy(out, &id, sizeof(id));
     return 0;
 }
 extern "C" int esac_hip_comm_init(esac_hip_ctx* c, int nranks, int rank, const void* unique_id, size_t bytes) {
     if (!c || !unique_id || bytes < sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks)
         return fail(-1, "esac_hip_comm_init: bad argument");
+    RCCL_BOUND();
     DeviceGuard guard(c->device);
-    if (c->comm) {
-        (void)ncclCommDestroy(c->comm);
-        c->comm = nullptr;
-    }
+    drop_comm(c);
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));
-    NCCL_OK(ncclCommInitRank(&c->comm, nranks, id, rank));
+    NCCL_OK(rccl().comm_init_rank(&c->comm, nranks, id, rank));
     c->comm_ranks = nranks;
     c->comm_rank = rank;
     return 0;
 }
 extern "C" int esac_hip_comm_destroy(esac_hip_ctx* c) {
     if (!c) return fail(-1, "null context");
-    if (c->comm) {
-        DeviceGuard guard(c->device);
-        (void)ncclCommDestroy(c->comm);
-        c->comm = nullptr;
-        c->comm_ranks = 0;
-    }
+    DeviceGuard guard(c->device);
+    drop_comm(c);
     return 0;
 }
 extern "C" int esac_hip_allreduce_sum(esac_hip_ctx* c, double* d_buf, size_t count, void* stream) {
     if (!c || !d_buf) return fail(-1, "esac_hip_allreduce_sum: null argument");
     if (!c->comm) return fail(-13, "esac_hip_allreduce_sum: no communicator (esac_hip_comm_init)");
     DeviceGuard guard(c->device);
-    NCCL_OK(ncclAllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream));
+    NCCL_OK(rccl().all_reduce(d_buf, d_buf, count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream));
     return 0;
 }
 

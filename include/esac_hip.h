@@ -224,7 +224,9 @@ int esac_hip_pick_record(esac_hip_ctx* ctx, const double* d_records, int world, 
  * RCCL / xGMI -- issued by the library itself on the launch stream (new).  esac_hip_comm_unique_id: rank 0 makes an RCCL unique
  * id (ESAC_COMM_ID_BYTES bytes) and hands it to every rank by whatever means the caller has (esac_amd/distributed.py: one
  * broadcast over the torch.distributed process group, once); esac_hip_comm_init: every rank joins with it (collective,
- * blocking); esac_hip_allreduce_sum: in place on `stream`, asynchronous.  -13: no communicator on this context.
+ * blocking); esac_hip_allreduce_sum: in place on `stream`, asynchronous.  -13: no communicator on this context.  RCCL is bound
+ * when the first of these is called (dlopen of librccl.so.1: the copy the process already holds, else ROCm's), not at link time:
+ * a single-GPU process never loads it; -14: it could not be loaded.  -300 - r: RCCL returned ncclResult_t r.
  */
 #define ESAC_COMM_ID_BYTES 128
 int esac_hip_comm_unique_id(void* out_id, size_t bytes);

@@ -137,6 +137,39 @@ int main(int argc, char** argv) {
         printf("host turn, plain C caller (us): args %.2f | launch sample %.2f | score %.2f | refine %.2f | record landed after %.2f | returned %.2f\n",
                acc[0] / 300e3, (acc[1] - acc[0]) / 300e3, (acc[2] - acc[1]) / 300e3, (acc[3] - acc[2]) / 300e3, acc[4] / 300e3, acc[5] / 300e3);
     }
+    if (argc > 3 && strcmp(argv[3], "comm") == 0) {
+        /* the multi-GPU exchange without torch in the process: RCCL is bound by the library at this first call (dlopen of
+         * librccl.so.1 = ROCm's own copy here), a one-rank communicator, one all-reduce(SUM) in place: the values stay */
+        int (*p_esac_hip_comm_unique_id)(void*, size_t);
+        int (*p_esac_hip_comm_init)(esac_hip_ctx*, int, int, const void*, size_t);
+        int (*p_esac_hip_comm_destroy)(esac_hip_ctx*);
+        int (*p_esac_hip_allreduce_sum)(esac_hip_ctx*, double*, size_t, void*);
+        RESOLVE(esac_hip_comm_unique_id);
+        RESOLVE(esac_hip_comm_init);
+        RESOLVE(esac_hip_comm_destroy);
+        RESOLVE(esac_hip_allreduce_sum);
+        double h[288], back[288];
+        void* d_buf = NULL;
+        for (int i = 0; i < 288; i++) h[i] = 0.25 * i - 7.0;
+        if (hipMalloc_(&d_buf, sizeof(h)) != 0 || hipMemcpy_(d_buf, h, sizeof(h), 1) != 0) return 18;
+        if (p_esac_hip_allreduce_sum(ctx, (double*)d_buf, 288, NULL) != -13) return 19; /* no communicator yet */
+        unsigned char id[ESAC_COMM_ID_BYTES];
+        if (p_esac_hip_comm_unique_id(id, sizeof(id)) != 0 || p_esac_hip_comm_init(ctx, 1, 0, id, sizeof(id)) != 0) {
+            fprintf(stderr, "communicator: %s\n", p_esac_hip_last_error());
+            return 20;
+        }
+        for (int rep = 0; rep < 3; rep++)
+            if (p_esac_hip_allreduce_sum(ctx, (double*)d_buf, 288, NULL) != 0) {
+                fprintf(stderr, "all-reduce: %s\n", p_esac_hip_last_error());
+                return 21;
+            }
+        if (hipMemcpy_(back, d_buf, sizeof(back), 2) != 0) return 22; /* blocking copy on the NULL stream: after the collective */
+        for (int i = 0; i < 288; i++)
+            if (back[i] != h[i]) return 23;
+        if (p_esac_hip_comm_destroy(ctx) != 0 || p_esac_hip_allreduce_sum(ctx, (double*)d_buf, 288, NULL) != -13) return 24;
+        hipFree_(d_buf);
+        printf("comm ok: one-rank RCCL communicator, all-reduce of 288 doubles in place\n");
+    }
     hipFree_(d_grad); hipFree_(d_sc); hipFree_(d_assign);
     free(sc);
     p_esac_hip_destroy(ctx);

@@ -38,6 +38,8 @@ def test_library_exports_every_declared_symbol():
     deps = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
     assert "torch" not in deps and "python" not in deps
     assert "amdhip64" in deps
+    # RCCL (570 MB) is bound by dlopen at the first esac_hip_comm_* call: a single-GPU process must not load it
+    assert "rccl" not in deps
 
 
 def test_params_struct_layout_matches_header():
@@ -184,3 +186,16 @@ def test_c_program_runs_forward_and_backward_without_torch():
     out = subprocess.run([exe, build.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "forward ok" in out.stdout and "backward ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_program_runs_the_score_exchange_on_rccl_without_torch():
+    """The multi-GPU exchange from the plain C caller: the library binds RCCL itself at the first esac_hip_comm_* call (ROCm's
+    librccl.so.1, no torch in the process), a one-rank communicator, the all-reduce in place on the NULL stream; -13 before
+    esac_hip_comm_init and after esac_hip_comm_destroy."""
+    import subprocess
+    from tests.native import build as nb
+    exe = nb.build_abi_check()
+    out = subprocess.run([exe, build.LIB_PATH, "gpu", "comm"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "comm ok" in out.stdout

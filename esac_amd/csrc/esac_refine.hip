@@ -487,7 +487,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     CYC_BEGIN();
     if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
     if (SLOTS && a.bwd.team_max_slots > 0 && a.bwd.n_sel[0] <= a.bwd.team_max_slots) return;  // few slots: the team launch refines them
-    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull};
+    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull, false};
     int cell0 = 0, Pn = P;  // this workgroup's cells: [cell0, cell0 + Pn)
     if (SHARED) {
         coop_init(co, a, (int)gridDim.x, (int)blockIdx.x, a.coop_extra ? (1L << 12) : (1L << 25));  // polls: ~seconds; the stall test gives up after ~1 ms

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     const long long cyc_start = clock64();
 #endif
     CYC_BEGIN();
-    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull};
+    Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull, false};
     if (SLOTS) {
         coop_init(co, a, 8, (int)(blockIdx.x & 63) >> 3, ESAC_TEAM_SPIN_LIMIT_SLOTS);
         co.gran = reinterpret_cast<u32x4*>(a.bwd.team_gran) + (size_t)slot * ESAC_TEAM_GRANULES;
@@ -561,11 +561,14 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     co.expect = co.G;
     if (a.coop_extra && co.g == co.G - 1) return;  // ESAC_DEBUG_COOP_STALL: the last member never shows up
     // first exchange, in flight while the winner is looked up: a census of the XCDs the members run on (64^XCC_ID each)
-    {
-        int xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        team_publish<1>((double)(1ull << (6 * (xcc & 7))), co);
-    }
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    team_publish<1>((double)(1ull << (6 * (xcc & 7))), co);
+    // ... and once it is in: do all members share this one's XCD?  (the census is the same number in every member, so they all
+    // answer alike: G in one 6-bit field.)  Then the exchanges that follow stay in that XCD's L2 (gran_store).
+    auto note_census = [&](double cz) {
+        co.local = !co.dead && (unsigned long long)cz == ((unsigned long long)co.G << (6 * (xcc & 7)));
+    };
     if (threadIdx.x < 33) s_pow10[threadIdx.x] = pow10_int((int)threadIdx.x - 16);  // (visible after the barrier of the winner pick)
     if (threadIdx.x < LM_LANE_SLOTS) s_tot[threadIdx.x] = 0.0;  // the zero slots stay zero: an exchange writes [0, 27) and [32, 59)
     // the lane-dealt LM step's constants of this lane (opaque to the optimiser: values to keep, not to rematerialise per round)
@@ -621,6 +624,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     } else if (a.fold_select) {
         __syncthreads();  // (s_pow10, s_coop_dead)
         team_collect<1>(census, co, s_tot, s_x);
+        note_census(census[0]);
         win = team_select<CPL>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_x, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
                                rec_in);
     } else {
@@ -634,7 +638,10 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 #pragma unroll
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
     if (a.E != 1) load_cells(a.sc + (size_t)e * 3 * P);
-    if (SLOTS || a.fold_select != 1) team_collect<1>(census, co, s_tot, s_x);
+    if (SLOTS || a.fold_select != 1) {
+        team_collect<1>(census, co, s_tot, s_x);
+        note_census(census[0]);
+    }
     CYC_END(1);
 
     // ---- refineHyp (esac_util.h:378-454) around ONE pass site

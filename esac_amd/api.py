@@ -368,7 +368,9 @@ class Engine:
         return {"teams": bool(v[0]), "team_calls": int(v[1]), "team_fallbacks": int(v[2]), "slots": int(v[3])}
 
     def refine_info(self):
-        """How the most recent winner refinement ran (ESAC_BUF_REFINE_INFO)."""
+        """How the most recent winner refinement ran (ESAC_BUF_REFINE_INFO).  `same_xcd`: the census of the team's first
+        exchange found every member on one XCD -- the exchanges after it then stayed in that XCD's L2 (plain granule stores,
+        refine_common.hpp:gran_store); otherwise they were written through (valid at any placement, 0.1-0.3 us slower each)."""
         v = self.read(BUF_REFINE_INFO)
         return {"mode": ("one_workgroup", "cooperating", "team")[int(v[0])] if 0 <= int(v[0]) <= 2 else int(v[0]),
                 "workgroups": int(v[1]),

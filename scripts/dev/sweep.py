@@ -5,21 +5,23 @@ from esac_amd import api, synthetic as S
 from oracle import esac_oracle as O
 eng = api.engine(0)
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+base = int(sys.argv[2]) if len(sys.argv) > 2 else 1000   # first frame seed
+key = int(sys.argv[3]) if len(sys.argv) > 3 else 77       # RNG seed of the calls
 bad = 0; worst_r = worst_t = 0.0; flips = 0; lm_diff = 0
 t0 = time.time()
 for k in range(n_frames):
     kind = k % 4
-    if kind == 0: f = S.make_frame(1000 + k); N = 256; mode = "single"
-    elif kind == 1: f = S.make_frame(1000 + k, E=3, true_expert=k % 3); N = 192; mode = "gating"
-    elif kind == 2: f = S.make_frame(1000 + k, noise=0.05, outlier_frac=0.5); N = 128; mode = "single"
-    else: f = S.make_frame(1000 + k, H=45, W=61, sub=10, shift=(k % 7 - 3, 2)); N = 96; mode = "single"
+    if kind == 0: f = S.make_frame(base + k); N = 256; mode = "single"
+    elif kind == 1: f = S.make_frame(base + k, E=3, true_expert=k % 3); N = 192; mode = "gating"
+    elif kind == 2: f = S.make_frame(base + k, noise=0.05, outlier_frac=0.5); N = 128; mode = "single"
+    else: f = S.make_frame(base + k, H=45, W=61, sub=10, shift=(k % 7 - 3, 2)); N = 96; mode = "single"
     ha = S.gating_assignment(f, N, mode=mode)
     E, _, H, W = f["coords"].shape
     p = eng.make_params(E, H, W, N, shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"],
-                        sub_sampling=f["sub"], seed=77, call=k)
+                        sub_sampling=f["sub"], seed=key, call=k)
     res = eng.forward_device(torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda(), p)
     ref = O.forward(f["coords"], ha, shift_x=f["shift"][0], shift_y=f["shift"][1], focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"],
-                    sub_sampling=f["sub"], seed=77, call=k)
+                    sub_sampling=f["sub"], seed=key, call=k)
     ok = int(res[api.RES_HYP]) == ref["winner"] and int(res[api.RES_REF_STEPS]) == ref["ref_steps"]
     cnt_equal = np.array_equal(eng.read(api.BUF_INLIER_COUNTS), ref["inlier_counts"])
     map_equal = np.array_equal(eng.read(api.BUF_INLIER_MAP), ref["inlier_map"])
@@ -30,4 +32,4 @@ for k in range(n_frames):
         bad += 1
         print("MISMATCH frame", k, "kind", kind, "winner", int(res[api.RES_HYP]), ref["winner"], "steps", int(res[api.RES_REF_STEPS]), ref["ref_steps"],
               "counts", cnt_equal, "map", map_equal, "r", r, "t", t)
-print("frames %d mismatches %d worst rot %.2e rad worst trans %.2e m, LM-iteration count differs on %d frames, %.1f s" % (n_frames, bad, worst_r, worst_t, lm_diff, time.time() - t0))
+print("frames %d (seeds %d.., key %d) mismatches %d worst rot %.2e rad worst trans %.2e m, LM-iteration count differs on %d frames, %.1f s" % (n_frames, base, key, bad, worst_r, worst_t, lm_diff, time.time() - t0))

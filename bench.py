@@ -556,6 +556,12 @@ def main():
                     row["rocprofv3_avg_us"] = sum(k["per_step_us"] for k in ks) if ks else None
                 kernels.append(row)
             out["kernels"] = kernels
+            # what a step spends outside its kernels: against the live stage times and against the committed rocprofv3 durations
+            rp = [r.get("rocprofv3_avg_us") for r in kernels]
+            out["host_turn_us"] = {"vs_live_stage_times": elapsed / steps * 1e6 - tot * 1e3,
+                                   "vs_rocprofv3_durations": elapsed / steps * 1e6 - sum(v or 0.0 for v in rp) if prof and any(rp) else None,
+                                   "note": "ms_per_step - sum of the stages' kernel durations: launch call of the first kernel, command processor, "
+                                           "kernel boundaries, record hand-off, Python (split: profiles/r05_host_turn.txt)"}
             score_ms = st["score"]
             alg_bytes = n_total * 12.0 * H * W
             achieved = alg_bytes / (score_ms * 1e-3) / 1e9

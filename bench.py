@@ -240,6 +240,8 @@ def main():
     ap.add_argument("--no-training", action="store_true", help="skip the extra `training` (esac.backward) figure")
     ap.add_argument("--no-extras", action="store_true", help="only the contract line: no batched / training / h2d / stage legs")
     ap.add_argument("--no-exact", action="store_true", help="skip the `value_exact` leg (the guaranteed routes)")
+    ap.add_argument("--sharded-leg", action="store_true",
+                    help="(internal) run only the `sharded_world1` leg and print its object: how the default run executes it, in a process of its own")
     args = ap.parse_args()
     preset = dict(PRESETS[args.config])
     for k in ("hyps", "experts", "grid", "policy", "scaling"):
@@ -362,7 +364,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if one_device else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if world == 1:
+    if world == 1 and not args.sharded_leg:
         # per-phase GPU times (hipEvent brackets between the launches of a call): their own pass over the first steps of the
         # timed sequence, AFTER the timed region -- a bracketed call is ~5 us slower and reading the events costs host time
         eng.set_timing(True, period=1)
@@ -375,7 +377,7 @@ def main():
     # the same K steps under the reference's own RNG seed (thread_rand.h:103, 1305), whose 20-step window is the unluckiest of
     # 24 seeds in refinement work (BENCH_SEED above): printed next to `value`, never instead of it
     seed1305 = None
-    if world == 1 and config_name == "cfg2":
+    if world == 1 and config_name == "cfg2" and not args.sharded_leg:
         params.seed = 1305
         for i in range(warmup):
             step(i)
@@ -391,7 +393,7 @@ def main():
     # ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING) -- what "score tensors identical" costs there; never `value`
     value_exact = value_fast = None
     auto_applies = E == 1 and n_total * H * W <= (1 << 21)
-    if world == 1 and config_name in ("cfg2", "cfg3") and not args.no_exact:
+    if world == 1 and config_name in ("cfg2", "cfg3") and not args.no_exact and not args.sharded_leg:
         pe = eng.make_params(E, H, W, n_total, seed=BENCH_SEED, call=0, exact_scores=not auto_applies, exact_sampling=not auto_applies, **kw)
         ke = max(10, steps // (1 if config_name == "cfg2" else 4))
         def step_other(i):
@@ -417,7 +419,18 @@ def main():
     # the multi-GPU call path on the ONE GPU of this box: the same K steps through forward_sharded(policy="range") in a one-rank RCCL
     # group -- what a rank adds to the plain call (the collective, Python glue), with the collective really executing
     sharded1 = None
-    if world == 1 and config_name == "cfg2" and not args.no_extras:
+    if world == 1 and config_name == "cfg2" and not args.no_extras and not args.sharded_leg:
+        # in a process of its own: this leg brings up RCCL (torch.distributed's communicator and the library's), and nothing it does
+        # -- not even a fault of that process -- may cost the contract line
+        import subprocess
+        try:
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--sharded-leg", "--steps", str(steps), "--warmup", str(warmup),
+                                    "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+            lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+            sharded1 = json.loads(lines[-1]) if lines else {"error": "the leg's process ended with status %d: %s" % (child.returncode, child.stderr[-300:])}
+        except Exception as exc:
+            sharded1 = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    if args.sharded_leg:
         import socket
         import torch.distributed as dist
         sock = socket.socket()
@@ -449,6 +462,7 @@ def main():
                         "allreduce_host_call_ms": float(np.median(ar_host)) if ar_host else None,
                         "zero_ms": 0.0, "pick_ms": 0.0,
                         "exchange": "esac_hip_allreduce_sum (the library's own RCCL communicator)" if eng._comm else "torch.distributed.all_reduce",
+                        "process": "a process of its own (bench.py --sharded-leg): plain_ms_per_step is that process's own K plain steps",
                         "note": "forward_sharded(policy='range') at world 1: the forward launches write scores and record into the exchange buffer, the "
                                 "record reaches the host from the refinement kernel itself (no pick launch at one rank), ONE RCCL all-reduce of "
                                 "N + 32 doubles runs on the launch stream; no memset (two buffers alternate, the pick of call i clears the buffer of "
@@ -461,6 +475,10 @@ def main():
                 eng.comm_destroy()
             if dist.is_initialized():
                 dist.destroy_process_group()
+        print(json.dumps(sharded1))
+        sys.stdout.flush()
+        os.dup2(os.open(os.devnull, os.O_WRONLY), 1)  # (RCCL's banner, see the end of main)
+        return
     def _mean_ms(name):
         v = [ev[0].elapsed_time(ev[1]) for n, ev in ar_timers if n == name]
         return float(np.mean(v)) if v else None

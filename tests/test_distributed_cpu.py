@@ -41,6 +41,13 @@ def _oracle_local(O, f, ha_full, gidx, call):
     return o["scores"], rec
 
 
+class _Untouchable:
+    """Stands for an Engine in the gloo workers: any use of it is a test failure."""
+
+    def __getattr__(self, name):
+        raise AssertionError("the engine was used on a gloo group: %s" % name)
+
+
 def _worker(rank, world, port, policy, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -61,7 +68,10 @@ def _worker(rank, world, port, policy, q):
         buf = D.pack_local(torch.from_numpy(np.ascontiguousarray(scores_l)), torch.from_numpy(rec_l), n_total,
                            torch.from_numpy(gidx.astype(np.int32)), rank, world)
         assert buf.numel() == n_total + world * D.RES_DOUBLES
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)  # THE one collective
+        # THE one collective, through the product's own entry: on a gloo group (and for a CPU buffer) the library's RCCL
+        # communicator must stay out of it -- the engine is never touched
+        assert D.native_comm(_Untouchable(), None) is None
+        D._all_reduce_sum(buf, None, engine=_Untouchable())
         scores_g, best = D.pick_global(buf, n_total, world)
         q.put((rank, scores_g.numpy().copy(), best.copy()))
     finally:

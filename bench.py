@@ -425,7 +425,7 @@ def main():
         import subprocess
         try:
             child = subprocess.run([sys.executable, os.path.abspath(__file__), "--sharded-leg", "--steps", str(steps), "--warmup", str(warmup),
-                                    "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                                    "--no-cpu-baseline"], capture_output=True, text=True, timeout=300)
             lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
             sharded1 = json.loads(lines[-1]) if lines else {"error": "the leg's process ended with status %d: %s" % (child.returncode, child.stderr[-300:])}
         except Exception as exc:

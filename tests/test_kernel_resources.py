@@ -148,3 +148,21 @@ def test_lane_dealt_lm_step_is_in_the_isa_and_its_dpp_hazards_are_covered(tmp_pa
                         assert not (dst & src), (name, ins[j], ins[i])
                     waited += 1
                 j -= 1
+
+
+def test_team_exchange_has_the_local_and_the_written_through_store(tmp_path):
+    """Round 5: the granules of a team whose census showed ONE XCD are plain 16-byte stores (they stay in that XCD's L2, where the
+    pollers' loads find them); a spread team writes them through (sc1: valid between any two CUs, but visible only when the write
+    has reached the home I/O die of its page -- the 67-vs-71 us state of this kernel, profiles/r05_gran_placement_before.txt).
+    Both forms must be in every team kernel, the pollers' loads must bypass the L1 (sc1), and no granule may be stored any other way."""
+    f = _isa_functions("esac_refine_team.hip", tmp_path)
+    teams = {n: ins for n, ins in f.items() if "k_refine_team" in n}
+    assert len(teams) == 12
+    for name, ins in teams.items():
+        st = [i for i in ins if i.startswith("global_store_dwordx4")]
+        plain = [i for i in st if not re.search(r"\bsc[01]\b|\bnt\b", i)]
+        through = [i for i in st if re.search(r"\bsc1\b", i) and not re.search(r"\bsc0\b", i)]
+        assert plain and through, (name, st)
+        assert len(plain) + len(through) == len(st), (name, st)
+        ld = [i for i in ins if i.startswith("global_load_dwordx4") and re.search(r"\bsc1\b", i)]
+        assert ld, name  # gran_load: the polls

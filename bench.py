@@ -224,6 +224,27 @@ OWN_BOUND = {
 }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` (N > 1) with no launcher around it: start the N ranks here -- torch.distributed.run, one process
+    per GPU, rendezvous on 127.0.0.1 -- pass their stderr through and relay rank 0's ONE JSON line.  Never a silent one-GPU run."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), ESAC_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+    if child.returncode != 0 or not lines:
+        sys.stderr.write("bench.py: the %d-rank run failed (status %d, %d JSON line(s) on its stdout)\n" % (n, child.returncode, len(lines)))
+        raise SystemExit(child.returncode or 1)
+    print(lines[-1])
+    sys.stdout.flush()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,14 +271,26 @@ def main():
     custom = any(getattr(args, k) is not None for k in ("hyps", "experts", "grid"))
     config_name = args.config if not custom else "custom"
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     # test hook (tests/test_gpu_distributed.py): several ranks on ONE device with gloo, to exercise this file's
     # multi-rank path on a single-GPU box; RCCL itself refuses two ranks on one device
     one_device = os.environ.get("ESAC_BENCH_ONE_DEVICE") == "1"
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not one_device and n_dev < args.gpus:
+        # never fall back to fewer GPUs than asked for: a line with n_gpus != the ranks that ran is worthless
+        sys.stderr.write("bench.py: --gpus %d but this node offers %d HIP device(s) (no CPU fallback for the product path)\n" % (args.gpus, n_dev))
+        raise SystemExit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)  # no launcher around this process: be the launcher
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)\n" % (args.gpus, world))
+        raise SystemExit(2)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback for the product path)")
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -268,7 +301,6 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
-    assert args.gpus == world or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
 
     E = int(preset["experts"])
     H, W = (int(v) for v in preset["grid"].split("x"))
@@ -483,6 +515,22 @@ def main():
         v = [ev[0].elapsed_time(ev[1]) for n, ev in ar_timers if n == name]
         return float(np.mean(v)) if v else None
     allreduce_ms, shard_build_ms = _mean_ms("allreduce"), _mean_ms("shard")
+    # what every rank's exchange actually ran on: the ranks its communicator spans as RCCL itself reports them (the library's
+    # communicator: ncclCommCount through esac_hip_comm_info; the torch.distributed route: the group's size), and the GPU it is bound to
+    rank_reports = None
+    if world > 1:
+        import torch.distributed as dist
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "pci_device_id": getattr(props, "pci_device_id", None), "name": props.name, "pid": os.getpid()}
+        if eng._comm:
+            info = eng.comm_info()
+            mine.update(ranks_seen=info["nranks"], comm_rank=info["rank"], comm_device=info["rccl_device"], route="library RCCL communicator")
+        else:
+            mine.update(ranks_seen=dist.get_world_size(), comm_rank=dist.get_rank(), comm_device=None,
+                        route="torch.distributed (%s)" % dist.get_backend())
+        rank_reports = [None] * world
+        dist.all_gather_object(rank_reports, mine)
 
     if rank == 0:
         gating_txt = {"single": "all hypotheses on the one expert", "gating": "softmax gating (true expert logit 6)",
@@ -530,6 +578,10 @@ def main():
         if world == 1:
             out["refine"] = eng.refine_info()  # how the winner's refinement of the last step ran (ESAC_BUF_REFINE_INFO)
         if world > 1:
+            out["ranks_seen"] = min(r["ranks_seen"] for r in rank_reports)  # the smallest communicator any rank ran its exchange on
+            out["devices"] = [r["device"] for r in rank_reports]           # hipGetDevice of every rank, by rank
+            out["rank_reports"] = rank_reports
+            out["launcher"] = "bench.py itself (torch.distributed.run, --nproc-per-node %d)" % world if os.environ.get("ESAC_BENCH_SELF_LAUNCHED") else "external"
             out["allreduce_ms"] = allreduce_ms
             out["exchange"] = ("esac_hip_allreduce_sum (the library's own RCCL communicator)" if eng._comm else
                                "torch.distributed.all_reduce (%s)" % ("gloo: ranks share one GPU" if one_device else "RCCL"))

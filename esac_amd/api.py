@@ -41,12 +41,13 @@ ABI_SYMBOLS = [
     "esac_hip_score_span_ms", "esac_hip_forward_batch", "esac_hip_backward", "esac_hip_set_debug", "esac_hip_check",
     "esac_hip_pick_record", "esac_hip_time_stages", "esac_hip_shard_balanced", "esac_hip_set_wait",
     "esac_hip_set_refine_team", "esac_hip_host_turn",
-    "esac_hip_comm_unique_id", "esac_hip_comm_init", "esac_hip_comm_destroy", "esac_hip_allreduce_sum",
+    "esac_hip_comm_unique_id", "esac_hip_comm_init", "esac_hip_comm_destroy", "esac_hip_allreduce_sum", "esac_hip_comm_info",
 ]
 COMM_ID_BYTES = 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS, FLAG_EXACT_SAMPLING, FLAG_SCORES_BY_INDEX = 1, 2, 4, 8, 16, 32
 FLAG_AUTO_EXACT = 64
+FLAG_REFINE_SOLO = 128
 WAIT_SPIN, WAIT_YIELD, WAIT_BLOCK = 0, 1, 2
 DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL, DEBUG_TEAM_SPREAD = 1, 2, 4
 
@@ -113,6 +114,7 @@ def load_library():
         lib.esac_hip_comm_init.argtypes = [vp, i32, i32, vp, C.c_size_t]
         lib.esac_hip_comm_destroy.argtypes = [vp]
         lib.esac_hip_allreduce_sum.argtypes = [vp, vp, C.c_size_t, vp]
+        lib.esac_hip_comm_info.argtypes = [vp, vp]
         for name in ABI_SYMBOLS:
             if name not in ("esac_hip_last_error",):
                 getattr(lib, name).restype = i32
@@ -147,6 +149,7 @@ class Engine:
         self._host_addr = C.addressof(self._host_buf)
         self._host_np = np.frombuffer(self._host_buf, dtype=np.float64)
         self._comm = None  # (nranks, rank) once comm_init has run
+        self._comm_key = None  # the process group (its ranks) the communicator mirrors (distributed.native_comm)
 
     def _call(self, fn, *args):
         """One C-ABI call with this engine's device current (the library calls hipSetDevice itself; the context
@@ -175,7 +178,7 @@ class Engine:
     def make_params(self, E, H, W, N, shift_x=0, shift_y=0, focal=525.0, ppx=320.0, ppy=240.0, inlier_thresh=10.0,
                     inlier_alpha=100.0, inlier_beta=0.5, max_reproj=100.0, sub_sampling=8, seed=1305, call=0,
                     max_tries=0, max_ref_steps=-1, hyp_offset=0, rescore_margin=0.0, exact_scores=False, score_shape="auto", pack_maps=False,
-                    exact_sampling=False, scores_by_index=False, expert_base=0):
+                    exact_sampling=False, scores_by_index=False, expert_base=0, refine_solo=False):
         p = Params()
         p.E, p.H, p.W, p.N = int(E), int(H), int(W), int(N)
         p.shift_x, p.shift_y = int(shift_x), int(shift_y)
@@ -189,7 +192,8 @@ class Engine:
         # exact_scores: True / False, or "auto" = the guaranteed routes where they are free (ESAC_FLAG_AUTO_EXACT: what esac.forward asks for)
         p.flags = (FLAG_AUTO_EXACT if exact_scores == "auto" else FLAG_EXACT_SCORES if exact_scores else 0) | \
             {"auto": 0, "tiled": FLAG_SCORE_TILED, "stream": FLAG_SCORE_STREAM}[score_shape] | \
-            (FLAG_PACK_MAPS if pack_maps else 0) | (FLAG_EXACT_SAMPLING if exact_sampling else 0) | (FLAG_SCORES_BY_INDEX if scores_by_index else 0)
+            (FLAG_PACK_MAPS if pack_maps else 0) | (FLAG_EXACT_SAMPLING if exact_sampling else 0) | (FLAG_SCORES_BY_INDEX if scores_by_index else 0) | \
+            (FLAG_REFINE_SOLO if refine_solo else 0)
         p.expert_base = int(expert_base)
         self._shape = (int(N), int(H), int(W))
         return p
@@ -394,6 +398,14 @@ class Engine:
     def comm_destroy(self):
         _check(self.lib.esac_hip_comm_destroy(self.ctx), self.lib)
         self._comm = None
+        self._comm_key = None
+
+    def comm_info(self):
+        """What the communicator itself reports (esac_hip_comm_info): ranks it spans, this rank, the GPU RCCL bound it to, the
+        context's GPU."""
+        out = (C.c_int32 * 4)()
+        _check(self.lib.esac_hip_comm_info(self.ctx, out), self.lib)
+        return {"nranks": int(out[0]), "rank": int(out[1]), "rccl_device": int(out[2]), "device": int(out[3])}
 
     def allreduce_sum(self, buf):
         """In-place all-reduce(SUM) of a device float64 tensor over this engine's RCCL communicator, on the current stream."""

@@ -372,50 +372,70 @@ __global__ __launch_bounds__(256) void k_bwd_accumulate(KArgs a) {
     const int P = a.H * a.W;
     const int e = blockIdx.y;
     const int n_sel = a.bwd.n_sel[0];
-    if (a.bwd.n_sel[1] > a.bwd.cap) return;  // more slots than the workspace holds: nothing is accumulated, the host grows it and retries
-    // the slots were refined by teams and one of them timed out (a member never became resident): nothing is accumulated
-    // either, the host refines the slots again with one workgroup each
-    if (a.bwd.team && __hip_atomic_load(a.coop_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.bwd.team_tag) return;
-    if (threadIdx.x < 64) {
-        int count = 0;
-        for (int base = 0; base < n_sel; base += 64) {
-            const int slot = base + (int)threadIdx.x;
-            int h = 0;
-            bool mine = false;
-            if (slot < n_sel) {
-                h = a.bwd.sel[slot];
-                mine = expert_of(a, h) == e;
+    // more slots than the workspace holds: nothing is accumulated, the host grows it and retries.  The slots were refined by
+    // teams and one of them timed out (a member never became resident): nothing is accumulated either, the host refines the
+    // slots again with one workgroup each.  (Both are the same answer in every workgroup of the launch.)
+    const bool team_failed = a.bwd.team && __hip_atomic_load(a.coop_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == a.bwd.team_tag;
+    const bool skip = a.bwd.n_sel[1] > a.bwd.cap || team_failed;
+    if (!skip) {
+        if (threadIdx.x < 64) {
+            int count = 0;
+            for (int base = 0; base < n_sel; base += 64) {
+                const int slot = base + (int)threadIdx.x;
+                int h = 0;
+                bool mine = false;
+                if (slot < n_sel) {
+                    h = a.bwd.sel[slot];
+                    mine = expert_of(a, h) == e;
+                }
+                const unsigned long long bal = __ballot(mine);
+                if (mine) {
+                    const int pos = count + __popcll(bal & ((1ull << threadIdx.x) - 1ull));
+                    s_slot[pos] = slot;
+                    s_prob[pos] = a.bwd.probs[h];
+                }
+                count += __popcll(bal);
             }
-            const unsigned long long bal = __ballot(mine);
-            if (mine) {
-                const int pos = count + __popcll(bal & ((1ull << threadIdx.x) - 1ull));
-                s_slot[pos] = slot;
-                s_prob[pos] = a.bwd.probs[h];
-            }
-            count += __popcll(bal);
+            if (threadIdx.x == 0) s_count = count;
         }
-        if (threadIdx.x == 0) s_count = count;
+        __syncthreads();
+        const int n = s_count;
+        const int rem = blockIdx.x * blockDim.x + threadIdx.x;  // c * P + cell
+        if (n > 0 && rem < 3 * P) {
+            float* o = a.bwd.out_grad + (size_t)e * 3 * P + rem;
+            float v = *o;
+            constexpr int U = 8;
+            for (int base = 0; base < n; base += U) {
+                double t[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = base + u < n ? base + u : n - 1;  // clamped: the loads are unconditional
+                    const size_t k = (size_t)s_slot[q] * 3 * P + rem;
+                    t[u] = s_prob[q] * a.bwd.grad1[k] + a.bwd.grad2[k];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (base + u < n) v = (float)((double)v + t[u]);  // float += double (esac.cpp:501-506)
+            }
+            *o = v;
+        }
     }
+    // The call's record -- expected loss, slots, entropy, out-of-range flag (k_bwd_loss wrote them), "a slot team timed out" --
+    // goes to the pinned slot the host polls (as the forward's record does: no copy, no stream-completion round trip), by the
+    // LAST workgroup of this launch to finish: every one arrives at a counter once its stores are issued.
+    if (!a.result_pin) return;
     __syncthreads();
-    const int n = s_count;
-    const int rem = blockIdx.x * blockDim.x + threadIdx.x;  // c * P + cell
-    if (n == 0 || rem >= 3 * P) return;
-    float* o = a.bwd.out_grad + (size_t)e * 3 * P + rem;
-    float v = *o;
-    constexpr int U = 8;
-    for (int base = 0; base < n; base += U) {
-        double t[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int q = base + u < n ? base + u : n - 1;  // clamped: the loads are unconditional
-            const size_t k = (size_t)s_slot[q] * 3 * P + rem;
-            t[u] = s_prob[q] * a.bwd.grad1[k] + a.bwd.grad2[k];
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (base + u < n) v = (float)((double)v + t[u]);  // float += double (esac.cpp:501-506)
+    if (threadIdx.x >= 64) return;
+    int last = 0;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(a.bwd.arrived, 1) == (int)(gridDim.x * gridDim.y) - 1;
+        if (last) a.bwd.arrived[0] = 0;  // (every workgroup has arrived: ready for the next call)
     }
-    *o = v;
+    if (!__shfl(last, 0)) return;
+    const int lane = threadIdx.x;
+    const double v = lane < 4 ? a.bwd.out[lane] : lane == 4 ? (team_failed ? 1.0 : 0.0) : lane == 32 ? a.epoch : 0.0;
+    pin_deliver(a.result_pin, v);
 }
 
 // ---------------------------------------------------------------- launchers

@@ -6,7 +6,6 @@
 // (the StopWatch prints of esac.cpp:124,149,161,179).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types only: the entry points are bound by dlopen (rccl() below)
 #include <sched.h>
 #include <time.h>
 #include <stdarg.h>
@@ -19,6 +18,13 @@
 #include "pose_math.hpp"
 
 using namespace esac;
+
+// RCCL's handful of types, declared here (see rccl() below: the library is bound by dlopen, its headers are not needed)
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+}
 
 static_assert(ESAC_RES_SCORE == ESAC_RES_SCORE_K && ESAC_RES_HYP == ESAC_RES_HYP_K && ESAC_RES_EXPERT == ESAC_RES_EXPERT_K &&
                   ESAC_RES_RVEC == ESAC_RES_RVEC_K && ESAC_RES_POSE == ESAC_RES_POSE_K &&
@@ -83,6 +89,8 @@ struct esac_hip_ctx {
     int team = ESAC_REFINE_TEAM_DEFAULT;  // members of the refinement team on small grids (esac_hip_set_refine_team; 0: one workgroup)
     bool team_spread = false;             // ESAC_DEBUG_TEAM_SPREAD: the members are consecutive workgroups (one per XCD)
     unsigned long long refine_tag = 0;    // tag of the most recent shared (cooperative / team) refinement launch, 0: none yet
+    unsigned long long checked_tag = 0;   // the failed launch esac_hip_check has already counted as a strike
+    bool refine_was_team = false;         // the most recent forward's refinement launch was a team's
     long long team_fallbacks = 0;         // blocking calls whose team timed out and were refined again by one workgroup
     int team_strikes = 0;                 // consecutive forward calls whose team timed out; at ESAC_TEAM_STRIKES the context stops asking
     bool team_latched_off = false;        // ... for teams (a caller that keeps the GPU's CUs busy on another stream would otherwise pay the
@@ -103,6 +111,8 @@ struct esac_hip_ctx {
     long long tPart = 0;
     bool rt32_stale = false;  // esac_hip_write_hyps ran: the fp32 [R|t] rows are rebuilt by the next esac_hip_score
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // esac_hip_host_turn: where the host's time of the most recent blocking forward went
+    hipStream_t side = nullptr;  // esac_hip_backward: path II runs here, beside path I on the caller's stream (ensure_side)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ncclComm_t comm = nullptr;  // esac_hip_comm_init: this context's rank in an RCCL communicator (the multi-GPU score exchange)
     int comm_ranks = 0, comm_rank = 0;
 };
@@ -125,27 +135,44 @@ constexpr int ESAC_SLOT_TEAMS_MAX = 32;  // training path: slots refined by team
 constexpr int ESAC_TEAM_STRIKES = 2;
 constexpr long long ESAC_TEAM_REARM_CALLS = 1000;
 
-// RCCL, bound at the first esac_hip_comm_* call (see "the one collective of the multi-GPU path" below)
+// RCCL, bound at the first esac_hip_comm_* call (see "the one collective of the multi-GPU path" below).  The handful of
+// types and entry points this file needs are declared HERE (the stable NCCL 2.x C API: a 128-byte unique id, an opaque
+// communicator, ncclResult_t 0 = success, ncclSum = 0, ncclDouble = 8), not taken from <rccl/rccl.h>: a single-GPU build of the
+// library needs neither RCCL's headers at compile time nor its shared object at run time.
+static_assert(sizeof(ncclUniqueId) == ESAC_COMM_ID_BYTES, "unique id size");
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int NCCL_SUM = 0, NCCL_DOUBLE = 8;  // ncclRedOp_t ncclSum, ncclDataType_t ncclFloat64
 struct Rccl {
-    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
-    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
-    decltype(&ncclCommDestroy) comm_destroy = nullptr;
-    decltype(&ncclAllReduce) all_reduce = nullptr;
-    decltype(&ncclGetErrorString) error_string = nullptr;
+    ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*all_reduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*error_string)(ncclResult_t) = nullptr;
+    ncclResult_t (*comm_count)(const ncclComm_t, int*) = nullptr;      // what the communicator itself reports (esac_hip_comm_info)
+    ncclResult_t (*comm_user_rank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*comm_cu_device)(const ncclComm_t, int*) = nullptr;
     bool ok = false;
 };
 static const Rccl& rccl() {
     static const Rccl bound = [] {
         Rccl r;
         void* h = nullptr;
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+        // the copy the process already holds first (torch ships its own librccl.so under another path: two copies of RCCL in
+        // one process would each bring up their own transports), then the loader's search path, then ROCm's
+        for (const char* name : {"librccl.so.1", "librccl.so"})
+            if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+        if (!h)
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
         if (!h) return r;
         r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
         r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
         r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
         r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(h, "ncclAllReduce"));
         r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(h, "ncclGetErrorString"));
+        r.comm_count = reinterpret_cast<decltype(r.comm_count)>(dlsym(h, "ncclCommCount"));
+        r.comm_user_rank = reinterpret_cast<decltype(r.comm_user_rank)>(dlsym(h, "ncclCommUserRank"));
+        r.comm_cu_device = reinterpret_cast<decltype(r.comm_cu_device)>(dlsym(h, "ncclCommCuDevice"));
         r.ok = r.get_unique_id && r.comm_init_rank && r.comm_destroy && r.all_reduce && r.error_string;
         return r;
     }();
@@ -198,7 +225,7 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
 
 static void free_bws(esac_hip_ctx* c) {
     void* ptrs[] = {c->bws.sel,   c->bws.n_sel, c->bws.probs,    c->bws.losses,     c->bws.ref_hyps, c->bws.sgrad, c->bws.dloss,
-                    c->bws.maps,  c->bws.map_info, c->bws.corr_lists, c->bws.grad1, c->bws.grad2,   c->bws.out, c->bws.team_gran};
+                    c->bws.maps,  c->bws.map_info, c->bws.corr_lists, c->bws.grad1, c->bws.grad2,   c->bws.out, c->bws.team_gran, c->bws.arrived};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     c->bws = BwdArgs{};
@@ -213,6 +240,9 @@ extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     free_bws(c);
     if (c->sc4) (void)hipFree(c->sc4);
     drop_comm(c);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -420,7 +450,7 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     a.expert_base = p->expert_base;
     a.coop_max = c->coop_max;
     a.coop_extra = c->coop_stall ? 1 : 0;
-    a.team = c->team_latched_off ? 0 : c->team;
+    a.team = c->team;  // (the forward entry points fold the time-out latch in: forward_team)
     a.team_stride = c->team_spread ? 1 : 8;
     a.solo = 0;
     a.samp_cap = (int)(((long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP) > 0x7fffffffLL ? 0x7fffffff : (long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP);
@@ -437,6 +467,16 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     c->lastN = p->N; c->lastH = p->H; c->lastW = p->W;
     *out = a;
     return 0;
+}
+
+// The forward path's team request: off while the context is latched (two team time-outs in a row, see forward_impl).  The latch is
+// the FORWARD path's: the training path's slot teams have a switch of their own (esac_hip_ctx::slot_teams).
+static void forward_team(const esac_hip_ctx* c, KArgs& a) {
+    if (c->team_latched_off) a.team = 0;
+    if (a.flags & ESAC_FLAG_REFINE_SOLO) {
+        a.team = 0;
+        a.solo = 1;
+    }
 }
 
 static int check_launch(const char* what) {
@@ -491,7 +531,11 @@ extern "C" int esac_hip_select(esac_hip_ctx* c, const float* d_sc, const int64_t
     });
 }
 extern "C" int esac_hip_refine(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
-    return run_stage(c, d_sc, d_assign, p, stream, "k_refine", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) { cc->refine_tag = launch_refine(a, s); });
+    return run_stage(c, d_sc, d_assign, p, stream, "k_refine", [](esac_hip_ctx* cc, const KArgs& a0, hipStream_t s) {
+        KArgs a = a0;
+        forward_team(cc, a);
+        cc->refine_tag = launch_refine(a, s);
+    });
 }
 extern "C" int esac_hip_score_exact(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign, const esac_hip_params* p, void* stream) {
     return run_stage(c, d_sc, d_assign, p, stream, "k_rescore(all)", [](esac_hip_ctx* cc, const KArgs& a, hipStream_t s) {
@@ -504,6 +548,45 @@ extern "C" int esac_hip_score_exact(esac_hip_ctx* c, const float* d_sc, const in
     });
 }
 
+// Blocking calls: the last kernel stores the record and the call's epoch word into pinned host memory (one ESAC_PIN_DOUBLES slot
+// per frame: record, epoch word, status word, check word) and the host polls.  A slot has landed when its epoch word is this
+// call's AND its check word fits the other 34 words (the kernel stores them without a fence: esac_kernels.hpp, pin_mix).
+static int wait_record(esac_hip_ctx* c, hipStream_t s, int B, double want, const char* who) {
+    auto all_landed = [&]() {
+        for (int b = 0; b < B; b++) {
+            const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES);
+            if (*(const volatile double*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES + 32) != want) return false;
+            unsigned long long h = 0;
+            for (int k = 0; k < 34; k++) h ^= pin_mix(w[k], k);
+            if (h != w[34]) return false;
+        }
+        return true;
+    };
+    bool landed = false;
+    if (c->wait_mode == ESAC_WAIT_BLOCK) {
+        HIP_OK(hipStreamSynchronize(s));
+        landed = all_landed();
+    } else {
+        const bool yield = c->wait_mode == ESAC_WAIT_YIELD;
+        for (long spins = 0; spins < 200000000L; spins++) {
+            if (all_landed()) {
+                landed = true;
+                break;
+            }
+            if (yield) sched_yield();
+            if ((spins & (yield ? 63 : 1023)) == (yield ? 63 : 1023) && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernels are done (or failed)
+                landed = all_landed();
+                break;
+            }
+        }
+    }
+    if (!landed) {
+        HIP_OK(hipStreamSynchronize(s));
+        if (!all_landed()) return fail(-9, "%s did not deliver a result record", who);
+    }
+    return 0;
+}
+
 static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_stride, const int64_t* d_assign,
                         const esac_hip_params* p, int B, void* stream, double* d_scores_out, double* d_result_out,
                         double* h_result_out) {
@@ -513,6 +596,11 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     KArgs a;
     int rc = make_args(c, d_sc, d_assign, p, &a, B, sc_frame_stride);
     if (rc) return rc;
+    if (c->team_latched_off && ++c->solo_since_latch > ESAC_TEAM_REARM_CALLS) {  // (blocking or not: every forward call counts)
+        c->team_latched_off = false;               // try a team again; one more time-out latches at once
+        c->team_strikes = ESAC_TEAM_STRIKES - 1;
+    }
+    forward_team(c, a);
     c->host_ns[6] = t_entry;
     c->host_ns[0] = now_ns() - t_entry;
     hipStream_t s = (hipStream_t)stream;
@@ -558,6 +646,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     if ((rc = check_launch(exact ? "k_stats_exact" : "k_select_rescore"))) return rc;
     if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
     c->refine_tag = launch_refine(a, s);
+    c->refine_was_team = refine_team_members(a) > 0;
     if ((rc = check_launch("k_refine"))) return rc;
     c->host_ns[3] = now_ns() - t_entry;
     if (tm) {
@@ -571,44 +660,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     if (h_result_out) {
         // the refinement kernel stores the record and then the epoch word into pinned host memory
         // (one ESAC_PIN_DOUBLES slot per frame: record, epoch word, status word)
-        auto wait_record = [&](double want) -> int {
-            // a slot has landed when its epoch word is this call's AND its check word fits the other 34 words (the kernel
-            // stores them without a fence: esac_kernels.hpp, pin_mix)
-            auto all_landed = [&]() {
-                for (int b = 0; b < B; b++) {
-                    const volatile unsigned long long* w = reinterpret_cast<const volatile unsigned long long*>(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES);
-                    if (*(const volatile double*)(c->h_pin + (size_t)b * ESAC_PIN_DOUBLES + 32) != want) return false;
-                    unsigned long long h = 0;
-                    for (int k = 0; k < 34; k++) h ^= pin_mix(w[k], k);
-                    if (h != w[34]) return false;
-                }
-                return true;
-            };
-            bool landed = false;
-            if (c->wait_mode == ESAC_WAIT_BLOCK) {
-                HIP_OK(hipStreamSynchronize(s));
-                landed = all_landed();
-            } else {
-                const bool yield = c->wait_mode == ESAC_WAIT_YIELD;
-                for (long spins = 0; spins < 200000000L; spins++) {
-                    if (all_landed()) {
-                        landed = true;
-                        break;
-                    }
-                    if (yield) sched_yield();
-                    if ((spins & (yield ? 63 : 1023)) == (yield ? 63 : 1023) && hipStreamQuery(s) == hipSuccess) {  // stream idle: kernels are done (or failed)
-                        landed = all_landed();
-                        break;
-                    }
-                }
-            }
-            if (!landed) {
-                HIP_OK(hipStreamSynchronize(s));
-                if (!all_landed()) return fail(-9, "esac_hip_forward: the refinement kernel did not deliver a result record");
-            }
-            return 0;
-        };
-        if ((rc = wait_record(c->epoch))) return rc;
+        if ((rc = wait_record(c, s, B, c->epoch, "esac_hip_forward: the refinement kernel"))) return rc;
         c->host_ns[4] = now_ns() - t_entry;
         bool team_failed = false;
         for (int b = 0; b < B; b++) team_failed |= c->h_pin[(size_t)b * ESAC_PIN_DOUBLES + 33] == 3.0;
@@ -634,12 +686,9 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             }
             c->refine_tag = launch_refine(a, s);
             if ((rc = check_launch("k_refine (one workgroup, after a team time-out)"))) return rc;
-            if ((rc = wait_record(c->epoch))) return rc;
+            if ((rc = wait_record(c, s, B, c->epoch, "esac_hip_forward: the refinement kernel"))) return rc;
         } else if (was_team) {
             c->team_strikes = 0;
-        } else if (c->team_latched_off && ++c->solo_since_latch >= ESAC_TEAM_REARM_CALLS) {
-            c->team_latched_off = false;               // try a team again; one more time-out latches at once
-            c->team_strikes = ESAC_TEAM_STRIKES - 1;
         }
         __sync_synchronize();
         bool bad_assign = false;
@@ -675,6 +724,7 @@ extern "C" int esac_hip_time_stages(esac_hip_ctx* c, const float* d_sc, const in
     int rc = make_args(c, d_sc, d_assign, p, &a);
     if (rc) return rc;
     a.tstamps = nullptr;
+    forward_team(c, a);
     hipStream_t s = (hipStream_t)stream;
     c->rt32_stale = false;
     mark_sampling(c, a);
@@ -741,6 +791,9 @@ extern "C" int esac_hip_pick_record(esac_hip_ctx* c, const double* d_records, in
     }
     __sync_synchronize();
     memcpy(h_record_out, (const void*)c->h_pin, ESAC_RES_DOUBLES * sizeof(double));
+    if (c->h_pin[33] == 3.0)
+        return fail(-12, "esac_hip_pick_record: the refinement team of at least one rank timed out (its record carries ESAC_RES_VALID = 3); "
+                         "every rank sees the same records: run the frame again with ESAC_FLAG_REFINE_SOLO");
     if (c->h_pin[33] == 2.0) return fail(-11, "esac_hip_pick_record: no rank produced a hypothesis");
     return 0;
 }
@@ -787,7 +840,22 @@ extern "C" int esac_hip_allreduce_sum(esac_hip_ctx* c, double* d_buf, size_t cou
     if (!c || !d_buf) return fail(-1, "esac_hip_allreduce_sum: null argument");
     if (!c->comm) return fail(-13, "esac_hip_allreduce_sum: no communicator (esac_hip_comm_init)");
     DeviceGuard guard(c->device);
-    NCCL_OK(rccl().all_reduce(d_buf, d_buf, count, ncclDouble, ncclSum, c->comm, (hipStream_t)stream));
+    NCCL_OK(rccl().all_reduce(d_buf, d_buf, count, NCCL_DOUBLE, NCCL_SUM, c->comm, (hipStream_t)stream));
+    return 0;
+}
+// What the communicator ITSELF reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), beside what the context was told
+// and the GPU it is bound to: the proof a multi-GPU bench line carries of how many ranks RCCL saw (bench.py: ranks_seen).
+extern "C" int esac_hip_comm_info(esac_hip_ctx* c, int32_t out[4]) {
+    if (!c || !out) return fail(-1, "esac_hip_comm_info: null argument");
+    if (!c->comm) return fail(-13, "esac_hip_comm_info: no communicator (esac_hip_comm_init)");
+    int count = c->comm_ranks, rank = c->comm_rank, dev = -1;
+    if (rccl().comm_count) NCCL_OK(rccl().comm_count(c->comm, &count));
+    if (rccl().comm_user_rank) NCCL_OK(rccl().comm_user_rank(c->comm, &rank));
+    if (rccl().comm_cu_device) NCCL_OK(rccl().comm_cu_device(c->comm, &dev));
+    out[0] = count;
+    out[1] = rank;
+    out[2] = dev;
+    out[3] = c->device;
     return 0;
 }
 
@@ -830,12 +898,14 @@ static int ensure_bws(esac_hip_ctx* c, int N, int P, int cap) {
     rc |= alloc(&c->bws.grad1, (size_t)ncap * nP * 3);
     rc |= alloc(&c->bws.grad2, (size_t)ncap * nP * 3);
     rc |= alloc(&c->bws.out, (size_t)4);
+    rc |= alloc(&c->bws.arrived, (size_t)1);
     rc |= alloc(&c->bws.team_gran, (size_t)ncap * 2 * ESAC_REFINE_TEAM_MAX * 32 * 2);  // 16-byte granules: [slot][parity][member][value]
     if (rc) {
         free_bws(c);
         return rc;
     }
     HIP_OK(hipMemset(c->bws.n_sel, 0, 4 * sizeof(int)));
+    HIP_OK(hipMemset(c->bws.arrived, 0, sizeof(int)));
     HIP_OK(hipMemset(c->bws.team_gran, 0, (size_t)ncap * 2 * ESAC_REFINE_TEAM_MAX * 32 * 2 * sizeof(double)));
     c->bN = nN; c->bP = nP; c->bcap = ncap; c->b_lists = nlists;
     return 0;
@@ -1003,8 +1073,20 @@ extern "C" int esac_hip_check(esac_hip_ctx* c) {
     unsigned long long st = 0, coop[2] = {0, 0};
     HIP_OK(hipMemcpy(&st, c->ws.status, sizeof(st), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(coop, c->ws.coop_counter, sizeof(coop), hipMemcpyDeviceToHost));
-    if (c->refine_tag != 0 && coop[1] == c->refine_tag)  // the failure word carries the tag of the launch that failed: only the most recent one counts
+    if (c->refine_tag != 0 && coop[1] == c->refine_tag) {  // the failure word carries the tag of the launch that failed: only the most recent one counts
+        // asynchronous calls learn of a team time-out here (or from the pick of the multi-GPU exchange, whose caller then asks here):
+        // the same two-strikes latch as the blocking call's, so that a GPU whose CUs are held by someone else does not cost every
+        // frame the 1 ms wait
+        if (c->refine_was_team && c->checked_tag != c->refine_tag) {
+            c->checked_tag = c->refine_tag;
+            c->team_fallbacks++;
+            if (++c->team_strikes >= ESAC_TEAM_STRIKES && !c->team_latched_off) {
+                c->team_latched_off = true;
+                c->solo_since_latch = 0;
+            }
+        }
         return fail(-12, "the cooperating refinement workgroups of the most recent call could not synchronise (not all of them became resident)");
+    }
     if (st != 0 && (double)st == c->sample_epoch) return fail(-10, "hypAssignment held a value outside [0,E) in the most recent sampling call");
     return 0;
 }

@@ -1148,8 +1148,10 @@ __global__ __launch_bounds__(256) void k_pick_record(const double* __restrict__ 
     const int lane = threadIdx.x;
     double bs = -INFINITY, bh = INFINITY;
     int br = -1;
+    bool failed = false;  // a rank's refinement team timed out (ESAC_RES_VALID = 3): no winner may be declared without its candidate
     for (int r = lane; r < world; r += 64) {
         const double* rec = records + (size_t)r * 32;
+        failed |= rec[31] == 3.0;
         if (rec[31] != 1.0) continue;
         const double s = rec[0], h = rec[1];
         if (br < 0 || s > bs || (s == bs && h < bh)) {
@@ -1168,10 +1170,11 @@ __global__ __launch_bounds__(256) void k_pick_record(const double* __restrict__ 
             br = orr;
         }
     }
+    failed = __any(failed);
     if (lane < 32) pin[lane] = br >= 0 ? records[(size_t)br * 32 + lane] : 0.0;
     __threadfence_system();
     if (lane == 0) {
-        pin[33] = br >= 0 ? 0.0 : 2.0;  // 2: no rank contributed a record
+        pin[33] = failed ? 3.0 : br >= 0 ? 0.0 : 2.0;  // 3: a rank's team timed out; 2: no rank contributed a record
         __threadfence_system();
         *reinterpret_cast<volatile double*>(pin + 32) = epoch;
     }

@@ -34,6 +34,17 @@ __host__ __device__ inline unsigned long long pin_mix(unsigned long long bits, i
     const int r = k & 63;
     return r ? (h << r) | (h >> (64 - r)) : h;
 }
+#ifdef __HIPCC__
+// A full wavefront hands 34 words (lane k < 34: word k; word 32 = the call's epoch, 33 = status) + their check word to the pinned
+// slot: one store instruction, no fence (see above).
+__device__ __forceinline__ void pin_deliver(double* pin, double v) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long h = lane < 34 ? pin_mix((unsigned long long)__double_as_longlong(v), lane) : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o);
+    if (lane < 35) pin[lane] = lane < 34 ? v : __longlong_as_double((long long)h);
+}
+#endif
 constexpr int ESAC_FLAG_EXACT_SCORES_K = 1;  // = ESAC_FLAG_EXACT_SCORES (include/esac_hip.h)
 constexpr int ESAC_FLAG_EXACT_SAMPLING_K = 16, ESAC_FLAG_SCORES_BY_INDEX_K = 32;  // = ESAC_FLAG_* (checked in esac_capi.hip)
 constexpr int ESAC_SELECT_SPLIT = 16;          // cell ranges (workgroups) per contender in k_select_rescore when H*W >= 32768
@@ -78,6 +89,8 @@ struct BwdArgs {
                                      // on the device -- not of what an earlier call selected
     double* team_gran;               // [cap][2][32][32] granules (16 B each) of the slots' exchanges
     unsigned long long team_tag;     // tag of the slot-team launch: the downstream kernels skip their work when it failed
+    int* arrived;                    // [1] workgroups of k_bwd_accumulate that are done: the last one delivers the call's record to the
+                                     // pinned slot (KArgs::result_pin) and leaves this at zero
 };
 
 struct KArgs {

@@ -499,16 +499,14 @@ __device__ __forceinline__ void refine_write_record(const KArgs& a, const Record
     const double v = lane < 34 ? s_rec[lane] : 0.0;
     if (lane < 32) {
         a.result[lane] = v;
-        // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" from a record; never set on a failed one
-        if (a.result_user) a.result_user[lane] = lane == 31 ? (coop_failed ? 0.0 : 1.0) : v;
+        // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" (0) from a record (1); 3 = the workgroups sharing this
+        // refinement timed out -- not a record either, but one the consumer must not take for an empty shard (k_pick_record: -12)
+        if (a.result_user) a.result_user[lane] = lane == 31 ? (coop_failed ? 3.0 : 1.0) : v;
     }
     if (a.result_pin) {
         // straight into pinned host memory (the host polls instead of waiting for a copy kernel + stream-completion signal:
         // ~15-20 us of a blocking call's latency), 34 words + their check word, no fence (esac_kernels.hpp: pin_mix)
-        unsigned long long h = lane < 34 ? pin_mix((unsigned long long)__double_as_longlong(v), lane) : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o);
-        if (lane < 35) a.result_pin[lane] = lane < 34 ? v : __longlong_as_double((long long)h);
+        pin_deliver(a.result_pin, v);
     }
 }
 

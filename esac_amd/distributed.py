@@ -28,6 +28,12 @@ import torch
 import torch.distributed as dist
 
 RES_SCORE, RES_HYP, RES_DOUBLES = 0, 1, 32
+RES_VALID = RES_DOUBLES - 1  # slot 31 of a device record: 1 = a record, 0 = none (empty shard), 3 = the rank's refinement team timed out
+
+
+class TeamTimeout(RuntimeError):
+    """The refinement team of at least one rank did not synchronise (ESAC_RES_VALID = 3 in its record, status -12 of the pick):
+    no winner was declared.  Every rank reads the same all-reduced records, so every rank raises this for the same frame."""
 
 
 def shard_range(n_total, rank, world):
@@ -101,12 +107,16 @@ def pick_global(buf, n_total, world, engine=None, zero=None):
         except RuntimeError as exc:
             if "no rank produced" in str(exc):
                 raise RuntimeError("esac: no rank produced a hypothesis")
+            if "[status -12]" in str(exc):
+                raise TeamTimeout(str(exc))
             raise
     recs = buf[n_total:].view(world, RES_DOUBLES).cpu().numpy()
+    if (recs[:, RES_VALID] == 3.0).any():
+        raise TeamTimeout("esac: the refinement team of rank(s) %s timed out" % np.nonzero(recs[:, RES_VALID] == 3.0)[0].tolist())
     best = None
     for r in range(world):
         rec = recs[r]
-        if rec[RES_DOUBLES - 1] != 1.0:
+        if rec[RES_VALID] != 1.0:
             continue  # empty shard
         if best is None or rec[RES_SCORE] > best[RES_SCORE] or (rec[RES_SCORE] == best[RES_SCORE] and rec[RES_HYP] < best[RES_HYP]):
             best = rec
@@ -127,13 +137,26 @@ class _Exchange:
 
     def __init__(self, dev, n_total, world):
         self.bufs = [torch.zeros(n_total + world * RES_DOUBLES, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.clean = [True, True]  # all-zero and not handed out since
         self.turn = 0
 
-    def take(self):
-        """(this call's buffer, the next call's buffer)"""
-        cur, nxt = self.bufs[self.turn], self.bufs[self.turn ^ 1]
+    def take(self, need_zero=True):
+        """(this call's buffer, the next call's buffer).  A buffer is clean when the pick launch of the previous call has cleared
+        it (`cleared`); a call that ended early -- an exception between here and its pick -- leaves the other one holding the
+        all-reduced data of the call before, and the next taker clears it itself.  need_zero=False: the caller overwrites every
+        slot (one rank: the whole buffer is its own)."""
+        i = self.turn
+        cur, nxt = self.bufs[i], self.bufs[i ^ 1]
+        if need_zero and not self.clean[i]:
+            cur.zero_()
+        self.clean[i] = False
         self.turn ^= 1
+        self._next = i ^ 1
         return cur, nxt
+
+    def cleared(self):
+        """The pick launch of the call that took last has run with zero=<its next buffer>."""
+        self.clean[self._next] = True
 
 
 def _exchange(dev, n_total, world):
@@ -207,29 +230,47 @@ def native_comm(engine, group=None):
     the per-frame collective is one C call that enqueues ncclAllReduce on the launch stream -- torch.distributed's own enqueue
     of a collective costs the host 20-27 us per call (bench.py: sharded_world1).  Only for backend "nccl" (one rank per GPU);
     None when the group is gloo (CPU tests, several ranks sharing one GPU), when ESAC_NATIVE_RCCL=0, or when joining failed (the
-    torch.distributed all-reduce -- RCCL as well -- then carries the exchange)."""
+    torch.distributed all-reduce -- RCCL as well -- then carries the exchange).
+    Every rank runs the SAME sequence of control-plane collectives whatever fails where: (1) every rank probes that the library
+    can bind RCCL (rank 0's probe IS the id), (2) broadcast of (id or None), (3) MIN over "I can join" -- only then
+    ncclCommInitRank, which blocks until all ranks are in it -- (4) MIN over "I joined"."""
     import os
     if _native["off"] or os.environ.get("ESAC_NATIVE_RCCL", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
         return None
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if engine._comm == (world, rank):
+    key = (id(group) if group is not None else None, tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)))
+    if engine._comm == (world, rank) and engine._comm_key == key:
         return engine
     why = None
+    my_id = None
     try:
-        box = [engine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        engine.comm_init(world, rank, box[0])
-    except Exception as exc:  # keep the exchange alive on the torch.distributed route
+        my_id = engine.comm_unique_id()  # also the probe that RCCL can be bound in this process
+    except Exception as exc:
         why = str(exc)
-    # every rank takes the same route: one rank that could not join sends all of them to torch.distributed (once, control plane)
-    joined = torch.tensor([0 if why else 1], dtype=torch.int32, device=engine.device)
-    dist.all_reduce(joined, op=dist.ReduceOp.MIN, group=group)
-    if int(joined.item()) == 1:
-        return engine
+    box = [my_id if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if box[0] is None and why is None:
+        why = "rank 0 could not make an RCCL unique id"
+
+    def all_agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=engine.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) == 1
+
+    joined = False
+    if all_agree(why is None):
+        try:
+            engine.comm_init(world, rank, box[0])
+            engine._comm_key = key
+            joined = True
+        except Exception as exc:
+            why = str(exc)
+        if all_agree(joined):
+            return engine
     import warnings
     warnings.warn("esac: RCCL communicator of the library could not be set up on every rank (%s); using torch.distributed.all_reduce"
                   % (why or "another rank failed"))
-    if why is None:
+    if joined:
         engine.comm_destroy()
     _native["off"] = True
     return None
@@ -267,6 +308,22 @@ def owned_experts(E, rank, world):
 
 
 def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None, policy="range", maps="full", timers=None):
+    """forward_sharded_once, and once more with every rank refining in ONE workgroup (ESAC_FLAG_REFINE_SOLO) when a rank's
+    refinement team timed out: the calls of a multi-rank exchange are asynchronous (no rank waits for its own record before the
+    collective), so the blocking call's own recovery does not apply -- the failed record travels through the all-reduce
+    (ESAC_RES_VALID = 3), the pick refuses to declare a winner (-12) on EVERY rank alike, and every rank comes back here.  The
+    rank whose team it was counts the strike (esac_hip_check): two in a row and its context stops asking for teams."""
+    try:
+        return forward_sharded_once(engine, scene_coords, hyp_assign_full, params_kw, group, policy, maps, timers)
+    except TeamTimeout:
+        try:
+            engine.check()  # (-12 on the rank whose team failed: counted towards the latch there; other ranks pass)
+        except RuntimeError:
+            pass
+        return forward_sharded_once(engine, scene_coords, hyp_assign_full, dict(params_kw, refine_solo=True), group, policy, maps, timers)
+
+
+def forward_sharded_once(engine, scene_coords, hyp_assign_full, params_kw, group=None, policy="range", maps="full", timers=None):
     """Multi-GPU esac_forward: every rank holds `scene_coords` (or only its experts' maps) and the full assignment
     vector; returns (scores_global [N] f64 device tensor, winning record np[32]).
 
@@ -290,7 +347,8 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
     dev = engine.device
     if policy == "range":
         # the returned score vector is a view of a persistent buffer: valid until the call after the next on this device
-        buf, nxt = _exchange(dev, n_total, world).take()
+        ex = _exchange(dev, n_total, world)
+        buf, nxt = ex.take(need_zero=world > 1)
         if world == 1:
             # one rank: its record IS the winner -- the refinement kernel hands it to the host itself (no pick launch, no second
             # wait); the collective still runs (a one-rank RCCL all-reduce on the launch stream: the dtype / stream path N ranks take)
@@ -303,7 +361,7 @@ def forward_sharded(engine, scene_coords, hyp_assign_full, params_kw, group=None
         contribute_range(engine, scene_coords, ha_full, params_kw, rank, world, buf, zero=False)
         if dist.is_initialized():
             _all_reduce_sum(buf, group, timers, engine)  # the one collective of this path
-        return pick_global(buf, n_total, world, engine, zero=nxt)
+        return _pick_and_clear(ex, buf, nxt, n_total, world, engine)
     if policy == "balanced":
         return _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, group, maps, timers)
     if policy != "expert":
@@ -350,11 +408,29 @@ _balanced_ws = {}
 def _forward_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, group, maps, timers):
     """policy "balanced": contribute_balanced, one all-reduce, device-side pick."""
     n_total = int(ha_full.shape[0])
-    buf, nxt = _exchange(engine.device, n_total, world).take()
+    ex = _exchange(engine.device, n_total, world)
+    buf, nxt = ex.take()
     contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps, timers, buf=buf)
     if dist.is_initialized():  # (also in a one-rank group: the collective's dtype / stream path is then the one N ranks take)
         _all_reduce_sum(buf, group, timers, engine)  # the one collective of this path
-    return pick_global(buf, n_total, world, engine, zero=nxt)
+    return _pick_and_clear(ex, buf, nxt, n_total, world, engine)
+
+
+def _pick_and_clear(ex, buf, nxt, n_total, world, engine):
+    """The winner pick that ends a call of the alternating pair; its launch clears `nxt` -- also when it refuses to declare a
+    winner (TeamTimeout: the kernel has run)."""
+    try:
+        out = pick_global(buf, n_total, world, engine, zero=nxt)
+    except TeamTimeout:
+        if buf.is_cuda:
+            ex.cleared()
+        raise
+    if buf.is_cuda:
+        ex.cleared()
+    else:
+        nxt.zero_()
+        ex.cleared()
+    return out
 
 
 def contribute_balanced(engine, scene_coords, ha_full, params_kw, total_experts, rank, world, maps="full", timers=None, buf=None):

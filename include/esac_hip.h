@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESAC_HIP_ABI_VERSION 5
+#define ESAC_HIP_ABI_VERSION 6
 
 /* reference compile-time constants (esac.cpp:44-45) */
 #define ESAC_MAX_SAMPLING_TRIES 1000000
@@ -101,6 +101,10 @@ typedef struct esac_hip_params {
  * the contenders is several times faster there).  esac.forward() of the Python module sets it unless told otherwise. */
 #define ESAC_FLAG_AUTO_EXACT 64
 #define ESAC_AUTO_EXACT_MAX_WORK (1 << 21) /* N * H * W up to which ESAC_FLAG_AUTO_EXACT applies */
+/* The winner is refined by ONE workgroup whatever the shape (no team on one XCD, no cooperating workgroups): the route that
+ * needs no co-residency of several workgroups.  What a blocking call falls back to by itself after a team time-out; a caller of
+ * ASYNCHRONOUS calls (the multi-GPU exchange: esac_hip_pick_record returned -12) sets it to run the frame again. */
+#define ESAC_FLAG_REFINE_SOLO 128
 
 #define ESAC_DEFAULT_MARGIN 1e-3f
 
@@ -119,7 +123,8 @@ enum {
     ESAC_RES_CONTENDERS = 29,/* how many hypotheses were re-scored exactly                       */
     ESAC_RES_LM_ITERS = 30,  /* total LM iterations spent in refinement                          */
     ESAC_RES_VALID = 31,     /* d_result_out only: 1.0 once a record has been written (multi-GPU exchange buffers
-                                are zero-padded; the host copy carries the inlier-map buffer index here instead) */
+                                are zero-padded; the host copy carries the inlier-map buffer index here instead);
+                                3.0: the workgroups sharing the refinement timed out -- no record, and not an empty shard */
     ESAC_RES_DOUBLES = 32
 };
 
@@ -212,7 +217,9 @@ int esac_hip_forward_batch(esac_hip_ctx* ctx, int B, const float* d_scene_coords
  * ESAC_RES_DOUBLES doubles each (device), e.g. the tail of the all-reduced buffer [N scores | world records] with
  * all-zero records for ranks without hypotheses (ESAC_RES_VALID marks real ones).  Picks the global winner -- highest
  * exact score, lowest global hypothesis index on ties (esac_util.h:519) -- on the device and delivers it to
- * h_record_out (blocking, through pinned memory).  -11: no rank contributed a record.
+ * h_record_out (blocking, through pinned memory).  -11: no rank contributed a record.  -12: the refinement team of at least one
+ * rank timed out (ESAC_RES_VALID = 3 in its record): no winner is declared without that rank's candidate; every rank reads the
+ * same records and gets the same status, so all of them run the frame again with ESAC_FLAG_REFINE_SOLO (esac_amd/distributed.py).
  * d_zero / n_zero: optional (NULL / 0) device doubles the same launch sets to 0 -- a caller that alternates between two
  * exchange buffers hands over the one the NEXT call will use, so that no call starts with a memset of its own.
  */
@@ -233,6 +240,9 @@ int esac_hip_comm_unique_id(void* out_id, size_t bytes);
 int esac_hip_comm_init(esac_hip_ctx* ctx, int nranks, int rank, const void* unique_id, size_t bytes);
 int esac_hip_comm_destroy(esac_hip_ctx* ctx);
 int esac_hip_allreduce_sum(esac_hip_ctx* ctx, double* d_buf, size_t count, void* stream);
+/* What the context's communicator ITSELF reports: out[0] = ncclCommCount, out[1] = ncclCommUserRank, out[2] = ncclCommCuDevice
+ * (-1 when the loaded RCCL lacks the query), out[3] = the context's GPU.  -13: no communicator.  (bench.py: `ranks_seen`.) */
+int esac_hip_comm_info(esac_hip_ctx* ctx, int32_t out[4]);
 
 /*
  * Load-balanced multi-GPU shard, built on the device (new; SURVEY.md 8e: "a load-balanced assignment from the
@@ -292,7 +302,7 @@ int esac_hip_score_exact(esac_hip_ctx* ctx, const float* d_scene_coords, const i
  * _backward) met a hypAssignment value outside [0,E), -12 when the workgroups sharing its most recent winner refinement
  * could not synchronise (blocking calls report the former themselves and, when a small-grid team timed out, run the
  * refinement again in one workgroup; asynchronous ones -- no host result pointer -- cannot: their device record then
- * lacks ESAC_RES_VALID), else 0.
+ * carries ESAC_RES_VALID = 3 and this function counts the time-out towards the same two-in-a-row latch), else 0.
  * Out-of-range values never cause an out-of-bounds read: such hypotheses are evaluated against expert 0. */
 int esac_hip_check(esac_hip_ctx* ctx);
 

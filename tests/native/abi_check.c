@@ -144,6 +144,8 @@ int main(int argc, char** argv) {
         int (*p_esac_hip_comm_init)(esac_hip_ctx*, int, int, const void*, size_t);
         int (*p_esac_hip_comm_destroy)(esac_hip_ctx*);
         int (*p_esac_hip_allreduce_sum)(esac_hip_ctx*, double*, size_t, void*);
+        int (*p_esac_hip_comm_info)(esac_hip_ctx*, int32_t*);
+        RESOLVE(esac_hip_comm_info);
         RESOLVE(esac_hip_comm_unique_id);
         RESOLVE(esac_hip_comm_init);
         RESOLVE(esac_hip_comm_destroy);
@@ -158,6 +160,11 @@ int main(int argc, char** argv) {
             fprintf(stderr, "communicator: %s\n", p_esac_hip_last_error());
             return 20;
         }
+        int32_t info[4] = {-9, -9, -9, -9};
+        if (p_esac_hip_comm_info(ctx, info) != 0 || info[0] != 1 || info[1] != 0 || info[3] != 0 || (info[2] != 0 && info[2] != -1)) {
+            fprintf(stderr, "comm info: %d %d %d %d (%s)\n", info[0], info[1], info[2], info[3], p_esac_hip_last_error());
+            return 25;
+        }
         for (int rep = 0; rep < 3; rep++)
             if (p_esac_hip_allreduce_sum(ctx, (double*)d_buf, 288, NULL) != 0) {
                 fprintf(stderr, "all-reduce: %s\n", p_esac_hip_last_error());
@@ -167,6 +174,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 288; i++)
             if (back[i] != h[i]) return 23;
         if (p_esac_hip_comm_destroy(ctx) != 0 || p_esac_hip_allreduce_sum(ctx, (double*)d_buf, 288, NULL) != -13) return 24;
+        if (p_esac_hip_comm_info(ctx, info) != -13) return 26;
         hipFree_(d_buf);
         printf("comm ok: one-rank RCCL communicator, all-reduce of 288 doubles in place\n");
     }

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_functions():
         assert hasattr(lib, name), name
     lib.esac_hip_abi_version.restype = C.c_int
-    assert lib.esac_hip_abi_version() == api.ABI_VERSION == 5
+    assert lib.esac_hip_abi_version() == api.ABI_VERSION == 6
     # no torch / pybind in the ABI: the shared object must not depend on libtorch or libpython
     import subprocess
     deps = subprocess.run(["ldd", path], capture_output=True, text=True).stdout

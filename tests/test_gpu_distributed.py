@@ -223,6 +223,124 @@ def test_forward_sharded_across_processes_on_one_device(engine, world, policy):
             np.testing.assert_array_equal(scores_g, results[0][i][0])  # every rank holds the same global score vector
 
 
+def _stalled_rank_worker(rank, world, port, q):
+    """forward_sharded in `world` processes sharing the GPU (gloo group); rank 1's refinement teams never fill
+    (ESAC_DEBUG_COOP_STALL): its record travels as ESAC_RES_VALID = 3, the pick refuses on every rank, every rank runs the frame
+    again with ESAC_FLAG_REFINE_SOLO."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        eng = api.Engine(0)
+        if rank == 1:
+            eng.set_debug(coop_stall=True)
+        f = S.make_frame(64)
+        ha = torch.from_numpy(S.gating_assignment(f, 256)).cuda()
+        sc = torch.from_numpy(f["coords"]).cuda()
+        out = []
+        for call in (30, 31, 32):
+            scores_g, best = D.forward_sharded(eng, sc, ha, dict(seed=1305, call=call), policy="range")
+            out.append((best.copy(), eng.refine_info()))
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_team_timeout_of_one_rank_is_retried_by_every_rank(engine):
+    """The advisor's round-5 finding: at several ranks the forward calls are asynchronous, so a team time-out on one rank used to
+    leave that rank's record without ESAC_RES_VALID and the winner came silently from the others.  Now the pick refuses (-12)
+    on every rank alike and all of them repeat the frame with one workgroup per refinement; the failing rank's context counts
+    the strikes and latches after two."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stalled_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f = S.make_frame(64)
+    ha = torch.from_numpy(S.gating_assignment(f, 256)).cuda()
+    sc = torch.from_numpy(f["coords"]).cuda()
+    engine.set_refine_team(0)
+    try:
+        for i, call in enumerate((30, 31, 32)):
+            res = engine.forward_device(sc, ha, engine.make_params(1, 60, 80, 256, seed=1305, call=call))
+            for rank in range(2):
+                best, info = results[rank][i]
+                assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]), (rank, call)
+                assert best[api.RES_SCORE] == res[api.RES_SCORE]
+                np.testing.assert_allclose(best[api.RES_POSE:api.RES_POSE + 16], res[api.RES_POSE:api.RES_POSE + 16], rtol=0, atol=1e-6)
+    finally:
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
+    info1 = [info for _, info in results[1]]
+    assert info1[0]["team_fallbacks"] == 1 and not info1[0]["team_latched_off"], info1
+    assert info1[1]["team_fallbacks"] == 2 and info1[1]["team_latched_off"], info1
+    assert info1[2]["team_fallbacks"] == 2 and info1[2]["mode"] == "one_workgroup" and not info1[2]["timed_out"], info1  # latched: no wait
+    assert all(info["team_fallbacks"] == 0 for _, info in results[0])  # the healthy rank only repeats the frame
+
+
+def test_failed_record_is_not_an_empty_shard(engine):
+    """k_pick_record / pick_global: a record with ESAC_RES_VALID = 3 (team time-out) stops the pick (TeamTimeout) -- on the
+    device and in the host scan of a CPU buffer; the same frame with ESAC_FLAG_REFINE_SOLO on every rank gives the plain call's
+    winner."""
+    f = S.make_frame(65)
+    ha = torch.from_numpy(S.gating_assignment(f, 256)).cuda()
+    sc = torch.from_numpy(f["coords"]).cuda()
+    kw = dict(seed=1305, call=40)
+    world, n_total = 2, 256
+
+    def exchange(params_kw, stall_rank=None):
+        total = torch.zeros(n_total + world * D.RES_DOUBLES, dtype=torch.float64, device="cuda")
+        for rank in range(world):
+            engine.set_debug(coop_stall=rank == stall_rank)
+            buf = torch.empty_like(total)
+            D.contribute_range(engine, sc, ha, params_kw, rank, world, buf)
+            total += buf
+        engine.set_debug()
+        return total
+
+    try:
+        total = exchange(kw, stall_rank=1)
+        assert float(total[n_total + D.RES_DOUBLES + D.RES_VALID]) == 3.0 and float(total[n_total + D.RES_VALID]) == 1.0
+        with pytest.raises(D.TeamTimeout):
+            D.pick_global(total, n_total, world, engine)
+        with pytest.raises(D.TeamTimeout):
+            D.pick_global(total.cpu(), n_total, world)
+        total = exchange(dict(kw, refine_solo=True), stall_rank=1)  # the stall cannot bite: no team is asked for
+        _, best = D.pick_global(total, n_total, world, engine)
+        assert engine.refine_info()["mode"] == "one_workgroup"
+    finally:
+        engine.set_debug()
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
+    res = engine.forward_device(sc, ha, engine.make_params(1, 60, 80, n_total, **kw))
+    assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]) and best[api.RES_SCORE] == res[api.RES_SCORE]
+    np.testing.assert_allclose(best[api.RES_POSE:api.RES_POSE + 16], res[api.RES_POSE:api.RES_POSE + 16], rtol=0, atol=1e-6)
+
+
+def test_exchange_pair_survives_a_call_that_ended_early(engine):
+    """_Exchange: a call that raises between take() and its pick leaves the OTHER buffer holding the all-reduced data of the call
+    before; the next taker clears it (dirty flag) instead of summing stale scores and records into the new frame."""
+    ex = D._Exchange(torch.device("cuda", 0), 8, 2)
+    cur, nxt = ex.take()
+    cur.fill_(5.0)          # call i: its data, all-reduced
+    nxt.zero_(); ex.cleared()  # ... and its pick cleared the buffer of call i + 1
+    cur2, nxt2 = ex.take()  # call i + 1 starts (clean buffer) ...
+    assert cur2.data_ptr() == nxt.data_ptr() and float(cur2.abs().sum()) == 0.0
+    cur2.fill_(7.0)         # ... and dies before its pick: nxt2 (= call i's buffer) was never cleared
+    cur3, _ = ex.take()     # call i + 2 gets call i's buffer: cleared on take
+    assert cur3.data_ptr() == cur.data_ptr() and float(cur3.abs().sum()) == 0.0
+
+
 def _run_bench(world, extra):
     import json
     import subprocess
@@ -252,6 +370,33 @@ def test_bench_multi_rank_path_on_one_device():
     assert d["value"] > 0 and abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "batched" not in d and "cpu_baseline" not in d  # single-GPU extras only
     assert d["allreduce_ms"] is not None and d["allreduce_ms"] > 0
+    assert d["ranks_seen"] == 2 and d["devices"] == [0, 0] and d["launcher"] == "external"
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it (how the driver's scaling sweep may call it): bench.py starts the two
+    ranks itself and relays rank 0's one JSON line -- n_gpus is the number of ranks that ran, ranks_seen what their exchange's
+    communicator reported, devices the GPU of every rank.  More GPUs than the node has: a non-zero exit, never a one-GPU line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ESAC_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["devices"] == [0, 0] and len(d["rank_reports"]) == 2
+    assert sorted(r["rank"] for r in d["rank_reports"]) == [0, 1] and len({r["pid"] for r in d["rank_reports"]}) == 2
+    assert "bench.py itself" in d["launcher"] and d["config"]["hypotheses_total"] == 512
+    env.pop("ESAC_BENCH_ONE_DEVICE")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "9", "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "--gpus 9" in out.stderr
 
 
 @pytest.mark.parametrize("world", [2, 3])

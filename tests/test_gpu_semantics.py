@@ -460,7 +460,7 @@ def test_cooperative_refinement_reports_a_barrier_time_out(engine):
         engine.forward_device(sc, hat, p, result_out=rec, want_host=False)
         with pytest.raises(RuntimeError, match="status -12"):
             engine.check()
-        assert float(rec[31]) == 0.0  # no ESAC_RES_VALID on a failed record
+        assert float(rec[31]) == 3.0  # ESAC_RES_VALID = 3: not a record, and not an empty shard either
     finally:
         engine.set_debug()
     again = engine.forward_device(sc, hat, p)
@@ -569,7 +569,7 @@ def test_refinement_team_time_out_falls_back_to_one_workgroup(engine, oracle):
         engine.forward_device(sc, hat, p, result_out=dev_rec, want_host=False)
         with pytest.raises(RuntimeError, match="status -12"):
             engine.check()
-        assert float(dev_rec[31]) == 0.0  # no ESAC_RES_VALID on a failed record
+        assert float(dev_rec[31]) == 3.0  # ESAC_RES_VALID = 3: not a record, and not an empty shard either
     finally:
         engine.set_debug()
         engine.set_refine_team(api.REFINE_TEAM_DEFAULT)

@@ -141,12 +141,76 @@ __global__ __launch_bounds__(B) void k_bwd_loss(KArgs a) {
 // One workgroup per slot.  jacobeanR = -(J^T J)^-1 J^T over the inliers of the last accepted refinement step
 // (rows = d residual norm / d pose at the refined pose), clamped to zero as a whole when any entry exceeds 10;
 // the slab entry of inlier q is dLoss (1x6) * jacobeanR[:, q] * dProject/dObj (1x3).
+// The rare branch of path I: J^T J is rank deficient to rounding (inv_spd6 returned false) -- the reference's own route,
+// the SVD pseudo-inverse (bwd_math.hpp:pinv_sym6_jacobi: the same operations in the same order).  Here it must cost the
+// common path nothing: ONE lane runs rolled loops over matrices in LDS (a few hundred bytes of code, no registers beyond the
+// loop's own -- unrolled into registers it took the kernel to 480 of them and one wavefront per SIMD), the others wait.  Every
+// lane reaches this together (U21 is the same in all of them), so the barriers are uniform.  lds: >= 108 doubles.
+__device__ __forceinline__ void pinv_sym6_lds(const double (&U21)[21], double (&Ainv)[36], double* lds) {
+    double* A = lds;        // [6][6]
+    double* V = lds + 36;   // [6][6]
+    double* out = lds + 72; // [6][6]
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = i; j < 6; j++) {
+                A[i * 6 + j] = U21[k];
+                A[j * 6 + i] = U21[k];
+                k++;
+            }
+        for (int i = 0; i < 36; i++) V[i] = (i % 7 == 0) ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 60; sweep++) {
+            double off = 0;
+            for (int i = 0; i < 6; i++)
+                for (int j = i + 1; j < 6; j++) off += A[i * 6 + j] * A[i * 6 + j];
+            if (off == 0) break;
+            for (int p = 0; p < 6; p++)
+                for (int q = p + 1; q < 6; q++) {
+                    const double apq = A[p * 6 + q];
+                    const double theta = (A[q * 6 + q] - A[p * 6 + p]) / (2 * apq);
+                    double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                    if (!(fabs(theta) <= 1.7976931348623157e308)) t = 0;  // apq negligible (theta = inf / nan)
+                    if (apq == 0) t = 0;                                   // identity rotation = the reference's `continue`
+                    const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                    for (int m = 0; m < 6; m++) {
+                        const double akp = A[m * 6 + p], akq = A[m * 6 + q];
+                        A[m * 6 + p] = c * akp - sn * akq;
+                        A[m * 6 + q] = sn * akp + c * akq;
+                    }
+                    for (int m = 0; m < 6; m++) {
+                        const double apk = A[p * 6 + m], aqk = A[q * 6 + m];
+                        A[p * 6 + m] = c * apk - sn * aqk;
+                        A[q * 6 + m] = sn * apk + c * aqk;
+                    }
+                    for (int m = 0; m < 6; m++) {
+                        const double vkp = V[m * 6 + p], vkq = V[m * 6 + q];
+                        V[m * 6 + p] = c * vkp - sn * vkq;
+                        V[m * 6 + q] = sn * vkp + c * vkq;
+                    }
+                }
+        }
+        double thresh = 0;
+        for (int i = 0; i < 6; i++) thresh += fabs(A[i * 7]);
+        thresh *= 2 * 2.220446049250313e-16;
+        for (int i = 0; i < 36; i++) out[i] = 0;
+        for (int m = 0; m < 6; m++) {
+            const double w = A[m * 7];
+            if (!(fabs(w) > thresh)) continue;
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 6; j++) out[i * 6 + j] += V[i * 6 + m] * V[j * 6 + m] / w;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 36; i++) Ainv[i] = out[i];
+    __syncthreads();
+}
+
 template <int B>
-__global__ __launch_bounds__(B) void k_bwd_path1(KArgs a) {
-    __shared__ double s_part[28 * (B / 64)];
-    __shared__ double s_tot[28];
-    __shared__ double s_max[B / 64];
-    const int slot = blockIdx.x;
+__device__ __forceinline__ void bwd_path1(const KArgs& a, int slot, double* s_part, double* s_tot, double* s_max) {
     if (slot >= a.bwd.n_sel[0]) return;
     const int h = a.bwd.sel[slot];
     const int P = a.H * a.W;
@@ -183,7 +247,7 @@ __global__ __launch_bounds__(B) void k_bwd_path1(KArgs a) {
     }
     block_sum28<21, B>(U, s_part, s_tot);
     double Ainv[36];
-    if (!inv_spd6(U, Ainv)) pinv_sym6_jacobi(U, Ainv);  // workgroup-uniform: every lane holds the same sums
+    if (!inv_spd6(U, Ainv)) pinv_sym6_lds(U, Ainv, s_part);  // workgroup-uniform: every lane holds the same sums
     double dL[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) dL[k] = a.bwd.dloss[(size_t)slot * 6 + k];
@@ -239,13 +303,7 @@ __global__ __launch_bounds__(B) void k_bwd_path1(KArgs a) {
 // with a float step of 1e-3, esac_derivative.h:128-185).  sum_cells (dRE * dErr/dPose) * dPose/dObj is linear in the
 // per-cell term, so the 6 pose-space sums are reduced first and multiplied with the 6x12 dPNP matrix once.
 template <int B>
-__global__ __launch_bounds__(B) void k_bwd_path2(KArgs a) {
-    __shared__ double s_part[28 * (B / 64)];
-    __shared__ double s_tot[28];
-    __shared__ double s_sol[18][6];
-    __shared__ double s_J[72];
-    __shared__ int s_bad;
-    const int slot = blockIdx.x;
+__device__ __forceinline__ void bwd_path2(const KArgs& a, int slot, double* s_part, double* s_tot, double (*s_sol)[6], double* s_J, int& s_bad) {
     if (slot >= a.bwd.n_sel[0]) return;
     const int h = a.bwd.sel[slot];
     const int P = a.H * a.W;
@@ -360,6 +418,24 @@ __global__ __launch_bounds__(B) void k_bwd_path2(KArgs a) {
     }
 }
 
+// ================================================================= K7 + K8 in ONE launch
+// Neither path reads the other's output (path I: the refined pose, its inlier set, dLoss; path II: the initial hypothesis, its four
+// cells, d E / d score), and with a few dozen slots either one is a chain one workgroup long on an otherwise empty chip: workgroups
+// [0, slots) take path I, [slots, 2 slots) path II -- 47 + 36 us in sequence became max(path I, path II), with no second stream
+// and no event between them (round 6 measured that variant: the fork and the join cost 7 us each).
+template <int B>
+__global__ __launch_bounds__(B) void k_bwd_paths(KArgs a) {
+    __shared__ double s_part[28 * (B / 64) > 108 ? 28 * (B / 64) : 108];
+    __shared__ double s_tot[28];
+    __shared__ double s_max[B / 64];
+    __shared__ double s_sol[18][6];
+    __shared__ double s_J[72];
+    __shared__ int s_bad;
+    const int slots = (int)gridDim.x >> 1;
+    if ((int)blockIdx.x < slots) bwd_path1<B>(a, (int)blockIdx.x, s_part, s_tot, s_max);
+    else                         bwd_path2<B>(a, (int)blockIdx.x - slots, s_part, s_tot, s_sol, s_J, s_bad);
+}
+
 // ================================================================= K9: ordered accumulation into the float tensor
 // grid = (tiles of 3P elements, experts).  Wavefront 0 first compacts, in slot order, the slots whose hypothesis
 // belongs to this expert (ballot prefix) together with their probabilities into LDS; then one thread per tensor
@@ -443,13 +519,8 @@ static inline int slot_grid(const KArgs& a) { return a.N < a.bwd.cap ? a.N : a.b
 
 void launch_bwd_select(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bwd_select<1024>, dim3(1), dim3(1024), 0, s, a); }
 void launch_bwd_loss(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_bwd_loss<BWD_B>, dim3(1), dim3(BWD_B), 0, s, a); }
-void launch_bwd_path1(const KArgs& a, hipStream_t s) {
-    // 4 wavefronts: one per SIMD, so the rare Jacobi pseudo-inverse (~150 live registers on top of the pose state) fits
-    // the 512-register file instead of spilling onto the common path
-    hipLaunchKernelGGL(k_bwd_path1<256>, dim3(slot_grid(a)), dim3(256), 0, s, a);
-}
-void launch_bwd_path2(const KArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_bwd_path2<BWD_B>, dim3(slot_grid(a)), dim3(BWD_B), 0, s, a);
+void launch_bwd_paths(const KArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_bwd_paths<BWD_B>, dim3(2 * slot_grid(a)), dim3(BWD_B), 0, s, a);
 }
 void launch_bwd_accumulate(const KArgs& a, hipStream_t s) {
     const int per_expert = 3 * a.H * a.W;

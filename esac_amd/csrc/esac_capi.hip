@@ -111,8 +111,6 @@ struct esac_hip_ctx {
     long long tPart = 0;
     bool rt32_stale = false;  // esac_hip_write_hyps ran: the fp32 [R|t] rows are rebuilt by the next esac_hip_score
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // esac_hip_host_turn: where the host's time of the most recent blocking forward went
-    hipStream_t side = nullptr;  // esac_hip_backward: path II runs here, beside path I on the caller's stream (ensure_side)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     ncclComm_t comm = nullptr;  // esac_hip_comm_init: this context's rank in an RCCL communicator (the multi-GPU score exchange)
     int comm_ranks = 0, comm_rank = 0;
 };
@@ -240,9 +238,6 @@ extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     free_bws(c);
     if (c->sc4) (void)hipFree(c->sc4);
     drop_comm(c);
-    if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -1034,22 +1029,26 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
         if ((rc = check_launch("k_refine(slots)"))) return rc;
         launch_bwd_loss(a, s);                                      // esac.cpp:354-362 + dLoss + softmax derivative
         if ((rc = check_launch("k_bwd_loss"))) return rc;
-        launch_bwd_path1(a, s);                                     // esac.cpp:375-463
-        if ((rc = check_launch("k_bwd_path1"))) return rc;
-        launch_bwd_path2(a, s);                                     // esac.cpp:470-488
-        if ((rc = check_launch("k_bwd_path2"))) return rc;
-        launch_bwd_accumulate(a, s);                                // esac.cpp:491-508
+        launch_bwd_paths(a, s);                                     // esac.cpp:375-463 (path I) and :470-488 (path II), side by side
+        if ((rc = check_launch("k_bwd_paths"))) return rc;
+        // the last workgroup of the accumulation hands the call's record (h_out's four values + "a slot team timed out") to the
+        // pinned slot: no copies, no stream-completion round trip (two hipMemcpyAsync + hipStreamSynchronize before)
+        KArgs acc = a;
+        acc.result_pin = h_out ? c->d_pin : nullptr;
+        launch_bwd_accumulate(acc, s);                              // esac.cpp:491-508
         if ((rc = check_launch("k_bwd_accumulate"))) return rc;
         if (!h_out) return 0;
-        HIP_OK(hipMemcpyAsync(h_out, a.bwd.out, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-        unsigned long long failed_tag = 0;
-        if (teams) HIP_OK(hipMemcpyAsync(&failed_tag, a.coop_counter + 1, sizeof(failed_tag), hipMemcpyDeviceToHost, s));
-        HIP_OK(hipStreamSynchronize(s));
-        if (teams && failed_tag == a.bwd.team_tag) {  // a team timed out: nothing was accumulated; one workgroup per slot from here on
+        if ((rc = wait_record(c, s, 1, a.epoch, "esac_hip_backward: the accumulation kernel"))) return rc;
+        __sync_synchronize();
+        for (int k = 0; k < 4; k++) h_out[k] = c->h_pin[k];
+        const bool team_failed = c->h_pin[4] == 1.0;
+        if (teams && team_failed) {  // a team timed out: nothing was accumulated; one workgroup per slot from here on
             c->slot_team_fallbacks++;
             c->slot_teams = false;
             use_teams = false;
             attempt--;
+            c->epoch += 1.0;
+            a.epoch = c->epoch;
             continue;
         }
         c->last_nsel = (int)h_out[1];
@@ -1057,6 +1056,8 @@ extern "C" int esac_hip_backward(esac_hip_ctx* c, const float* d_sc, float* d_ou
         const int needed = (int)h_out[1];
         if (needed <= cap || attempt >= 1) break;  // one retry suffices: the second pass is sized by the true count
         cap = needed + 31 > worst ? worst : (needed + 31) / 32 * 32;
+        c->epoch += 1.0;
+        a.epoch = c->epoch;
     }
     if (h_out[3] != 0.0)
         return fail(-10, "hypAssignment holds a value outside [0,%d) (device-resident tensor; such hypotheses were scored against expert 0)", p->E);

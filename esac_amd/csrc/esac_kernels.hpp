@@ -205,8 +205,7 @@ bool refine_slots_can_team(const KArgs& a);            // grid fits a team of 8 
 unsigned long long launch_refine_slots_team(KArgs& a, hipStream_t s);  // esac_refine_team.hip; sets a.bwd.team_tag, returns it
 void launch_bwd_select(const KArgs& a, hipStream_t s);
 void launch_bwd_loss(const KArgs& a, hipStream_t s);
-void launch_bwd_path1(const KArgs& a, hipStream_t s);
-void launch_bwd_path2(const KArgs& a, hipStream_t s);
+void launch_bwd_paths(const KArgs& a, hipStream_t s);  // path I and path II of every slot, one launch
 void launch_bwd_accumulate(const KArgs& a, hipStream_t s);
 
 }  // namespace esac

@@ -30,6 +30,8 @@ BUF_BWD_PROBS, BUF_BWD_LOSSES, BUF_BWD_REF_HYPS, BUF_BWD_SCORE_GRADS, BUF_BWD_SL
 BUF_BWD_PATH1, BUF_BWD_PATH2 = 17, 18
 BUF_REFINE_INFO = 19
 BUF_BWD_TEAM_INFO = 20
+BUF_SPEC_INFO = 21
+BUF_SPEC_FLAGS = 22
 REFINE_TEAM_MAX, REFINE_TEAM_DEFAULT = 32, 8
 MAX_REF_STEPS = 100
 BWD_MAX_SLOTS = 1000
@@ -49,7 +51,7 @@ FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS, FLAG_EXA
 FLAG_AUTO_EXACT = 64
 FLAG_REFINE_SOLO = 128
 WAIT_SPIN, WAIT_YIELD, WAIT_BLOCK = 0, 1, 2
-DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL, DEBUG_TEAM_SPREAD = 1, 2, 4
+DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL, DEBUG_TEAM_SPREAD, DEBUG_NO_SPECULATION = 1, 2, 4, 8
 
 
 class Params(C.Structure):
@@ -300,7 +302,7 @@ class Engine:
             BUF_SCORES: ((N,), np.float64), BUF_RESULT: ((RES_DOUBLES,), np.float64),
             BUF_INLIER_MAP: ((H, W), np.uint8), BUF_INLIER_COUNTS: ((MAX_REF_STEPS + 1,), np.int32),
             BUF_WINNER_ERRS: ((H, W), np.float32), BUF_EXACT_FLAGS: ((N,), np.uint8),
-            BUF_CYCLES: ((32,), np.int64), BUF_REFINE_INFO: ((8,), np.int32), BUF_BWD_TEAM_INFO: ((4,), np.int32),
+            BUF_CYCLES: ((32,), np.int64), BUF_REFINE_INFO: ((8,), np.int32), BUF_BWD_TEAM_INFO: ((4,), np.int32), BUF_SPEC_INFO: ((4,), np.int32), BUF_SPEC_FLAGS: ((N,), np.uint8),
             BUF_BWD_PROBS: ((N,), np.float64), BUF_BWD_LOSSES: ((N,), np.float64), BUF_BWD_REF_HYPS: ((N, 6), np.float64),
             BUF_BWD_SCORE_GRADS: ((N,), np.float64), BUF_BWD_SLOTS: ((N,), np.int32),
             BUF_BWD_SLOT_INFO: ((min(N, BWD_MAX_SLOTS), 4), np.int32), BUF_BWD_DLOSS: ((min(N, BWD_MAX_SLOTS), 6), np.float64),
@@ -357,9 +359,14 @@ class Engine:
         """Waits for the device; raises if the most recent (asynchronous) call met an out-of-range hypAssignment."""
         _check(self.lib.esac_hip_check(self.ctx), self.lib)
 
-    def set_debug(self, keep_error_image=False, coop_stall=False, team_spread=False):
+    def set_debug(self, keep_error_image=False, coop_stall=False, team_spread=False, no_speculation=False):
         _check(self.lib.esac_hip_set_debug(self.ctx, (DEBUG_ERROR_IMAGE if keep_error_image else 0) | (DEBUG_COOP_STALL if coop_stall else 0) |
-                                           (DEBUG_TEAM_SPREAD if team_spread else 0)), self.lib)
+                                           (DEBUG_TEAM_SPREAD if team_spread else 0) | (DEBUG_NO_SPECULATION if no_speculation else 0)), self.lib)
+
+    def spec_info(self):
+        """The speculative forward route (several experts: the straggler chain beside the refinement; ESAC_BUF_SPEC_INFO)."""
+        v = self.read(BUF_SPEC_INFO)
+        return {"calls": int(v[0]), "failures": int(v[1]), "last_speculative": bool(v[2]), "last_failed": bool(v[3])}
 
     def set_refine_team(self, members=REFINE_TEAM_DEFAULT):
         """Workgroups that share the winner's refinement on a small single-frame grid (0 / 1: one workgroup;

@@ -111,6 +111,13 @@ struct esac_hip_ctx {
     long long tPart = 0;
     bool rt32_stale = false;  // esac_hip_write_hyps ran: the fp32 [R|t] rows are rebuilt by the next esac_hip_score
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // esac_hip_host_turn: where the host's time of the most recent blocking forward went
+    // speculative forward (forward_impl): the straggler chain of the sampler runs on this stream beside the launch stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool spec_off = false, spec_env_off = false;  // ESAC_DEBUG_NO_SPECULATION / ESAC_SPECULATE=0
+    bool spec_events = false;             // the two streams hand over through events instead of polled words (ESAC_SPEC_EVENTS=1: A/B)
+    long long spec_calls = 0;             // forward calls that took the speculative route
+    double last_spec_epoch = 0;           // epoch of the most recent speculative call (0: the most recent forward was not)
     ncclComm_t comm = nullptr;  // esac_hip_comm_init: this context's rank in an RCCL communicator (the multi-GPU score exchange)
     int comm_ranks = 0, comm_rank = 0;
 };
@@ -186,7 +193,8 @@ static void free_ws(esac_hip_ctx* c) {
     void* ptrs[] = {c->ws.hyps,       c->ws.hyps_R,      c->ws.rt32,         c->ws.sample_xy, c->ws.tries,      c->ws.samp_resume, c->ws.samp_round, c->ws.best_try, c->ws.samp_cand, c->ws.samp_entries, c->ws.samp_count, c->ws.samp_pending, c->ws.fast_scores,
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.sel_partials, c->ws.sel_arrived, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
-                    c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.refine_info, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials, c->ws.bucket_fill};
+                    c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.refine_info, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials, c->ws.bucket_fill,
+                    c->ws.spec_flag,  c->ws.spec_state};
     c->tN = c->tChunks = 0;
     c->tPart = 0;
     for (void* p : ptrs)
@@ -217,6 +225,8 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
     }
     if (const char* e = getenv("ESAC_FOLD_SELECT")) c->fold_select = atoi(e) != 0;
     if (const char* e = getenv("ESAC_SLOT_TEAMS")) c->slot_teams = atoi(e) != 0;
+    if (const char* e = getenv("ESAC_SPECULATE")) c->spec_off = c->spec_env_off = atoi(e) == 0;
+    if (const char* e = getenv("ESAC_SPEC_EVENTS")) c->spec_events = atoi(e) != 0;
     *out = c;
     return 0;
 }
@@ -238,6 +248,9 @@ extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     free_bws(c);
     if (c->sc4) (void)hipFree(c->sc4);
     drop_comm(c);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -304,11 +317,15 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.cycles, (size_t)32);
     rc |= alloc(&c->ws.tstamps, (size_t)nN * 2);
     rc |= alloc(&c->ws.span_acc, (size_t)2);
+    rc |= alloc(&c->ws.spec_flag, (size_t)nN);
+    rc |= alloc(&c->ws.spec_state, (size_t)8);
     if (rc) {
         if (old_hyps) (void)hipFree(old_hyps);
         return rc;
     }
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
+    HIP_OK(hipMemset(c->ws.spec_flag, 0, (size_t)nN));
+    HIP_OK(hipMemset(c->ws.spec_state, 0, 8 * sizeof(double)));
     HIP_OK(hipMemset(c->ws.coop_counter, 0, 2 * sizeof(unsigned long long)));  // [1]: tag of the last failed shared refinement (esac_hip_check)
     HIP_OK(hipMemset(c->ws.coop_partials, 0, (size_t)ESAC_TEAM_BATCH_MAX * ESAC_TEAM_GRANULES * 2 * sizeof(double)));  // (also the teams' granules)
     HIP_OK(hipMemset(c->ws.refine_info, 0, 8 * sizeof(int)));
@@ -448,6 +465,10 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     a.team = c->team;  // (the forward entry points fold the time-out latch in: forward_team)
     a.team_stride = c->team_spread ? 1 : 8;
     a.solo = 0;
+    a.spec_mode = 0;
+    a.spec_gate = 0;
+    a.spec_flags = 0;
+    a.spec_flag = nullptr;  // (forward_impl hands the flags to the kernels of a speculative call only)
     a.samp_cap = (int)(((long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP) > 0x7fffffffLL ? 0x7fffffff : (long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP);
     a.flags = p->flags;
     c->epoch += 1.0;  // every call gets its own epoch: result hand-off word and the tag of the status word
@@ -617,33 +638,109 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         probe.tstamps = nullptr;
         if (c->fold_select && refine_folds_select(probe)) a.tstamps = nullptr;
     }
+    // Several experts: the sampler's straggler chain (wrong-expert hypotheses, which practically never win) runs BESIDE the scoring,
+    // selection and refinement of what the first pass settled (KArgs::spec_mode; k_spec_join makes the outputs the serial order's)
+    // (not where the selection runs in the refinement kernel's prologue -- a single frame of <= 256 hypotheses on a team: that
+    // route re-scores its contenders member by member, another summation order than k_select_rescore's and k_spec_join's)
+    const bool spec = !c->spec_off && B == 1 && !exact && sample_can_split(a) && !a.partials && (long long)a.H * a.W < 32768 &&
+                      !(c->fold_select && refine_folds_select(a));
+    c->last_spec_epoch = 0;
+    if (spec && !c->side) {
+        HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
     c->rt32_stale = false;
     mark_sampling(c, a);
-    launch_sample(a, s);
-    if ((rc = check_launch("k_sample"))) return rc;
-    c->host_ns[1] = now_ns() - t_entry;
-    if (tm) HIP_OK(hipEventRecord(c->ev[1], s));
-    // ESAC_FLAG_EXACT_SCORES: every hypothesis scored in the reference's arithmetic (esac_util.h:235-260), softmax
-    // statistics from those scores -- the score vector, probability and entropy are then the reference's own values
-    if (exact) launch_rescore_all(a, s);
-    else       launch_score(a, s);
-    if ((rc = check_launch(exact ? "k_rescore(all)" : "k_score_fast"))) return rc;
-    c->host_ns[2] = now_ns() - t_entry;
-    if (tm) HIP_OK(hipEventRecord(c->ev[2], s));
-    // a single frame of <= 256 hypotheses that a team refines: the selection runs in that kernel's prologue
-    a.fold_select = !c->fold_select ? 0 : refine_folds_select(a) ? 1 : refine_folds_exact_stats(a) ? 2 : 0;
-    if (exact) {
-        if (a.fold_select != 2) launch_stats_exact(a, s);
-    } else if (!a.fold_select) {
-        launch_select_rescore(a, s);
+    if (spec) {
+        c->spec_calls++;
+        c->last_spec_epoch = a.epoch;
+        a.tstamps = nullptr;
+        a.fold_select = 0;
+        a.spec_flag = c->ws.spec_flag;
+        KArgs chain;
+        int chain_waves = 0;
+        launch_sample_split(a, s, &chain, &chain_waves);
+        if ((rc = check_launch("k_sample (first pass)"))) return rc;
+        c->host_ns[1] = now_ns() - t_entry;
+        if (tm) HIP_OK(hipEventRecord(c->ev[1], s));
+        // The two streams hand over through WORDS in device memory (spec_state[3]: "the chain may start", [4]: "the chain is
+        // done"), not through events: an event between two streams costs the waiting side 8-13 us on this platform even when it is
+        // long satisfied.  Whoever waits is enqueued BEHIND the launch it waits for (host order below), so that even two
+        // streams that share a hardware queue cannot wait for each other; every wait is bounded in wall time.
+        const bool flags = !c->spec_events;
+        a.spec_flags = flags ? 1 : 0;
+        KArgs as = a;  // the settled hypotheses: score, selection, refinement of their winner -- no record leaves the workspace
+        as.spec_mode = 1;
+        as.result_user = nullptr;
+        as.result_pin = nullptr;
+        launch_score(as, s);
+        if ((rc = check_launch("k_score_fast (settled)"))) return rc;
+        c->host_ns[2] = now_ns() - t_entry;
+        if (tm) HIP_OK(hipEventRecord(c->ev[2], s));
+        // The chain starts when the speculative refinement has its CUs, not when the first pass is done: its thousands of
+        // single-wavefront workgroups fill every SIMD of the chip, and whatever the launch stream starts while it is in full
+        // swing finds no CU to run on until it has drained (measured: started behind the first pass, the selection took 27 us
+        // instead of 10; started behind the score kernel, the refinement's team waited 34 us for its CUs).
+        launch_select_rescore(as, s, flags ? nullptr : c->ev_fork);
+        if ((rc = check_launch("k_select_rescore (settled)"))) return rc;
+        if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
+        c->refine_tag = launch_refine(as, s);  // (its first workgroup opens the chain: spec_open_chain)
+        c->refine_was_team = refine_team_members(as) > 0;
+        if ((rc = check_launch("k_refine (speculative)"))) return rc;
+        if (flags) {
+            launch_spec_wait(a, 3, c->side);
+            launch_sample_stragglers_on(chain, chain_waves, c->side);
+        } else if (int e = launch_sample_chain(chain, chain_waves, c->side, c->ev_fork)) {
+            return fail(-100 - e, "hipStreamWaitEvent: %s", hipGetErrorString((hipError_t)e));
+        }
+        launch_score_stragglers(a, c->side, flags ? nullptr : c->ev_join);  // behind the chain on the side stream
+        if (flags) launch_spec_set(a, 4, c->side);
+        if ((rc = check_launch("straggler chain"))) return rc;
+        if (!flags) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
+        KArgs aj = a;
+        aj.spec_gate = 2;
+        launch_spec_join(aj, s);
+        if ((rc = check_launch("k_spec_join"))) return rc;
+        {
+            // The second refinement is enqueued NOW and returns at once unless the join marked the speculation as failed
+            // (KArgs::spec_gate): a failed speculation then costs the refinement, not a host round trip on top of it (and an
+            // asynchronous call could not look at the join's verdict anyway); a speculation that held has delivered its record
+            // before this launch starts
+            KArgs ag = a;
+            ag.spec_gate = 1;
+            const unsigned long long tag2 = launch_refine(ag, s);
+            (void)tag2;  // (esac_hip_check follows the speculative launch's tag: a team time-out there is the common case of the two)
+            if ((rc = check_launch("k_refine (gated)"))) return rc;
+        }
+        c->host_ns[3] = now_ns() - t_entry;
+    } else {
+        launch_sample(a, s);
+        if ((rc = check_launch("k_sample"))) return rc;
+        c->host_ns[1] = now_ns() - t_entry;
+        if (tm) HIP_OK(hipEventRecord(c->ev[1], s));
+        // ESAC_FLAG_EXACT_SCORES: every hypothesis scored in the reference's arithmetic (esac_util.h:235-260), softmax
+        // statistics from those scores -- the score vector, probability and entropy are then the reference's own values
+        if (exact) launch_rescore_all(a, s);
+        else       launch_score(a, s);
+        if ((rc = check_launch(exact ? "k_rescore(all)" : "k_score_fast"))) return rc;
+        c->host_ns[2] = now_ns() - t_entry;
+        if (tm) HIP_OK(hipEventRecord(c->ev[2], s));
+        // a single frame of <= 256 hypotheses that a team refines: the selection runs in that kernel's prologue
+        a.fold_select = !c->fold_select ? 0 : refine_folds_select(a) ? 1 : refine_folds_exact_stats(a) ? 2 : 0;
+        if (exact) {
+            if (a.fold_select != 2) launch_stats_exact(a, s);
+        } else if (!a.fold_select) {
+            launch_select_rescore(a, s);
+        }
+        if ((rc = check_launch(exact ? "k_stats_exact" : "k_select_rescore"))) return rc;
+        if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
+        c->refine_tag = launch_refine(a, s);
+        c->refine_was_team = refine_team_members(a) > 0;
+        if ((rc = check_launch("k_refine"))) return rc;
+        c->host_ns[3] = now_ns() - t_entry;
     }
-    if ((rc = check_launch(exact ? "k_stats_exact" : "k_select_rescore"))) return rc;
-    if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
-    c->refine_tag = launch_refine(a, s);
-    c->refine_was_team = refine_team_members(a) > 0;
-    if ((rc = check_launch("k_refine"))) return rc;
-    c->host_ns[3] = now_ns() - t_entry;
     if (tm) {
         HIP_OK(hipEventRecord(c->ev[4], s));
         // an EMPTY interval: what two adjacent hipEventRecord calls measure with nothing in between,
@@ -656,6 +753,15 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         // the refinement kernel stores the record and then the epoch word into pinned host memory
         // (one ESAC_PIN_DOUBLES slot per frame: record, epoch word, status word)
         if ((rc = wait_record(c, s, B, c->epoch, "esac_hip_forward: the refinement kernel"))) return rc;
+        if (spec && c->h_pin[33] == 5.0) {
+            // the context's own stream never reported the straggler chain as done within 20 ms (it shares a hardware queue with
+            // the caller's stream and something else is holding that queue, or its launch failed): no more speculation on this
+            // context, and this call again -- the serial route
+            c->spec_off = c->spec_env_off = true;
+            HIP_OK(hipStreamSynchronize(c->side));
+            HIP_OK(hipStreamSynchronize(s));
+            return forward_impl(c, d_sc, sc_frame_stride, d_assign, p, B, stream, d_scores_out, d_result_out, h_result_out);
+        }
         c->host_ns[4] = now_ns() - t_entry;
         bool team_failed = false;
         for (int b = 0; b < B; b++) team_failed |= c->h_pin[(size_t)b * ESAC_PIN_DOUBLES + 33] == 3.0;
@@ -1142,10 +1248,23 @@ extern "C" int esac_hip_read(esac_hip_ctx* c, int which, void* h_dst, size_t byt
             if (!c->keep_errs) return fail(-6, "esac_hip_read: the error image is only kept after esac_hip_set_debug(ctx, ESAC_DEBUG_ERROR_IMAGE)");
             src = c->ws.errs; want = P * sizeof(float); break;
         case ESAC_BUF_EXACT_FLAGS: src = c->ws.exact_flag; want = N; break;
+        case ESAC_BUF_SPEC_FLAGS: src = c->ws.spec_flag; want = N; break;
         case ESAC_BUF_CYCLES: src = c->ws.cycles; want = 32 * sizeof(long long); break;
         case ESAC_BUF_BWD_TEAM_INFO: {
             if (bytes != 4 * sizeof(int32_t)) return fail(-7, "esac_hip_read: the slot-team info holds 16 bytes, caller asked for %zu", bytes);
             const int32_t info[4] = {c->last_bwd_teams ? 1 : 0, (int32_t)c->slot_team_calls, (int32_t)c->slot_team_fallbacks, (int32_t)c->last_nsel};
+            memcpy(h_dst, info, sizeof(info));
+            return 0;
+        }
+        case ESAC_BUF_SPEC_INFO: {
+            if (bytes != 4 * sizeof(int32_t)) return fail(-7, "esac_hip_read: the speculation info holds 16 bytes, caller asked for %zu", bytes);
+            double st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (c->ws.spec_state) {
+                HIP_OK(hipDeviceSynchronize());
+                HIP_OK(hipMemcpy(st, c->ws.spec_state, sizeof(st), hipMemcpyDeviceToHost));
+            }
+            const int32_t info[4] = {(int32_t)c->spec_calls, (int32_t)st[2], c->last_spec_epoch != 0 ? 1 : 0,
+                                     c->last_spec_epoch != 0 && st[0] == c->last_spec_epoch ? 1 : 0};
             memcpy(h_dst, info, sizeof(info));
             return 0;
         }
@@ -1216,6 +1335,7 @@ extern "C" int esac_hip_set_debug(esac_hip_ctx* c, int flags) {
     c->keep_errs = (flags & ESAC_DEBUG_ERROR_IMAGE) != 0;
     c->coop_stall = (flags & ESAC_DEBUG_COOP_STALL) != 0;
     c->team_spread = (flags & ESAC_DEBUG_TEAM_SPREAD) != 0;
+    c->spec_off = c->spec_env_off || (flags & ESAC_DEBUG_NO_SPECULATION) != 0;
     return 0;
 }
 

@@ -21,7 +21,9 @@
 // those exact scores (first index on ties, esac_util.h:519).  All discrete decisions of refinement (inlier tests,
 // stopping rule) use the exact arithmetic.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "pose_math.hpp"
 #include "p3p_screen.hpp"
@@ -159,6 +161,7 @@ __device__ __forceinline__ void mark_pending(const KArgs& a, int h, int e, bool 
     base = __shfl(base, leader);
     if (!mine) return;
     a.tries[h] = SAMPLE_PENDING;
+    if (a.spec_flag) a.spec_flag[h] = 1;  // speculative forward: a straggler -- the launch stream's kernels leave it alone
     a.best_try[h] = ~0ull;          // k_sample_decide: lowest accepted try << 32 | its list position
     a.samp_resume[h] = 0x7fffffff;  // k_sample_prescreen: first try not screened yet
     a.samp_round[h] = 0;
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(1024) void k_pending_list(KArgs a) {
         flag_bad_assignment(a, h);
         a.tries[h] = SAMPLE_PENDING;
     }
+    if (a.spec_flag && h < a.N) a.spec_flag[h] = mine ? 1 : 0;  // speculative forward: what the first pass settled / left to the chain
     const unsigned long long m = __ballot(mine);
     if (lane == 0) s_wave[wave] = __popcll(m);
     const bool stats = expert_stats_on(a);  // assigned / pending per expert (see expert_stats)
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(SAMPLE_B) void k_sample(KArgs a) {
         }
         if (writer >= 0) {
             if (t == writer && holder) store_hypothesis(a, h, map, rvec, T, R, cx, cy, tries_val);
+            if (a.spec_flag && threadIdx.x == 0) a.spec_flag[h] = 0;  // settled by this pass
             return;
         }
         if (base + TRIES >= a.handover) {  // a straggler (wrong expert): the spread, screened search takes over from here
@@ -838,6 +843,7 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
     __shared__ float s_w[B / 64];
     frame_view(a);
     const int h = blockIdx.x;
+    if (a.spec_mode && (a.spec_mode == 1) == (a.spec_flag[h] != 0)) return;  // speculative forward: the settled / the stragglers only
     // optional device-side span measurement (timing mode): the kernel's duration is
     // max(end) - min(start) over its workgroups, on the constant 100 MHz wall clock
     long long t_start = 0;
@@ -916,9 +922,14 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
     frame_view(a);
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
+    // speculative forward (spec_mode 1): the selection among the hypotheses the sampler's first pass settled -- a straggler has
+    // no pose and no score yet; it keeps out of the maximum, the band and the statistics, and nothing of it is written but
+    // exact_flag = 0 (k_spec_join completes the picture when the straggler chain is done)
+    const bool spec = a.spec_mode == 1;
+    auto fast_score = [&](int i) { return spec && a.spec_flag[i] ? -INFINITY : a.fast_scores[i]; };
     // max (NaN-ignoring)
     float m = -INFINITY;
-    for (int i = threadIdx.x; i < a.N; i += B) m = fmaxf(m, a.fast_scores[i]);
+    for (int i = threadIdx.x; i < a.N; i += B) m = fmaxf(m, fast_score(i));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
@@ -941,11 +952,13 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
     for (int j0 = 0; blockIdx.x + (long long)gridDim.x * j0 < a.N; j0 += B) {
         int nc;
         if (single) {
-            const float fs = a.fast_scores[blockIdx.x];  // workgroup-uniform
+            const float fs = fast_score(blockIdx.x);  // workgroup-uniform
             nc = fs >= band ? 1 : 0;
             if (!nc && threadIdx.x == 0 && z == 0) {
-                a.scores[blockIdx.x] = (double)fs;
-                if (a.scores_user) a.scores_user[user_slot(a, blockIdx.x)] = (double)fs;
+                if (!(spec && a.spec_flag[blockIdx.x])) {
+                    a.scores[blockIdx.x] = (double)fs;
+                    if (a.scores_user) a.scores_user[user_slot(a, blockIdx.x)] = (double)fs;
+                }
                 a.exact_flag[blockIdx.x] = 0;
             }
         } else {
@@ -954,12 +967,14 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
             const long long hh = blockIdx.x + (long long)gridDim.x * (j0 + threadIdx.x);
             if (hh < a.N) {
                 const int h = (int)hh;
-                const float fs = a.fast_scores[h];
+                const float fs = fast_score(h);
                 if (fs >= band) {
                     s_cont[atomicAdd(&s_nc, 1)] = h;  // at most B entries per pass
                 } else if (z == 0) {
-                    a.scores[h] = (double)fs;
-                    if (a.scores_user) a.scores_user[user_slot(a, h)] = (double)fs;
+                    if (!(spec && a.spec_flag[h])) {
+                        a.scores[h] = (double)fs;
+                        if (a.scores_user) a.scores_user[user_slot(a, h)] = (double)fs;
+                    }
                     a.exact_flag[h] = 0;
                 }
             }
@@ -1018,6 +1033,7 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
     // softmax statistics (esac_util.h:461-497) from the fp32-path scores, in double; number of contenders
     double acc[3] = {0, 0, 0};
     for (int i = threadIdx.x; i < a.N; i += B) {
+        if (spec && a.spec_flag[i]) continue;
         const float s = a.fast_scores[i];
         const double d = (double)s - (double)m;
         const double ex = exp(d);
@@ -1062,6 +1078,268 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
         }
     }
 }
+
+// ================================================================= speculative forward: the join
+// The launch stream has scored, selected among and refined the winner of the hypotheses the sampler's first pass SETTLED; the
+// straggler chain and the stragglers' fp32 scores have finished beside it.  This kernel (ONE workgroup, the arithmetic of
+// k_select_rescore<1024, true> statement by statement, so that every number is the serial route's) completes the selection over
+// ALL hypotheses:
+//   * fp32 maximum and band over all of them; a settled hypothesis that was a contender of the narrower (settled-only) band but is
+//     not one of the final band gets its fp32 score back (what the serial route leaves there); a straggler outside the band gets
+//     its fp32 score, one inside is re-scored in reference arithmetic (esac_util.h:235-260) -- practically never: stragglers are
+//     wrong-expert hypotheses;
+//   * softMax / entropy statistics over all fp32 scores (esac_util.h:461-497), number of contenders;
+//   * draw's argmax over the exact scores of the final band, first global index on ties (esac_util.h:512-529).
+// It is the speculative winner (what else, with stragglers that score a hundredth of it): the record the refinement left in the
+// workspace gets the final probability / entropy / contender count and goes to the caller (device record, pinned host slot).
+// Otherwise spec_state[0] = this call's epoch: a blocking call reads status 4 from the pinned slot and launches the refinement
+// again (the workspace now holds exactly what k_select_rescore would have left: refine_pick_winner finds the true winner); an
+// asynchronous call has that launch enqueued already, gated on this word.
+// Hand-off words instead of events (KArgs::spec_flags): an event between two streams costs the waiting side 8-13 us on this
+// platform even when it is long satisfied (scripts/dev/fork_join.hip, profiles/r06_*timeline*), a polled word ~1 us.
+// The waits are bounded in wall time: a word that never comes (the other stream's launch failed) costs ESAC_SPEC_WAIT_TICKS, is
+// counted in spec_state[5] and reported by the join (status 5) -- never a hang.
+constexpr long long ESAC_SPEC_WAIT_TICKS = 2000000;  // 20 ms of the 100 MHz wall clock
+__device__ __forceinline__ bool spec_wait_word(const KArgs& a, int which) {
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(a.spec_state + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > ESAC_SPEC_WAIT_TICKS) return false;
+    }
+    return true;
+}
+__global__ __launch_bounds__(64) void k_spec_wait(KArgs a, int which) {
+    if (threadIdx.x == 0 && !spec_wait_word(a, which)) a.spec_state[5] += 1.0;  // (timed out: the chain runs late, the results stay right)
+}
+__global__ __launch_bounds__(64) void k_spec_set(KArgs a, int which) {
+    if (threadIdx.x == 0) __hip_atomic_store(a.spec_state + which, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_spec_wait(const KArgs& a, int which, hipStream_t s) { hipLaunchKernelGGL(k_spec_wait, dim3(1), dim3(64), 0, s, a, which); }
+void launch_spec_set(const KArgs& a, int which, hipStream_t s) { hipLaunchKernelGGL(k_spec_set, dim3(1), dim3(64), 0, s, a, which); }
+
+template <int B>
+__global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
+    constexpr int K = ESAC_FIRST_WIDE_MAX / B;  // hypotheses per thread (sample_can_split: N <= ESAC_FIRST_WIDE_MAX)
+    __shared__ double s_part[3 * (B / 64)];
+    __shared__ double s_tot[3];
+    __shared__ float s_max[B / 64];
+    __shared__ int s_nc;
+    __shared__ int s_cont[B];
+    __shared__ double s_best[B / 64];
+    __shared__ int s_besti[B / 64], s_bestg[B / 64];
+    const int P = a.H * a.W;
+    const Cam cam = make_cam(a);
+    // this thread's hypotheses h = threadIdx.x + k B (the order in which k_select_rescore's threads walk them), loaded once: the
+    // kernel is a handful of dependent passes over a few thousand values, and every pass that goes back to memory is a
+    // round trip on the critical path of the call
+    float fs[K];
+    double sc0[K];  // (and the score each hypothesis holds now: the winner pick below then needs no second trip to memory)
+    uint8_t strag[K], exact[K];
+    __shared__ int s_chain_ok;
+    if (threadIdx.x == 0) {
+        s_nc = 0;
+        // the straggler chain and the stragglers' scores are the OTHER stream's: wait for its "done" word (events: the stream
+        // order in front of this launch has waited already)
+        s_chain_ok = !a.spec_flags || spec_wait_word(a, 4);
+    }
+    __syncthreads();
+    if (a.spec_flags) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the other stream's kernels wrote, not what this CU's caches hold
+    const bool chain_ok = s_chain_ok != 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int h = (int)threadIdx.x + k * B;
+        const bool in = h < a.N;
+        fs[k] = in ? a.fast_scores[h] : -INFINITY;
+        sc0[k] = in ? a.scores[h] : 0.0;
+        strag[k] = in ? a.spec_flag[h] : 0;
+        exact[k] = in ? a.exact_flag[h] : 0;
+    }
+    // (the record the speculative refinement left, its status word: the last wavefront-0 steps of this kernel need them)
+    const double rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < K; k++) m = fmaxf(m, fs[k]);  // (-inf for the slots beyond N: fmaxf ignores them like the loop bound does)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = s_max[0];
+#pragma unroll
+    for (int k = 1; k < B / 64; k++) m = fmaxf(m, s_max[k]);
+    const float band = m - a.margin;
+    // the final band: stragglers inside it are listed for the exact re-score (practically never any); what is outside it and
+    // holds an exact score of the narrower band -- or is a straggler -- gets its fp32 score
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int h = (int)threadIdx.x + k * B;
+        if (h >= a.N) continue;
+        if (fs[k] >= band) {
+            if (strag[k]) {
+                const int pos = atomicAdd(&s_nc, 1);
+                if (pos < B) s_cont[pos] = h;  // (more than B of them: the overflow pass below)
+            }
+        } else if (strag[k] || exact[k]) {
+            a.scores[h] = (double)fs[k];
+            if (a.scores_user) a.scores_user[user_slot(a, h)] = (double)fs[k];
+            a.exact_flag[h] = 0;
+            exact[k] = 0;
+        }
+    }
+    __syncthreads();
+    const int n_list = s_nc;
+    for (int pass = 0; pass * B < n_list; pass++) {
+        if (pass > 0) {  // beyond B stragglers inside the band: list the next B in thread order (never seen; kept for completeness)
+            __syncthreads();
+            if (threadIdx.x == 0) s_nc = 0;
+            __syncthreads();
+            for (int k = 0; k < K; k++) {
+                const int h = (int)threadIdx.x + k * B;
+                if (h < a.N && fs[k] >= band && strag[k] && !a.exact_flag[h]) {
+                    const int pos = atomicAdd(&s_nc, 1);
+                    if (pos < B) s_cont[pos] = h;
+                }
+            }
+            __syncthreads();
+        }
+        const int nc = min(pass == 0 ? n_list : s_nc, B);
+        for (int ci = 0; ci < nc; ci++) {
+            // (the order of the list is whatever the atomics made it: every entry is re-scored by the whole workgroup, one after the other)
+            const int hc = s_cont[ci];
+            const int e = expert_of(a, hc);
+            const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
+            const double* hp = a.hyps + (size_t)hc * 6;
+            const double t[3] = {hp[3], hp[4], hp[5]};
+            double R[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) R[k] = a.hyps_R[(size_t)hc * 9 + k];
+            double acc[1] = {0};
+            for (int i = threadIdx.x; i < P; i += B) {
+                const int row = i / a.W, col = i - row * a.W;
+                float err = project_exact_err(R, t, cam, mx[i], mx[P + i], mx[2 * P + i], cell_px(a, col), cell_py(a, row));
+                err = err < a.max_reproj ? err : a.max_reproj;  // std::min(l, maxReproj), esac_util.h:358
+                acc[0] += soft_inlier_exact(err, a.tau, a.beta);
+            }
+            block_sum<1, B>(acc, s_part, s_tot);
+            if (threadIdx.x == 0) {
+                const float scale = a.alpha / a.W / a.H;
+                double sc = acc[0];
+                sc *= scale;  // double *= float
+                a.scores[hc] = sc;
+                if (a.scores_user) a.scores_user[user_slot(a, hc)] = sc;
+                a.exact_flag[hc] = 1;
+            }
+            __syncthreads();
+        }
+    }
+    if (n_list > 0) {  // (workgroup-uniform) the re-scored stragglers' flags, as this thread's registers hold them
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if (strag[k] && fs[k] >= band) exact[k] = 1;
+    }
+    // softmax statistics over ALL fp32-path scores (k_select_rescore's own loop and reduction)
+    double acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if ((int)threadIdx.x + k * B >= a.N) continue;
+        const float s = fs[k];
+        const double d = (double)s - (double)m;
+        const double ex = exp(d);
+        acc[0] += ex;
+        acc[1] += ex * d;
+        acc[2] += (s >= band) ? 1.0 : 0.0;
+    }
+    block_sum<3, B>(acc, s_part, s_tot);
+    const double entropy = log2(acc[0]) - acc[1] / (acc[0] * 0.6931471805599453);
+    if (threadIdx.x == 0) {
+        a.n_contenders[0] = (int)acc[2];
+        a.stats[0] = (double)m;
+        a.stats[1] = acc[0];
+        a.stats[2] = entropy;
+    }
+    // draw(probs, training=false): refine_pick_winner's rule over the final band
+    double bs = -INFINITY;
+    int bi = 0x7fffffff, bg = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int h = (int)threadIdx.x + k * B;
+        if (h >= a.N || !exact[k]) continue;
+        const int g = global_hyp(a, h);
+        const double s = strag[k] ? a.scores[h] : sc0[k];  // (a straggler inside the band: re-scored by this kernel)
+        if (s > bs || (s == bs && g < bg)) {
+            bs = s;
+            bi = h;
+            bg = g;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(bs, o);
+        const int oi = __shfl_xor(bi, o);
+        const int og = __shfl_xor(bg, o);
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_best[threadIdx.x >> 6] = bs;
+        s_besti[threadIdx.x >> 6] = bi;
+        s_bestg[threadIdx.x >> 6] = bg;
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    bs = s_best[0];
+    bi = s_besti[0];
+    bg = s_bestg[0];
+#pragma unroll
+    for (int w = 1; w < B / 64; w++) {
+        const double os = s_best[w];
+        const int og = s_bestg[w];
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = s_besti[w];
+            bg = og;
+        }
+    }
+    const int win = bi == 0x7fffffff ? 0 : bi;  // (no contender at all -- every score NaN: hypothesis 0, as refine_pick_winner)
+    const double win_score = bi == 0x7fffffff ? a.scores[0] : bs;
+    const int lane = threadIdx.x;
+    const double status = !chain_ok ? 5.0 : __shfl(rec_pre, 33);
+    if (!chain_ok) {  // the other stream never reported: nothing here can be trusted -- the host runs the call again, serially (status 5)
+        if (a.result_pin) pin_deliver(a.result_pin, lane == 32 ? a.epoch : lane == 33 ? 5.0 : 0.0);
+        if (a.result_user && lane == 31) a.result_user[31] = 3.0;  // (asynchronous callers: not a record -- esac_hip_pick_record: -12)
+        if (lane == 0) {
+            a.spec_state[0] = 0.0;
+            a.spec_state[5] += 1.0;
+        }
+        return;
+    }
+    // the speculative refinement's record is final when it refined THE winner (and ran to its end: a team that timed out is the
+    // host's business, status 3, exactly as on the serial route)
+    const double rec_hyp = __shfl(rec_pre, ESAC_RES_HYP_K), rec_score = __shfl(rec_pre, ESAC_RES_SCORE_K);
+    const bool held = rec_hyp == (double)global_hyp(a, win) && rec_score == win_score;
+    if (!held && status != 3.0) {
+        if (lane == 0) {
+            a.spec_state[0] = a.epoch;
+            a.spec_state[2] += 1.0;  // failed speculations on this context so far (ESAC_BUF_SPEC_INFO)
+        }
+        if (a.result_pin && a.spec_gate != 2) pin_deliver(a.result_pin, lane == 32 ? a.epoch : lane == 33 ? 4.0 : 0.0);  // (2: a gated refinement follows)
+        return;
+    }
+    if (lane == 0) a.spec_state[0] = 0.0;
+    double v = lane < 32 ? rec_pre : lane == 32 ? a.epoch : lane == 33 ? status : 0.0;
+    if (lane == ESAC_RES_PROB_K) v = exp(rec_score - (double)m) / acc[0];
+    if (lane == ESAC_RES_ENTROPY_K) v = entropy;
+    if (lane == ESAC_RES_CONTENDERS_K) v = (double)(int)acc[2];
+    if (lane < 32) {
+        a.result[lane] = v;
+        if (a.result_user) a.result_user[lane] = lane == 31 ? (status == 3.0 ? 3.0 : 1.0) : v;  // ESAC_RES_VALID (refine_write_record)
+    }
+    if (a.result_pin) pin_deliver(a.result_pin, v);
+}
+void launch_spec_join(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_spec_join<1024>, dim3(1), dim3(1024), 0, s, a); }
 
 // ================================================================= K3b: exact score of EVERY hypothesis
 // (training path esac.cpp:295-316, esac_hip_score_exact)
@@ -1385,20 +1663,76 @@ constexpr int ESAC_CHAIN_PER_HYP = 8;
         launch_sample_stragglers(b, waves, s);
     }
 }
+// ---- speculative forward: the sampler in two parts (see KArgs::spec_mode).  The shapes that have a FIRST PASS which settles
+// most hypotheses and a straggler chain behind it: several experts, a single frame, the screened route, at most
+// ESAC_FIRST_WIDE_MAX hypotheses (beyond that the chain takes every hypothesis from try 0: nothing is settled early).
+constexpr int ESAC_SPLIT_LATENCY_MAX = 1024, ESAC_SPLIT_HANDOVER = 32;  // = launch_sample's ESAC_LATENCY_MAX / ESAC_HANDOVER
+bool sample_can_split(const KArgs& a) {
+    return a.frames == 1 && a.E > 1 && a.max_tries > 1024 && !(a.flags & ESAC_FLAG_EXACT_SAMPLING_K) && a.N <= ESAC_FIRST_WIDE_MAX &&
+           a.first_try == 0;
+}
+// The first pass on `s` -- its last kernel completes `fork` (the kernel's own completion signal: hipExtLaunchKernelGGL; an event
+// recorded behind it costs the launch stream 5 us, scripts/dev/fork_join.hip) -- and the chain on `side` behind that event.
+// Exactly the kernels, arguments and order of launch_sample for these shapes.  Returns 0, or the hipError_t of the event wait.
+// The first pass on `s`; the chain's arguments (where it takes over, how many wavefronts) come back in `chain`.
+// Exactly the kernels, arguments and order of launch_sample for these shapes.
+int launch_sample_split(const KArgs& a, hipStream_t s, KArgs* chain, int* chain_waves) {
+    const long long total = a.N;
+    if (a.sc4) hipLaunchKernelGGL(k_pack_cells, dim3(2048), dim3(256), 0, s, a);
+    KArgs b = a;
+    b.handover = 0x7fffffff;
+    const long long w8 = (long long)8 * total;  // ESAC_CHAIN_PER_HYP (launch_sample)
+    *chain_waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > 131072 ? 131072 : w8));
+    if (total <= ESAC_SPLIT_LATENCY_MAX) {
+        b.handover = ESAC_SPLIT_HANDOVER;
+        if (total <= 256) hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, 1), dim3(256), 0, s, b);
+        else              hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, 1), dim3(128), 0, s, b);
+        b.first_try = b.handover;
+    } else {
+        hipLaunchKernelGGL(k_sample_first<32>, dim3((a.N + 1) / 2, 1), dim3(64), 0, s, b);
+        b.first_try += 32;
+        hipLaunchKernelGGL(k_pending_list, dim3((a.N + 1023) / 1024, 1), dim3(1024), 0, s, b);
+    }
+    *chain = b;
+    return 0;
+}
+void launch_sample_stragglers_on(const KArgs& chain, int waves, hipStream_t side) { launch_sample_stragglers(chain, waves, side); }
+// the straggler chain on `side`, behind `fork`
+int launch_sample_chain(const KArgs& chain, int waves, hipStream_t side, hipEvent_t fork) {
+    const hipError_t e = hipStreamWaitEvent(side, fork, 0);
+    if (e != hipSuccess) return (int)e;
+    launch_sample_stragglers(chain, waves, side);
+    return 0;
+}
+void launch_score_stragglers(const KArgs& a, hipStream_t side, hipEvent_t done) {
+    KArgs b = a;
+    b.spec_mode = 2;
+    b.tstamps = nullptr;
+    launch_score_fast(b, side, done);
+}
+
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hyps_to_rt32, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
 }
-void launch_score_fast(const KArgs& a, hipStream_t s) {
+// done: optional -- the kernel's own completion signal for a waiter on another stream (an event recorded behind the launch costs
+// this stream 5 us: scripts/dev/fork_join.hip)
+void launch_score_fast(const KArgs& a, hipStream_t s, hipEvent_t done) {
     // few hypotheses in flight (a single frame): the launch is ramp + load latency, 8 wavefronts per hypothesis hide
     // more of it (device span 2.96 -> 2.57 us at 256 hypotheses); many hypotheses: 4 wavefronts stream best
-    if ((long long)a.N * a.frames <= 2048) hipLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, a);
-    else               hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
+    const bool wide = (long long)a.N * a.frames <= 2048;
+    if (!done) {
+        if (wide) hipLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, a);
+        else      hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
+    } else {
+        if (wide) hipExtLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, nullptr, done, 0, a);
+        else      hipExtLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, nullptr, done, 0, a);
+    }
 }
 void launch_score(const KArgs& a, hipStream_t s) {
     if (a.partials) launch_score_tiled(a, s);
     else            launch_score_fast(a, s);
 }
-void launch_select_rescore(const KArgs& a, hipStream_t s) {
+void launch_select_rescore(const KArgs& a, hipStream_t s, hipEvent_t done) {
     // few contenders, latency matters: 16 wavefronts per workgroup; a single frame spreads its hypotheses over up to
     // 256 workgroups (a contender gets a CU to itself), batched frames over 16 each (the frames fill the chip)
     // a contender on a 480x640 grid is 0.15 ms of one workgroup in reference arithmetic: ESAC_SELECT_SPLIT workgroups share
@@ -1407,8 +1741,15 @@ void launch_select_rescore(const KArgs& a, hipStream_t s) {
     const int cap = (a.frames > 1 ? 16 : 256) / split;
     const int grid = a.N < cap ? a.N : (cap < 1 ? 1 : cap);
 constexpr int ESAC_SELECT_B = 1024;  // threads of the single-frame variant (A/B: scripts/dev/variants.sh)
-    if (split == 1 && a.N <= grid) hipLaunchKernelGGL((k_select_rescore<ESAC_SELECT_B, false>), dim3(grid, a.frames), dim3(ESAC_SELECT_B), 0, s, a);
-    else                           hipLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, a);
+    // (done: the kernel's own completion signal for a waiter on another stream -- an event recorded behind it costs this stream 5 us)
+    const bool single = split == 1 && a.N <= grid;
+    if (!done) {
+        if (single) hipLaunchKernelGGL((k_select_rescore<ESAC_SELECT_B, false>), dim3(grid, a.frames), dim3(ESAC_SELECT_B), 0, s, a);
+        else        hipLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, a);
+    } else {
+        if (single) hipExtLaunchKernelGGL((k_select_rescore<ESAC_SELECT_B, false>), dim3(grid, a.frames), dim3(ESAC_SELECT_B), 0, s, nullptr, done, 0, a);
+        else        hipExtLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, nullptr, done, 0, a);
+    }
 }
 void launch_rescore_all(const KArgs& a, hipStream_t s) {
     const int grid = a.N < 4096 ? a.N : 4096;  // bulk exact scoring: 4 wavefronts per hypothesis are enough

@@ -485,6 +485,8 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const long long cyc_start = clock64();
 #endif
     CYC_BEGIN();
+    if (!SLOTS && spec_gate_closed(a)) return;
+    if (!SLOTS) spec_open_chain(a);
     if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
     if (SLOTS && a.bwd.team_max_slots > 0 && a.bwd.n_sel[0] <= a.bwd.team_max_slots) return;  // few slots: the team launch refines them
     Coop co{1, 0, nullptr, nullptr, nullptr, 0ull, 1, 0L, &lds.coop_dead, false, nullptr, 0ull, false};
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const int nc = SLOTS ? 0 : a.n_contenders[0];
     const int picked = SLOTS ? 0 : refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
     const int win = SLOTS ? a.bwd.sel[blockIdx.x] : picked;
+    if (!SLOTS && spec_nothing_to_refine(a, win, writer)) return;
     const double win_score = a.scores[win];
     RecordInputs rec_in{0.0, 0.0, 0ull};
     if (!SLOTS && writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);

@@ -502,6 +502,8 @@ template <int CPL, int MODE = TEAM_SINGLE>
 __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     constexpr int B = REFINE_B;
     constexpr bool SLOTS = MODE == TEAM_SLOTS;
+    if (MODE == TEAM_SINGLE && spec_gate_closed(a)) return;
+    if (MODE == TEAM_SINGLE) spec_open_chain(a);
     if (MODE == TEAM_SINGLE && (blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
     const int slot = MODE != TEAM_SINGLE ? (int)(blockIdx.x >> 6) * 8 + (int)(blockIdx.x & 7) : 0;  // slot / frame of this block's team
     if (SLOTS && slot >= a.bwd.n_sel[0]) return;
@@ -630,6 +632,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     } else {
         nc = a.n_contenders[0];
         win = refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
+        if (MODE == TEAM_SINGLE && spec_nothing_to_refine(a, win, writer)) return;
         win_score = a.scores[win];
         if (writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
     }

@@ -436,6 +436,35 @@ __device__ __forceinline__ int refine_pick_winner(const KArgs& a, double* s_best
     return bi == 0x7fffffff ? 0 : bi;
 }
 
+// ---- speculative forward (KArgs::spec_mode, esac_kernels.hip: k_spec_join)
+// A gated launch (asynchronous calls: the second refinement is enqueued whatever the join will find) runs only when the join
+// marked this call's speculation as failed.
+__device__ __forceinline__ bool spec_gate_closed(const KArgs& a) { return a.spec_gate && a.spec_state[0] != a.epoch; }
+// Hand-off words between the two streams of a speculative call: the epoch of the call they belong to, written through to memory
+// (sc1) and polled past the caches -- valid between any two CUs.
+__device__ __forceinline__ void spec_word_set(const KArgs& a, int which) {
+    __hip_atomic_store(a.spec_state + which, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool spec_word_is_set(const KArgs& a, int which) {
+    return __hip_atomic_load(a.spec_state + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+}
+// "The straggler chain may start": the first workgroup of the SPECULATIVE refinement is running, i.e. the launch has its CUs.
+// (The chain's thousands of single-wavefront workgroups fill every SIMD; a refinement launched into that waits for it to drain.)
+__device__ __forceinline__ void spec_open_chain(const KArgs& a) {
+    if (a.spec_mode == 1 && a.spec_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) spec_word_set(a, 3);
+}
+// The speculative refinement found no settled contender (every hypothesis a straggler, or every settled score NaN): there is
+// nothing to refine yet -- the record says so (hypothesis -1: k_spec_join then sends the call to the second refinement).
+// Workgroup-uniform; every workgroup sharing the refinement takes the same way out.
+__device__ __forceinline__ bool spec_nothing_to_refine(const KArgs& a, int win, bool writer) {
+    if (a.spec_mode != 1 || a.exact_flag[win]) return false;
+    if (writer && threadIdx.x == 0) {
+        a.result[ESAC_RES_HYP_K] = -1.0;
+        a.spec_state[1] = 0.0;
+    }
+    return true;
+}
+
 // ---- pose2trans (esac_util.h:537-548) and the result record.
 // What the record needs besides the refinement's own outcome is known when the kernel starts (the selection kernel wrote
 // it): loaded there, so that the end of the kernel is arithmetic and stores only.
@@ -497,6 +526,7 @@ __device__ __forceinline__ void refine_write_record(const KArgs& a, const Record
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wavefront: its LDS operations complete in order
     const double v = lane < 34 ? s_rec[lane] : 0.0;
+    if (a.spec_mode == 1 && lane == 33) a.spec_state[1] = v;  // speculative refinement: the status word waits for k_spec_join
     if (lane < 32) {
         a.result[lane] = v;
         // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" (0) from a record (1); 3 = the workgroups sharing this

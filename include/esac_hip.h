@@ -157,6 +157,11 @@ enum {
                                       that THEMSELVES select <= 32 hypotheses (decided on the device), grids of 1024..8192 cells; [1] calls that issued the team launch so
                                       far; [2] of them, calls in which a team timed out and the slots were refined again by one
                                       workgroup each (teams stay off on this context afterwards); [3] slots of the last call */
+    ESAC_BUF_SPEC_INFO = 21,       /* int32[4] speculative forward (ESAC_DEBUG_NO_SPECULATION): [0] forward calls on this context that took the
+                                      speculative route, [1] those among them whose speculation failed (the refinement ran again for
+                                      the true winner), [2] 1 when the most recent forward call was speculative, [3] 1 when its
+                                      speculation failed */
+    ESAC_BUF_SPEC_FLAGS = 22,      /* uint8[N] after a speculative call: 1 where the sampler's first pass left the hypothesis to the straggler chain */
     ESAC_BUF_REFINE_INFO = 19      /* int32[8] how the most recent winner refinement ran (refineHyp, esac_util.h:378-454):
                                       [0] 0 one workgroup, 1 cooperating workgroups (grids beyond one LDS list), 2 a team on
                                       one XCD (small grids); [1] workgroups sharing it; [2] XCD census of a team: byte x = members
@@ -347,6 +352,16 @@ int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
  * hardware places on different XCDs -- the placement the team's exchange must survive (it is correct at any placement,
  * only slower across XCDs); ESAC_BUF_REFINE_INFO[3] then reads 0. */
 #define ESAC_DEBUG_TEAM_SPREAD 4
+/* ESAC_DEBUG_NO_SPECULATION (tests, A/B measurements): esac_hip_forward runs its kernels strictly one after the other on the
+ * caller's stream.  By default a single-frame call with several experts and at most 8192 hypotheses (the screened sampling
+ * route, the fp32 ranking stream, grids below 32768 cells) is SPECULATIVE: once the sampler's first pass (32 tries per
+ * hypothesis) has settled the hypotheses of usable experts, those are scored, selected from and their winner refined on the
+ * caller's stream, while the sampler's straggler chain -- the wrong-expert hypotheses that need ~10^3 tries each and practically
+ * never win -- and the stragglers' scores run beside them on a stream the context owns; a join kernel then completes the
+ * selection over all hypotheses (band, re-scores, softmax statistics, argmax: the serial route's arithmetic statement by
+ * statement) and delivers the record, or, when the winner is not the one that was refined, has the refinement run again.  Every
+ * output -- poses, scores, flags, statistics, the record -- is what the serial order produces (ESAC_BUF_SPEC_INFO counts). */
+#define ESAC_DEBUG_NO_SPECULATION 8
 int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
 
 /* The winner's refinement (refineHyp, esac_util.h:378-454) on a single frame whose grid fits one workgroup's LDS list

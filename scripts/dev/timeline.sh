@@ -19,15 +19,20 @@ qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols
 rows = list(db.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else "")))
 def short(n):
     return n.replace("void esac::", "").replace("esac::", "").split("(")[0][:44]
-calls, cur = [], None
+calls, cur, prev = [], None, ""
 for r in rows:
     n = short(r[0])
-    if n.startswith("k_sample<") or n.startswith("k_sample_first") or (n.startswith("k_pending_list") and (cur is None or not any(k[0].startswith("k_sample") for k in cur))):
-        if n.startswith("k_sample<") or cur is None or not any(k[0].startswith("k_sample_first") for k in cur):
-            cur = []
-            calls.append(cur)
+    if "esac" not in r[0] and cur is None:
+        continue
+    start = n.startswith(("k_pack_cells", "k_sample_first", "k_sample<")) or (n.startswith("k_pending_list") and not prev.startswith("k_sample_first"))
+    if start and prev.startswith("k_pack_cells"):
+        start = False
+    if start:
+        cur = []
+        calls.append(cur)
     if cur is not None:
         cur.append((n, r[1], r[2], r[3] if qcol else 0))
+    prev = n
 calls = calls[int(len(calls) * 0.4):-1]
 print("calls analysed: %d (columns: %s)" % (len(calls), qcol))
 per = collections.OrderedDict()

@@ -1136,6 +1136,17 @@ __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
     double sc0[K];  // (and the score each hypothesis holds now: the winner pick below then needs no second trip to memory)
     uint8_t strag[K], exact[K];
     __shared__ int s_chain_ok;
+    // what the LAUNCH stream's own kernels left (they finished before this launch started): flags, the settled hypotheses' scores,
+    // the speculative refinement's record and status word -- in flight while thread 0 waits for the other stream
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int h = (int)threadIdx.x + k * B;
+        const bool in = h < a.N;
+        sc0[k] = in ? a.scores[h] : 0.0;
+        strag[k] = in ? a.spec_flag[h] : 0;
+        exact[k] = in ? a.exact_flag[h] : 0;
+    }
+    const double rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
     if (threadIdx.x == 0) {
         s_nc = 0;
         // the straggler chain and the stragglers' scores are the OTHER stream's: wait for its "done" word (events: the stream
@@ -1148,14 +1159,8 @@ __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int h = (int)threadIdx.x + k * B;
-        const bool in = h < a.N;
-        fs[k] = in ? a.fast_scores[h] : -INFINITY;
-        sc0[k] = in ? a.scores[h] : 0.0;
-        strag[k] = in ? a.spec_flag[h] : 0;
-        exact[k] = in ? a.exact_flag[h] : 0;
+        fs[k] = h < a.N ? a.fast_scores[h] : -INFINITY;
     }
-    // (the record the speculative refinement left, its status word: the last wavefront-0 steps of this kernel need them)
-    const double rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
     float m = -INFINITY;
 #pragma unroll
     for (int k = 0; k < K; k++) m = fmaxf(m, fs[k]);  // (-inf for the slots beyond N: fmaxf ignores them like the loop bound does)

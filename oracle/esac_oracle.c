@@ -875,7 +875,9 @@ static void repro_errs(const ctx_t* c, const double pose[6], int expert, float* 
                           sc_at(a, expert, 1, y, x), sc_at(a, expert, 2, y, x), &u, &v);
             float dx = (float)px - u, dy = (float)py - v; /* Point2f subtraction */
             float l = (float)norm2f(dx, dy);
-            errs[y * a->W + x] = l < a->max_reproj ? l : a->max_reproj; /* std::min */
+            /* std::min(l, maxReproj) = (maxReproj < l) ? maxReproj : l (esac_util.h:358): a NaN error -- a non-finite scene
+             * coordinate -- STAYS NaN, and with it the score of every hypothesis of this expert (esac_util.h:248-250) */
+            errs[y * a->W + x] = a->max_reproj < l ? a->max_reproj : l;
         }
 }
 

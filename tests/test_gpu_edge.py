@@ -333,3 +333,87 @@ def test_more_experts_than_helper_class_bins(engine, oracle):
     res, ref = _both(engine, oracle, f["coords"], ha, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=40, seed=1305, call=3, max_tries=700)
     _same(engine, res, ref)
     assert ref["expert"] == 1100 and (ref["tries"] < 0).sum() > 100  # budgets spent on wrong experts' maps
+
+
+def _discrete(engine, res):
+    return dict(tries=engine.read(api.BUF_TRIES), xy=engine.read(api.BUF_SAMPLE_XY), winner=int(res[api.RES_HYP]), steps=int(res[api.RES_REF_STEPS]),
+                counts=engine.read(api.BUF_INLIER_COUNTS), imap=engine.read(api.BUF_INLIER_MAP), lm=int(res[api.RES_LM_ITERS]),
+                rec=res.copy(), scores=engine.read(api.BUF_SCORES), flags=engine.read(api.BUF_EXACT_FLAGS))
+
+
+@pytest.mark.parametrize("route", ["default", "fast", "one_workgroup", "stream", "tiled", "several_experts", "batch"])
+@pytest.mark.parametrize("where", ["outlier_cell", "winner_inlier"])
+def test_non_finite_scene_coordinates(engine, oracle, where, route):
+    """A scene coordinate that is NaN / +Inf / -Inf -- what a diverged expert network emits.
+
+    The REFERENCE: `std::min((float)cv::norm(curPt), maxReproj)` (esac_util.h:358) returns the NaN, so every score of that
+    expert's hypotheses is NaN, softMax is NaN throughout and draw() keeps index 0 (esac_util.h:512-529): it refines hypothesis 0
+    and returns that -- pinned against the reference's own sources in tests/test_oracle_vs_ref.py::
+    test_non_finite_scene_coordinate_matches_reference.
+
+    THIS implementation deliberately does not follow it there (deviation table): a cell that is not finite is a cell that
+    can never be an inlier -- scored as an outlier at maxReproj, kept out of every inlier set (the refinement agrees with the
+    reference on that: `NaN < tau` is false, esac_util.h:404) -- and the selection proceeds over finite scores.  The statement
+    this test holds on every route: a non-finite cell behaves EXACTLY like the same cell at 1e30 (a coordinate the reference clamps
+    to maxReproj, esac_util.h:358) -- same samples, same winner, same refinement trace, same pose -- and that call in turn agrees
+    with the oracle on the 1e30 map as every other frame does."""
+    E = 3 if route == "several_experts" else 1
+    N = 400 if route == "several_experts" else 256
+    f = S.make_frame(41, E=E, true_expert=E - 1)
+    ha = S.gating_assignment(f, N, mode="gating")
+    kw = dict(focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=1305, call=17)
+    te = f["true_expert"]
+    clean = oracle.forward(f["coords"], ha, **kw)
+    if where == "winner_inlier":
+        ys, xs = np.nonzero(clean["inlier_map"])
+    else:
+        ys, xs = np.nonzero(f["outlier_mask"] & (clean["inlier_map"] == 0))
+    cells = [(int(ys[i]), int(xs[i])) for i in (0, len(ys) // 2, len(ys) - 1)]
+    bad_maps = {}
+    for name, vals in (("non_finite", (np.nan, np.inf, -np.inf)), ("huge", (1e30, 1e30, -1e30))):
+        c = f["coords"].copy()
+        for (y, x), v, ch in zip(cells, vals, (0, 1, 2)):
+            c[te, ch, y, x] = v
+        bad_maps[name] = c
+    ref = oracle.forward(bad_maps["huge"], ha, **kw)  # (the oracle on the NaN map is the reference's "hypothesis 0" answer)
+    mk = dict(kw)
+    if route == "default":
+        mk["exact_scores"] = "auto"
+    elif route in ("stream", "tiled"):
+        mk["score_shape"] = route
+    if route == "one_workgroup":
+        engine.set_refine_team(0)
+    try:
+        got = {}
+        for name, c in bad_maps.items():
+            sc, hat = torch.from_numpy(c).cuda(), torch.from_numpy(ha).cuda()
+            p = engine.make_params(E, 60, 80, N, **mk)
+            if route == "batch":
+                other = torch.from_numpy(S.make_frame(42)["coords"]).cuda()
+                recs = engine.forward_batch(torch.stack([other, sc, other]), torch.stack([hat, hat, hat]), engine.make_params(E, 60, 80, N, **dict(mk, call=16)))
+                got[name] = dict(rec=recs[1].copy())
+            else:
+                got[name] = _discrete(engine, engine.forward_device(sc, hat, p))
+    finally:
+        engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
+    a, b = got["non_finite"], got["huge"]
+    if route == "batch":
+        np.testing.assert_array_equal(a["rec"][:31], b["rec"][:31])
+        r_err, t_err = S.pose_errors(a["rec"][api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
+        assert int(a["rec"][api.RES_HYP]) == ref["winner"] and r_err <= 1e-4 and t_err <= 1e-3
+        return
+    for key in ("tries", "xy", "winner", "steps", "counts", "imap", "lm", "flags"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert np.isfinite(a["scores"]).all()
+    np.testing.assert_allclose(a["scores"], b["scores"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(a["rec"][:31], b["rec"][:31], rtol=0, atol=1e-9)
+    for (y, x) in cells:
+        assert a["imap"][y, x] == 0  # never an inlier
+    # ... and the 1e30 call is an ordinary frame: held against the oracle
+    np.testing.assert_array_equal(a["tries"], ref["tries"])
+    np.testing.assert_array_equal(a["xy"], ref["sample_xy"])
+    assert a["winner"] == ref["winner"] and a["steps"] == ref["ref_steps"]
+    np.testing.assert_array_equal(a["counts"], ref["inlier_counts"])
+    np.testing.assert_array_equal(a["imap"], ref["inlier_map"])
+    r_err, t_err = S.pose_errors(a["rec"][api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
+    assert r_err <= 1e-4 and t_err <= 1e-3, (r_err, t_err)

@@ -94,3 +94,32 @@ def test_oracle_backward_matches_reference_esac_backward(oracle, case):
     assert out["loss"] == pytest.approx(loss_ref, rel=1e-12, abs=1e-12)
     assert np.abs(g_ref).max() > 1e-2  # a real gradient came out
     np.testing.assert_allclose(g_ora, g_ref, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf, 1e30])
+def test_non_finite_scene_coordinate_matches_reference(oracle, bad):
+    """What the REFERENCE does with a scene coordinate that is not finite: `std::min((float)cv::norm(curPt), maxReproj)`
+    (esac_util.h:358) returns its FIRST argument when that is NaN, so the cell's error stays NaN, every hypothesis' score is NaN
+    (esac_util.h:248-250), softMax yields NaN throughout and draw() keeps index 0 (esac_util.h:519-523: `maxProb < 0` is true
+    once, nothing compares greater than NaN afterwards): the reference refines hypothesis 0, whatever it is.  A huge but finite
+    coordinate (1e30) clamps to maxReproj and changes nothing.  The oracle restates exactly that (the HIP path deliberately does
+    not: DESIGN.md, deviation table; tests/test_gpu_edge.py::test_non_finite_scene_coordinates)."""
+    f = S.make_frame(7)
+    ha = S.gating_assignment(f, 48)
+    coords = f["coords"].copy()
+    coords[0, 1, 17, 23] = bad
+    kw = dict(focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"])
+    ref = ref_binding.forward(coords, ha, seed=1305, **kw)
+    ora = oracle.forward(coords, ha, irand=ref_binding.replay_irand(1305), **kw)
+    np.testing.assert_array_equal(ora["sample_xy"], ref["sample_xy"])
+    np.testing.assert_array_equal(ora["hyps"], ref["hyps"])
+    np.testing.assert_array_equal(ora["scores"], ref["scores"])  # (assert_array_equal treats NaN == NaN)
+    assert ora["winner"] == ref["winner"]
+    np.testing.assert_array_equal(ora["refined"], ref["refined"])
+    np.testing.assert_array_equal(ora["inlier_map"], ref["inlier_map"])
+    np.testing.assert_array_equal(ora["pose"], ref["pose"])
+    if np.isfinite(bad):
+        assert np.isfinite(ref["scores"]).all()
+    else:
+        assert np.isnan(ref["scores"]).all() and ref["winner"] == 0
+        assert ref["inlier_map"][17, 23] == 0 and ref["inlier_map"].sum() > 1000  # hypothesis 0 is refined as usual, without that cell

@@ -376,6 +376,8 @@ def main():
     lm_iters = ref_steps = 0.0
     gpu_poses = {}
     sync()
+    if world == 1:
+        eng.host_turn_mean(reset=True)  # the library's running sums of its host-side stamps: cleared here, read after the K steps
     t0 = time.perf_counter()
     trace = [] if os.environ.get("ESAC_BENCH_TRACE") else None
     for i in range(steps):  # the timed region: EXACTLY the K steps, nothing else
@@ -388,6 +390,8 @@ def main():
             gpu_poses[(warmup + i) % n_frames] = (r[api.RES_POSE:api.RES_POSE + 16].reshape(4, 4).copy(), int(r[api.RES_HYP]), warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
+    host_split = eng.host_turn_mean(reset=True) if world == 1 else None
+    spec_info = eng.spec_info() if world == 1 else None
     if trace is not None:
         trace.append(time.perf_counter())
         sys.stderr.write("step durations (us): " + " ".join("%.1f" % ((b - a) * 1e6) for a, b in zip(trace[:-1], trace[1:])) + "\n")
@@ -577,6 +581,11 @@ def main():
                               "fp32 ranking stream + exact re-score of the contenders (ESAC_FLAG_AUTO_EXACT does not apply to this shape)")
         if world == 1:
             out["refine"] = eng.refine_info()  # how the winner's refinement of the last step ran (ESAC_BUF_REFINE_INFO)
+            if spec_info and spec_info["calls"]:
+                # several experts: the sampler's straggler chain ran beside score / selection / refinement of the settled hypotheses
+                # (ESAC_DEBUG_NO_SPECULATION); failures = calls whose winner was not the one refined speculatively (refined again)
+                out["speculation"] = dict(spec_info, note="calls / failures over warm-up + timed steps; a failed speculation costs a second refinement, "
+                                                         "every output is the serial route's")
         if world > 1:
             out["ranks_seen"] = min(r["ranks_seen"] for r in rank_reports)  # the smallest communicator any rank ran its exchange on
             out["devices"] = [r["device"] for r in rank_reports]           # hipGetDevice of every rank, by rank
@@ -630,20 +639,27 @@ def main():
             rp = [r.get("rocprofv3_avg_us") for r in kernels]
             out["host_turn_us"] = {"vs_live_stage_times": elapsed / steps * 1e6 - tot * 1e3,
                                    "vs_rocprofv3_durations": elapsed / steps * 1e6 - sum(v or 0.0 for v in rp) if prof and any(rp) else None,
+                                   "split_us": host_split,
                                    "note": "ms_per_step - sum of the stages' kernel durations: launch call of the first kernel, command processor, "
-                                           "kernel boundaries, record hand-off, Python (split: profiles/r05_host_turn.txt)"}
+                                           "kernel boundaries, record hand-off, Python.  split_us: means of the library's host-side stamps over THESE "
+                                           "K timed steps (esac_hip_host_turn_mean): call_total = args_ready + first_launch_call + further_launch_calls "
+                                           "+ wait_for_record (the GPU's time as the host sees it) + record_to_return; between_calls = the caller's loop"}
             score_ms = st["score"]
             alg_bytes = n_total * 12.0 * H * W
             achieved = alg_bytes / (score_ms * 1e-3) / 1e9
             traffic = rp_ms = None
             srow = next(r for r in kernels if r["stage"] == "score")
-            if prof:
-                if srow.get("rocprofv3"):
-                    fb = [k.get("fetch_bytes_x2corr") for k in srow["rocprofv3"]]
-                    wb = [k.get("write_bytes") or 0 for k in srow["rocprofv3"]]
-                    if all(v is not None for v in fb):
-                        traffic = float(sum(fb) + sum(wb))
-                    rp_ms = srow["rocprofv3_avg_us"] * 1e-3 if srow.get("rocprofv3_avg_us") else None
+            # the figures of the ONE route `value` ran: a profile holds every score kernel the profiled command launched (the exact
+            # route's k_rescore AND the fast route's k_score_fast: two routes that never run in one call)
+            tiled_route = H * W >= 32768 and n_total >= 64 and W % 4 == 0
+            route_kernels = ("k_bucket", "k_score_tiled") if tiled_route else (("k_rescore",) if auto_applies else ("k_score_fast",))
+            route_rows = [k for k in (srow.get("rocprofv3") or []) if any(rk in k["name"] for rk in route_kernels)]
+            if prof and route_rows:
+                fb = [k.get("fetch_bytes_x2corr") for k in route_rows]
+                wb = [k.get("write_bytes") or 0 for k in route_rows]
+                if all(v is not None for v in fb):
+                    traffic = float(sum(fb) + sum(wb))  # per launch (one launch of each of the route's kernels per step)
+                rp_ms = sum(k["avg_us"] for k in route_rows) * 1e-3
             cache_resident = 12.0 * H * W * E <= 4 * 2**20
             quoted_ms = max(score_ms, rp_ms) if rp_ms else score_ms
             achieved_q = alg_bytes / (quoted_ms * 1e-3) / 1e9
@@ -657,6 +673,7 @@ def main():
                 "achieved": achieved_q, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_q / HBM_PEAK_GBPS,
                 "achieved_live": achieved, "frac_live": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": prof["file"] if prof and traffic is not None else None,
+                "route_kernels": [k["name"] for k in route_rows] if prof else None,
                 "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": score_ms,
                 "kernel_ms_source": "HIP events on the launch stream around %d back-to-back launches of the stage, mean over the %d cycled frames (extremes dropped) "
                                     "(includes ~1.5 us of dependent-kernel boundary per launch)" % (reps, n_frames),
@@ -683,6 +700,18 @@ def main():
                                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (stf["score"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                  "stage_us": {k: v * 1e3 for k, v in stf.items()}}
             out["profile_stale"] = bool(prof["stale"]) if prof else None  # committed rocprofv3 / PMC figures measured on other kernel sources?
+            if prof:
+                # the kernel that holds most of the call's GPU time, by name: what the contract's `roofline` (the score stage)
+                # is NOT at the 60x80 grid -- with its own bound and how far HBM is from being it
+                esac_k = [k for k in prof["kernels"] if "esac::" in k["name"] and k.get("per_step_us")]
+                if esac_k:
+                    dk = max(esac_k, key=lambda k: k["per_step_us"])
+                    moved = (dk.get("fetch_bytes_x2corr") or 0.0) + (dk.get("write_bytes") or 0.0)
+                    out["dominant_kernel"] = {"name": dk["name"], "avg_us": dk["avg_us"], "share_of_gpu_time": dk.get("pct", 0.0) / 100.0,
+                                              "frac_of_issue_bound": dk.get("frac_of_issue_bound"), "valu_busy_frac": dk.get("valu_busy_frac"),
+                                              "bytes_moved_per_launch": moved, "hbm_frac": moved / (dk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                              "bound": OWN_BOUND["refine"] if "k_refine" in dk["name"] else OWN_BOUND["sample"] if "k_sample" in dk["name"] else OWN_BOUND["score"],
+                                              "source": prof["file"]}
             rf = out["roofline"]
             if rf["cache_served"]:
                 # the algorithmic bytes never leave the caches / registers: HBM is not this kernel's roof.  Lead with the roof

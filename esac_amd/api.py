@@ -44,6 +44,7 @@ ABI_SYMBOLS = [
     "esac_hip_pick_record", "esac_hip_time_stages", "esac_hip_shard_balanced", "esac_hip_set_wait",
     "esac_hip_set_refine_team", "esac_hip_host_turn",
     "esac_hip_comm_unique_id", "esac_hip_comm_init", "esac_hip_comm_destroy", "esac_hip_allreduce_sum", "esac_hip_comm_info",
+    "esac_hip_host_turn_mean",
 ]
 COMM_ID_BYTES = 128
 ABI_VERSION = 6
@@ -112,6 +113,7 @@ def load_library():
         lib.esac_hip_set_wait.argtypes = [vp, i32]
         lib.esac_hip_set_refine_team.argtypes = [vp, i32]
         lib.esac_hip_host_turn.argtypes = [vp, vp]
+        lib.esac_hip_host_turn_mean.argtypes = [vp, vp, i32]
         lib.esac_hip_comm_unique_id.argtypes = [vp, C.c_size_t]
         lib.esac_hip_comm_init.argtypes = [vp, i32, i32, vp, C.c_size_t]
         lib.esac_hip_comm_destroy.argtypes = [vp]
@@ -426,6 +428,15 @@ class Engine:
         _check(self.lib.esac_hip_host_turn(self.ctx, out.ctypes.data), self.lib)
         return {"args_ready": out[0] * 1e-3, "sample_launched": out[1] * 1e-3, "score_launched": out[2] * 1e-3, "refine_launched": out[3] * 1e-3,
                 "record_landed": out[4] * 1e-3, "returned": out[5] * 1e-3, "entry_ns": out[6]}
+
+    def host_turn_mean(self, reset=True):
+        """Means of the host-side stamps over the blocking forward calls since the last reset (esac_hip_host_turn_mean), in us:
+        where the host's share of a step goes."""
+        out = np.zeros(8, np.float64)
+        _check(self.lib.esac_hip_host_turn_mean(self.ctx, out.ctypes.data, 1 if reset else 0), self.lib)
+        u = out * 1e-3
+        return {"calls": int(out[7]), "args_ready": u[0], "first_launch_call": u[1] - u[0], "further_launch_calls": u[3] - u[1],
+                "wait_for_record": u[4] - u[3], "record_to_return": u[5] - u[4], "call_total": u[5], "between_calls": u[6]}
 
     def set_timing(self, on, period=1):
         """Per-phase events on every `period`-th forward call (the next call is the first sampled one)."""

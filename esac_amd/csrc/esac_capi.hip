@@ -111,6 +111,9 @@ struct esac_hip_ctx {
     long long tPart = 0;
     bool rt32_stale = false;  // esac_hip_write_hyps ran: the fp32 [R|t] rows are rebuilt by the next esac_hip_score
     double host_ns[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // esac_hip_host_turn: where the host's time of the most recent blocking forward went
+    double host_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ... summed over the blocking forward calls since the last reset (esac_hip_host_turn_mean)
+    double host_last_return = 0;                    // CLOCK_MONOTONIC at which the previous blocking forward returned
+    long long host_n = 0;
     // speculative forward (forward_impl): the straggler chain of the sampler runs on this stream beside the launch stream
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -805,6 +808,26 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
             return fail(-10, "hypAssignment holds a value outside [0,%d) (device-resident tensor; such hypotheses were scored against expert 0)", p->E);
     }
     c->host_ns[5] = now_ns() - t_entry;
+    if (h_result_out) {  // running sums (seven additions: the caller's timed loop is not touched by reading them later)
+        for (int k = 0; k < 6; k++) c->host_sum[k] += c->host_ns[k];
+        if (c->host_last_return > 0) c->host_sum[6] += t_entry - c->host_last_return;  // the caller's time between two calls
+        c->host_last_return = t_entry + c->host_ns[5];
+        c->host_n++;
+    }
+    return 0;
+}
+
+extern "C" int esac_hip_host_turn_mean(esac_hip_ctx* c, double out_ns[8], int reset) {
+    if (!c || !out_ns) return fail(-1, "esac_hip_host_turn_mean: null argument");
+    const double n = c->host_n > 0 ? (double)c->host_n : 1.0;
+    for (int k = 0; k < 6; k++) out_ns[k] = c->host_sum[k] / n;
+    out_ns[6] = c->host_n > 1 ? c->host_sum[6] / (double)(c->host_n - 1) : 0.0;
+    out_ns[7] = (double)c->host_n;
+    if (reset) {
+        for (double& v : c->host_sum) v = 0;
+        c->host_n = 0;
+        c->host_last_return = 0;
+    }
     return 0;
 }
 

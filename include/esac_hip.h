@@ -338,6 +338,11 @@ int esac_hip_time_stages(esac_hip_ctx* ctx, const float* d_scene_coords, const i
  * What remains of a step beyond the kernels' own durations -- the "host turn" -- is [1] + the gap to the first kernel's
  * start + ([5] - [4]) + the caller's own time between calls (scripts/dev/host_turn.py puts them side by side). */
 int esac_hip_host_turn(esac_hip_ctx* ctx, double out_ns[8]);
+/* The same stamps as MEANS over the blocking esac_hip_forward / _batch calls since the last reset (running sums kept by the
+ * library: the caller's timed loop is not disturbed by collecting them): out_ns[0..5] as above, out_ns[6] = mean time between the
+ * return of one call and the entry of the next (the caller's own share of a step), out_ns[7] = number of calls averaged.
+ * reset != 0 clears the sums afterwards. */
+int esac_hip_host_turn_mean(esac_hip_ctx* ctx, double out_ns[8], int reset);
 /* enable/disable the per-phase events (off by default: zero overhead).  enabled = k > 1 samples every k-th forward
  * call only, starting with the next one (the events themselves cost GPU time: an empty pair reads ~5 us). */
 int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);

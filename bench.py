@@ -478,8 +478,8 @@ def main():
             def step_sharded(i, timers=None):
                 return D.forward_sharded(eng, d_coords[i % n_frames], d_assign[i % n_frames],
                                          dict(seed=BENCH_SEED, call=i, exact_scores="auto", **kw), policy="range", timers=timers)[1]
-            for i in range(max(warmup, 10)):
-                step_sharded(i)
+            for i in range(max(warmup, 40)):  # (RCCL's first few dozen collectives of a communicator carry one-off stalls: 20 timed steps behind 10
+                step_sharded(i)               # warm-up calls read +23..39 us a step, behind 40: +12..14 -- this leg is about the steady state)
             torch.cuda.synchronize()
             t_sh = time.perf_counter()
             for i in range(steps):

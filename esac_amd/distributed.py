@@ -222,6 +222,7 @@ def contribute_range(engine, scene_coords, hyp_assign_full, params_kw, rank, wor
 
 
 _native = {"off": False}
+_WORLD = "the default process group"
 
 
 def native_comm(engine, group=None):
@@ -237,10 +238,10 @@ def native_comm(engine, group=None):
     import os
     if _native["off"] or os.environ.get("ESAC_NATIVE_RCCL", "1") == "0" or not dist.is_initialized() or dist.get_backend(group) != "nccl":
         return None
+    if engine._comm is not None and engine._comm_key is not None and engine._comm_key[0] is (group if group is not None else _WORLD):
+        return engine  # (per frame: one identity test -- the group object the communicator was made for)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    key = (id(group) if group is not None else None, tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)))
-    if engine._comm == (world, rank) and engine._comm_key == key:
-        return engine
+    key = (group if group is not None else _WORLD, tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)))
     why = None
     my_id = None
     try:

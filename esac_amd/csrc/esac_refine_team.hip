@@ -657,11 +657,10 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     for (int k = 0; k < 6; k++) c[k] = prev[k] = 0.0;
     unsigned run_set = 0, next_set = 0, acc_set = 0;  // sets as bit masks over this lane's cells: the running re-fit's, the one the last
                                                       // full pass found, the last ACCEPTED step's (inlierMap, esac_util.h:440)
-    // The loop carries the pose (`param`), this lane's cells and a handful of scalars -- nothing else.  What only a REJECTED
-    // trial needs again (the normal equations and the point they were built at, `prev`) waits in LDS, one copy per wavefront
-    // (every lane holds the same values; lane 0 stores, everyone reads back: no barrier): 66 registers that would
-    // otherwise be shuffled between the two register files around every pass, and ONE site each for the pass, the
-    // normal equations and the solve.
+    // The loop carries the pose (`param`), this lane's cells, a handful of scalars and what a REJECTED trial needs again: this
+    // lane's column of the normal equations and the point they were built at (c, dg, prev above: 13 registers since the LM step
+    // is dealt to the lanes -- round 4 kept the whole matrix, 66 uniform values, in an LDS stash per wavefront).  ONE site each
+    // for the pass, the normal equations and the solve.
     double param[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) param[k] = pose[k];

@@ -648,7 +648,13 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     const bool spec = !c->spec_off && B == 1 && !exact && sample_can_split(a) && !a.partials && (long long)a.H * a.W < 32768 &&
                       !(c->fold_select && refine_folds_select(a));
     c->last_spec_epoch = 0;
-    if (spec && !c->side) {
+    bool spec_ok = spec;
+    if (spec_ok && s != nullptr) {  // a stream that is being captured into a graph takes no launches on other streams beside it
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) spec_ok = false;
+        (void)hipGetLastError();
+    }
+    if (spec_ok && !c->side) {
         HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
         HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -656,7 +662,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
     c->rt32_stale = false;
     mark_sampling(c, a);
-    if (spec) {
+    if (spec_ok) {
         c->spec_calls++;
         c->last_spec_epoch = a.epoch;
         a.tstamps = nullptr;
@@ -756,7 +762,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         // the refinement kernel stores the record and then the epoch word into pinned host memory
         // (one ESAC_PIN_DOUBLES slot per frame: record, epoch word, status word)
         if ((rc = wait_record(c, s, B, c->epoch, "esac_hip_forward: the refinement kernel"))) return rc;
-        if (spec && c->h_pin[33] == 5.0) {
+        if (spec_ok && c->h_pin[33] == 5.0) {
             // the context's own stream never reported the straggler chain as done within 20 ms (it shares a hardware queue with
             // the caller's stream and something else is holding that queue, or its launch failed): no more speculation on this
             // context, and this call again -- the serial route

@@ -298,7 +298,7 @@ class Engine:
         return out
 
     def read(self, which):
-        N, H, W = self._shape
+        N, H, W = self._shape or (0, 0, 0)  # (the context-level info buffers need no shape)
         shapes = {
             BUF_HYPS: ((N, 6), np.float64), BUF_SAMPLE_XY: ((N, 4, 2), np.int32), BUF_TRIES: ((N,), np.int32),
             BUF_SCORES: ((N,), np.float64), BUF_RESULT: ((RES_DOUBLES,), np.float64),

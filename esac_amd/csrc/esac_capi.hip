@@ -116,9 +116,7 @@ struct esac_hip_ctx {
     long long host_n = 0;
     // speculative forward (forward_impl): the straggler chain of the sampler runs on this stream beside the launch stream
     hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool spec_off = false, spec_env_off = false;  // ESAC_DEBUG_NO_SPECULATION / ESAC_SPECULATE=0
-    bool spec_events = false;             // the two streams hand over through events instead of polled words (ESAC_SPEC_EVENTS=1: A/B)
     long long spec_calls = 0;             // forward calls that took the speculative route
     double last_spec_epoch = 0;           // epoch of the most recent speculative call (0: the most recent forward was not)
     ncclComm_t comm = nullptr;  // esac_hip_comm_init: this context's rank in an RCCL communicator (the multi-GPU score exchange)
@@ -197,7 +195,7 @@ static void free_ws(esac_hip_ctx* c) {
                     c->ws.scores,     c->ws.exact_flag,   c->ws.n_contenders, c->ws.sel_partials, c->ws.sel_arrived, c->ws.stats,
                     c->ws.errs,       c->ws.inlier_map,   c->ws.inlier_counts, c->ws.result, c->ws.corr_list, c->ws.cycles, c->ws.tstamps, c->ws.span_acc,
                     c->ws.status,     c->ws.coop_partials, c->ws.coop_counter, c->ws.refine_info, c->ws.order,        c->ws.rt_sorted,  c->ws.chunks,     c->ws.n_chunks,  c->ws.partials, c->ws.bucket_fill,
-                    c->ws.spec_flag,  c->ws.spec_state};
+                    c->ws.spec_flag,  c->ws.spec_state,  c->ws.spec_cnt};
     c->tN = c->tChunks = 0;
     c->tPart = 0;
     for (void* p : ptrs)
@@ -229,7 +227,6 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
     if (const char* e = getenv("ESAC_FOLD_SELECT")) c->fold_select = atoi(e) != 0;
     if (const char* e = getenv("ESAC_SLOT_TEAMS")) c->slot_teams = atoi(e) != 0;
     if (const char* e = getenv("ESAC_SPECULATE")) c->spec_off = c->spec_env_off = atoi(e) == 0;
-    if (const char* e = getenv("ESAC_SPEC_EVENTS")) c->spec_events = atoi(e) != 0;
     *out = c;
     return 0;
 }
@@ -252,8 +249,6 @@ extern "C" int esac_hip_destroy(esac_hip_ctx* c) {
     if (c->sc4) (void)hipFree(c->sc4);
     drop_comm(c);
     if (c->side) (void)hipStreamDestroy(c->side);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->h_pin) (void)hipHostFree(c->h_pin);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -322,6 +317,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.span_acc, (size_t)2);
     rc |= alloc(&c->ws.spec_flag, (size_t)nN);
     rc |= alloc(&c->ws.spec_state, (size_t)8);
+    rc |= alloc(&c->ws.spec_cnt, (size_t)1);
     if (rc) {
         if (old_hyps) (void)hipFree(old_hyps);
         return rc;
@@ -329,6 +325,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
     HIP_OK(hipMemset(c->ws.spec_flag, 0, (size_t)nN));
     HIP_OK(hipMemset(c->ws.spec_state, 0, 8 * sizeof(double)));
+    HIP_OK(hipMemset(c->ws.spec_cnt, 0, sizeof(int)));
     HIP_OK(hipMemset(c->ws.coop_counter, 0, 2 * sizeof(unsigned long long)));  // [1]: tag of the last failed shared refinement (esac_hip_check)
     HIP_OK(hipMemset(c->ws.coop_partials, 0, (size_t)ESAC_TEAM_BATCH_MAX * ESAC_TEAM_GRANULES * 2 * sizeof(double)));  // (also the teams' granules)
     HIP_OK(hipMemset(c->ws.refine_info, 0, 8 * sizeof(int)));
@@ -470,7 +467,6 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     a.solo = 0;
     a.spec_mode = 0;
     a.spec_gate = 0;
-    a.spec_flags = 0;
     a.spec_flag = nullptr;  // (forward_impl hands the flags to the kernels of a speculative call only)
     a.samp_cap = (int)(((long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP) > 0x7fffffffLL ? 0x7fffffff : (long long)c->capN * ESAC_SAMPLE_LIST_PER_HYP);
     a.flags = p->flags;
@@ -656,8 +652,6 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     }
     if (spec_ok && !c->side) {
         HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-        HIP_OK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        HIP_OK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
     c->rt32_stale = false;
@@ -676,10 +670,8 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         if (tm) HIP_OK(hipEventRecord(c->ev[1], s));
         // The two streams hand over through WORDS in device memory (spec_state[3]: "the chain may start", [4]: "the chain is
         // done"), not through events: an event between two streams costs the waiting side 8-13 us on this platform even when it is
-        // long satisfied.  Whoever waits is enqueued BEHIND the launch it waits for (host order below), so that even two
-        // streams that share a hardware queue cannot wait for each other; every wait is bounded in wall time.
-        const bool flags = !c->spec_events;
-        a.spec_flags = flags ? 1 : 0;
+        // long satisfied (profiles/r06_ab_speculation.txt).  Whoever waits is enqueued BEHIND the launch it waits for (host order
+        // below), so that even two streams that share a hardware queue cannot wait for each other; every wait is bounded in wall time.
         KArgs as = a;  // the settled hypotheses: score, selection, refinement of their winner -- no record leaves the workspace
         as.spec_mode = 1;
         as.result_user = nullptr;
@@ -692,22 +684,16 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         // single-wavefront workgroups fill every SIMD of the chip, and whatever the launch stream starts while it is in full
         // swing finds no CU to run on until it has drained (measured: started behind the first pass, the selection took 27 us
         // instead of 10; started behind the score kernel, the refinement's team waited 34 us for its CUs).
-        launch_select_rescore(as, s, flags ? nullptr : c->ev_fork);
+        launch_select_rescore(as, s);
         if ((rc = check_launch("k_select_rescore (settled)"))) return rc;
         if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
         c->refine_tag = launch_refine(as, s);  // (its first workgroup opens the chain: spec_open_chain)
         c->refine_was_team = refine_team_members(as) > 0;
         if ((rc = check_launch("k_refine (speculative)"))) return rc;
-        if (flags) {
-            launch_spec_wait(a, 3, c->side);
-            launch_sample_stragglers_on(chain, chain_waves, c->side);
-        } else if (int e = launch_sample_chain(chain, chain_waves, c->side, c->ev_fork)) {
-            return fail(-100 - e, "hipStreamWaitEvent: %s", hipGetErrorString((hipError_t)e));
-        }
-        launch_score_stragglers(a, c->side, flags ? nullptr : c->ev_join);  // behind the chain on the side stream
-        if (flags) launch_spec_set(a, 4, c->side);
+        launch_spec_wait(a, 3, c->side);
+        launch_sample_stragglers_on(chain, chain_waves, c->side);
+        launch_score_stragglers(a, c->side);  // behind the chain on the side stream; its last workgroup writes "the chain is done"
         if ((rc = check_launch("straggler chain"))) return rc;
-        if (!flags) HIP_OK(hipStreamWaitEvent(s, c->ev_join, 0));
         KArgs aj = a;
         aj.spec_gate = 2;
         launch_spec_join(aj, s);

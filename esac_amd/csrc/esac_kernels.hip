@@ -21,7 +21,6 @@
 // those exact scores (first index on ties, esac_util.h:519).  All discrete decisions of refinement (inlier tests,
 // stopping rule) use the exact arithmetic.
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -681,8 +680,12 @@ __global__ __launch_bounds__(64) void k_sample_screened(KArgs a) {
     // the last kernel of the screened chain leaves the chain's counters (list lengths, per-expert counters) at zero for the
     // next call: nothing after k_sample_decide reads them, and a fill in front of every sampling launch is a 3 us
     // launch and a kernel boundary on a 250 us call (esac_capi.hip zeroes them when the workspace is allocated)
-    if (RESUME && blockIdx.x == 0 && blockIdx.y == 0)
+    if (RESUME && blockIdx.x == 0 && blockIdx.y == 0) {
+        // (the length of the pending list survives in n_contenders[1]: the speculative route scores exactly those hypotheses
+        // behind this kernel, k_score_stragglers)
+        if (lane == 0) a.n_contenders[1] = min(a.samp_count[1], a.N * a.frames);
         for (int i = lane; i < 4 + 2 * ESAC_STAT_BINS; i += 64) a.samp_count[i] = 0;
+    }
     // (RESUME: the list builders marked what is pending -- also when the chain started at try 0)
     if ((RESUME || a.first_try > 0) && a.tries[h] != SAMPLE_PENDING) return;
     if (!RESUME && a.first_try == 0 && lane == 0) flag_bad_assignment(a, h);
@@ -838,12 +841,9 @@ __device__ __forceinline__ f32x2 soft_inlier_fast2(const PoseF& p, float fx, flo
     return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
 }
 
+// the fp32 score of hypothesis h by one workgroup of B threads; returns it in thread 0 (already stored to fast_scores[h])
 template <int B>
-__global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
-    __shared__ float s_w[B / 64];
-    frame_view(a);
-    const int h = blockIdx.x;
-    if (a.spec_mode && (a.spec_mode == 1) == (a.spec_flag[h] != 0)) return;  // speculative forward: the settled / the stragglers only
+__device__ __forceinline__ float score_fast_one(const KArgs& a, int h, float* s_w) {
     // optional device-side span measurement (timing mode): the kernel's duration is
     // max(end) - min(start) over its workgroups, on the constant 100 MHz wall clock
     long long t_start = 0;
@@ -893,18 +893,59 @@ __global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
     const float w = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = w;
     __syncthreads();
+    float out = 0.0f;
     if (threadIdx.x == 0) {
         double tot = 0;
 #pragma unroll
         for (int k = 0; k < B / 64; k++) tot += (double)s_w[k];
         const float scale = a.alpha / a.W / a.H;  // float / int / int (esac_util.h:256)
-        a.fast_scores[h] = (float)(tot * (double)scale);
+        out = (float)(tot * (double)scale);
+        a.fast_scores[h] = out;
         if (a.tstamps) {
             a.tstamps[2 * h] = t_start;
             a.tstamps[2 * h + 1] = wall_clock64();
         }
     }
+    return out;
 }
+
+template <int B>
+__global__ __launch_bounds__(B) void k_score_fast(KArgs a) {
+    __shared__ float s_w[B / 64];
+    frame_view(a);
+    const int h = blockIdx.x;
+    if (a.spec_mode == 1 && a.spec_flag[h] != 0) return;  // speculative forward: the settled hypotheses only (the stragglers: k_score_stragglers)
+    (void)score_fast_one<B>(a, h, s_w);
+}
+
+// Speculative forward, the side stream's last kernel: the fp32 scores of the STRAGGLERS -- the pending list the chain worked
+// through (samp_pending; its length in n_contenders[1], k_sample_screened<true>) -- and, from the last workgroup to finish, the
+// "chain is done" word the join polls (spec_state[4]).  The scores are written through (sc1) and every workgroup arrives at a
+// counter once its store has reached memory: no launch of its own for the word, no release fence per workgroup (an L2 write-back
+// each).  A single frame (the route's condition).
+template <int B>
+__global__ __launch_bounds__(B) void k_score_stragglers(KArgs a) {
+    __shared__ float s_w[B / 64];
+    const int count = a.n_contenders[1];
+    // only the workgroups that have a straggler to score arrive at the counter (1024 arrivals at one address were 5 us of this
+    // kernel; a frame has a few hundred stragglers at most); no straggler at all: workgroup 0 writes the word
+    const int nwork = count < (int)gridDim.x ? count : (int)gridDim.x;
+    if ((int)blockIdx.x >= (nwork > 0 ? nwork : 1)) return;
+    for (int e = blockIdx.x; e < count; e += gridDim.x) {
+        const int h = a.samp_pending[e];
+        const float v = score_fast_one<B>(a, h, s_w);
+        if (threadIdx.x == 0) __hip_atomic_store(a.fast_scores + h, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();  // (s_w is rewritten by the next hypothesis)
+    }
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nwork <= 1 || __hip_atomic_fetch_add(a.spec_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwork - 1) {
+            __hip_atomic_store(a.spec_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.spec_state + 4, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 
 // ================================================================= K3: select + exact re-score of the contenders
 // softMax / entropy statistics (esac_util.h:461-497) from the fp32-path scores, the band of contenders
@@ -1095,7 +1136,7 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
 // Otherwise spec_state[0] = this call's epoch: a blocking call reads status 4 from the pinned slot and launches the refinement
 // again (the workspace now holds exactly what k_select_rescore would have left: refine_pick_winner finds the true winner); an
 // asynchronous call has that launch enqueued already, gated on this word.
-// Hand-off words instead of events (KArgs::spec_flags): an event between two streams costs the waiting side 8-13 us on this
+// Hand-off words instead of events: an event between two streams costs the waiting side 8-13 us on this
 // platform even when it is long satisfied (scripts/dev/fork_join.hip, profiles/r06_*timeline*), a polled word ~1 us.
 // The waits are bounded in wall time: a word that never comes (the other stream's launch failed) costs ESAC_SPEC_WAIT_TICKS, is
 // counted in spec_state[5] and reported by the join (status 5) -- never a hang.
@@ -1111,11 +1152,7 @@ __device__ __forceinline__ bool spec_wait_word(const KArgs& a, int which) {
 __global__ __launch_bounds__(64) void k_spec_wait(KArgs a, int which) {
     if (threadIdx.x == 0 && !spec_wait_word(a, which)) a.spec_state[5] += 1.0;  // (timed out: the chain runs late, the results stay right)
 }
-__global__ __launch_bounds__(64) void k_spec_set(KArgs a, int which) {
-    if (threadIdx.x == 0) __hip_atomic_store(a.spec_state + which, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
 void launch_spec_wait(const KArgs& a, int which, hipStream_t s) { hipLaunchKernelGGL(k_spec_wait, dim3(1), dim3(64), 0, s, a, which); }
-void launch_spec_set(const KArgs& a, int which, hipStream_t s) { hipLaunchKernelGGL(k_spec_set, dim3(1), dim3(64), 0, s, a, which); }
 
 template <int B>
 __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
@@ -1149,12 +1186,11 @@ __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
     const double rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
     if (threadIdx.x == 0) {
         s_nc = 0;
-        // the straggler chain and the stragglers' scores are the OTHER stream's: wait for its "done" word (events: the stream
-        // order in front of this launch has waited already)
-        s_chain_ok = !a.spec_flags || spec_wait_word(a, 4);
+        // the straggler chain and the stragglers' scores are the OTHER stream's: wait for its "done" word
+        s_chain_ok = spec_wait_word(a, 4);
     }
     __syncthreads();
-    if (a.spec_flags) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the other stream's kernels wrote, not what this CU's caches hold
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the other stream's kernels wrote, not what this CU's caches hold
     const bool chain_ok = s_chain_ok != 0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -1702,42 +1738,30 @@ int launch_sample_split(const KArgs& a, hipStream_t s, KArgs* chain, int* chain_
     return 0;
 }
 void launch_sample_stragglers_on(const KArgs& chain, int waves, hipStream_t side) { launch_sample_stragglers(chain, waves, side); }
-// the straggler chain on `side`, behind `fork`
-int launch_sample_chain(const KArgs& chain, int waves, hipStream_t side, hipEvent_t fork) {
-    const hipError_t e = hipStreamWaitEvent(side, fork, 0);
-    if (e != hipSuccess) return (int)e;
-    launch_sample_stragglers(chain, waves, side);
-    return 0;
-}
-void launch_score_stragglers(const KArgs& a, hipStream_t side, hipEvent_t done) {
+// the side stream's last kernel (see k_score_stragglers): behind the chain
+void launch_score_stragglers(const KArgs& a, hipStream_t side) {
     KArgs b = a;
-    b.spec_mode = 2;
     b.tstamps = nullptr;
-    launch_score_fast(b, side, done);
+    b.spec_mode = 0;
+    const int grid = a.N < 1024 ? a.N : 1024;
+    if ((long long)a.N <= 2048) hipLaunchKernelGGL(k_score_stragglers<512>, dim3(grid), dim3(512), 0, side, b);
+    else                        hipLaunchKernelGGL(k_score_stragglers<256>, dim3(grid), dim3(256), 0, side, b);
 }
 
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_hyps_to_rt32, dim3((a.N + 255) / 256), dim3(256), 0, s, a);
 }
-// done: optional -- the kernel's own completion signal for a waiter on another stream (an event recorded behind the launch costs
-// this stream 5 us: scripts/dev/fork_join.hip)
-void launch_score_fast(const KArgs& a, hipStream_t s, hipEvent_t done) {
+void launch_score_fast(const KArgs& a, hipStream_t s) {
     // few hypotheses in flight (a single frame): the launch is ramp + load latency, 8 wavefronts per hypothesis hide
     // more of it (device span 2.96 -> 2.57 us at 256 hypotheses); many hypotheses: 4 wavefronts stream best
-    const bool wide = (long long)a.N * a.frames <= 2048;
-    if (!done) {
-        if (wide) hipLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, a);
-        else      hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
-    } else {
-        if (wide) hipExtLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, nullptr, done, 0, a);
-        else      hipExtLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, nullptr, done, 0, a);
-    }
+    if ((long long)a.N * a.frames <= 2048) hipLaunchKernelGGL(k_score_fast<512>, dim3(a.N, a.frames), dim3(512), 0, s, a);
+    else               hipLaunchKernelGGL(k_score_fast<256>, dim3(a.N, a.frames), dim3(256), 0, s, a);
 }
 void launch_score(const KArgs& a, hipStream_t s) {
     if (a.partials) launch_score_tiled(a, s);
     else            launch_score_fast(a, s);
 }
-void launch_select_rescore(const KArgs& a, hipStream_t s, hipEvent_t done) {
+void launch_select_rescore(const KArgs& a, hipStream_t s) {
     // few contenders, latency matters: 16 wavefronts per workgroup; a single frame spreads its hypotheses over up to
     // 256 workgroups (a contender gets a CU to itself), batched frames over 16 each (the frames fill the chip)
     // a contender on a 480x640 grid is 0.15 ms of one workgroup in reference arithmetic: ESAC_SELECT_SPLIT workgroups share
@@ -1746,15 +1770,8 @@ void launch_select_rescore(const KArgs& a, hipStream_t s, hipEvent_t done) {
     const int cap = (a.frames > 1 ? 16 : 256) / split;
     const int grid = a.N < cap ? a.N : (cap < 1 ? 1 : cap);
 constexpr int ESAC_SELECT_B = 1024;  // threads of the single-frame variant (A/B: scripts/dev/variants.sh)
-    // (done: the kernel's own completion signal for a waiter on another stream -- an event recorded behind it costs this stream 5 us)
-    const bool single = split == 1 && a.N <= grid;
-    if (!done) {
-        if (single) hipLaunchKernelGGL((k_select_rescore<ESAC_SELECT_B, false>), dim3(grid, a.frames), dim3(ESAC_SELECT_B), 0, s, a);
-        else        hipLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, a);
-    } else {
-        if (single) hipExtLaunchKernelGGL((k_select_rescore<ESAC_SELECT_B, false>), dim3(grid, a.frames), dim3(ESAC_SELECT_B), 0, s, nullptr, done, 0, a);
-        else        hipExtLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, nullptr, done, 0, a);
-    }
+    if (split == 1 && a.N <= grid) hipLaunchKernelGGL((k_select_rescore<ESAC_SELECT_B, false>), dim3(grid, a.frames), dim3(ESAC_SELECT_B), 0, s, a);
+    else                           hipLaunchKernelGGL((k_select_rescore<1024, true>), dim3(grid, a.frames, split), dim3(1024), 0, s, a);
 }
 void launch_rescore_all(const KArgs& a, hipStream_t s) {
     const int grid = a.N < 4096 ? a.N : 4096;  // bulk exact scoring: 4 wavefronts per hypothesis are enough

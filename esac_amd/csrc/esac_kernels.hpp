@@ -162,15 +162,15 @@ struct KArgs {
     // (k_sample_prescreen .. k_sample_screened: wrong-expert hypotheses that practically never win) and the stragglers' scores run
     // beside them on a stream of the context's own; k_spec_join then folds the stragglers in and delivers -- or finds that a
     // straggler wins after all, and the refinement runs again for it.  Every output is what the serial order produces.
-    int spec_mode;          // 0: off.  Score / selection kernels: 1 = the settled hypotheses only (spec_flag[h] == 0), 2 = the
-                            // stragglers only.  Refinement kernels: 1 = speculative (no record leaves the workspace; the status word
+    int spec_mode;          // 0: off.  Score / selection kernels: 1 = the settled hypotheses only (spec_flag[h] == 0).
+                            // Refinement kernels: 1 = speculative (no record leaves the workspace; the status word
                             // goes to spec_state[1]; no settled contender at all: give up at once)
     uint8_t* spec_flag;     // [N] 1: the sampler's first pass left hypothesis h to the straggler chain (written there, read-only afterwards)
     double* spec_state;     // [8] [0] the epoch of the call whose speculation FAILED (k_spec_join), [1] status word of the speculative
                             // refinement, [2] failed speculations so far, [3] "the chain may start" = the epoch of the call whose
                             // speculative refinement has STARTED (its workgroups are resident), [4] "the chain is done" = the epoch
                             // of the call whose straggler chain has finished, [5] hand-offs that timed out so far
-    int spec_flags;         // 1: the streams hand over through spec_state[3] / [4] (polled words), 0: through events
+    int* spec_cnt;          // [1] workgroups of k_score_stragglers that are done (the last one writes spec_state[4] and leaves this at zero)
     int spec_gate;          // refinement kernels: 1 = return at once unless spec_state[0] is this call's epoch (asynchronous calls: the
                             // second refinement is enqueued unconditionally and runs only when the speculation failed)
     // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
@@ -200,21 +200,19 @@ void launch_sample(const KArgs& a, hipStream_t s);
 // on `side` behind that event
 bool sample_can_split(const KArgs& a);
 int launch_sample_split(const KArgs& a, hipStream_t s, KArgs* chain, int* chain_waves);
-int launch_sample_chain(const KArgs& chain, int waves, hipStream_t side, hipEvent_t fork);
 void launch_sample_stragglers_on(const KArgs& chain, int waves, hipStream_t side);
-void launch_score_stragglers(const KArgs& a, hipStream_t side, hipEvent_t done);  // fp32 scores of the stragglers; signals `done` (optional)
+void launch_score_stragglers(const KArgs& a, hipStream_t side);  // fp32 scores of the stragglers + the "chain is done" word
 void launch_spec_join(const KArgs& a, hipStream_t s);
-// hand-offs between the two streams of a speculative call through words in device memory instead of events (KArgs::spec_flags):
-// a one-wavefront kernel that waits until spec_state[which] is this call's epoch / one that sets it
+// hand-offs between the two streams of a speculative call through words in device memory, not events: a one-wavefront kernel that
+// waits until spec_state[which] is this call's epoch
 void launch_spec_wait(const KArgs& a, int which, hipStream_t s);
-void launch_spec_set(const KArgs& a, int which, hipStream_t s);
 void launch_hyps_to_rt32(const KArgs& a, hipStream_t s);
-void launch_score_fast(const KArgs& a, hipStream_t s, hipEvent_t done = nullptr);
+void launch_score_fast(const KArgs& a, hipStream_t s);
 void launch_score(const KArgs& a, hipStream_t s);  // the fp32 score in the shape the C ABI chose (a.partials != null: tiled)
 void launch_score_tiled(const KArgs& a, hipStream_t s);
 void launch_bucket_order(const KArgs& a, hipStream_t s);  // esac_score_tiled.hip: order[] = hypotheses sorted by expert
 int tiled_sub_tiles(int P);
-void launch_select_rescore(const KArgs& a, hipStream_t s, hipEvent_t done = nullptr);
+void launch_select_rescore(const KArgs& a, hipStream_t s);
 void launch_rescore_all(const KArgs& a, hipStream_t s);
 void launch_stats_exact(const KArgs& a, hipStream_t s);
 void launch_pick_record(const double* records, int world, double* pin, double epoch, double* zero, int n_zero, hipStream_t s);

@@ -451,7 +451,7 @@ __device__ __forceinline__ bool spec_word_is_set(const KArgs& a, int which) {
 // "The straggler chain may start": the first workgroup of the SPECULATIVE refinement is running, i.e. the launch has its CUs.
 // (The chain's thousands of single-wavefront workgroups fill every SIMD; a refinement launched into that waits for it to drain.)
 __device__ __forceinline__ void spec_open_chain(const KArgs& a) {
-    if (a.spec_mode == 1 && a.spec_flags && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) spec_word_set(a, 3);
+    if (a.spec_mode == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) spec_word_set(a, 3);
 }
 // The speculative refinement found no settled contender (every hypothesis a straggler, or every settled score NaN): there is
 // nothing to refine yet -- the record says so (hypothesis -1: k_spec_join then sends the call to the second refinement).

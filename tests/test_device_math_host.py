@@ -544,3 +544,37 @@ def test_fast_quartic_agrees_with_the_exact_route_or_says_maybe():
         agreed += 1
     assert agreed > len(cases) // 4 and said_maybe > 0, (agreed, said_maybe)  # it is a guard, not a blanket refusal
 
+
+
+def test_ill_conditioned_minimal_set_is_a_known_divergence(oracle, probe):
+    """Round 6's 1000-frame sweep with several experts (profiles/r06_sweep_1000_several_experts.txt) found ONE hypothesis whose
+    accepted try differs between the oracle and the HIP path -- on every route, the guaranteed fp64 one included: frame 5874 of
+    the synthetic generator, hypothesis 1746 on the garbage map of a wrong expert, try 2198: four cells of a 3 x 2 pixel-cell
+    neighbourhood (an image triangle 16 pixels wide) whose scene points lie ~2 m apart, i.e. a camera ~70 m away.  Three-point
+    pose from such a sliver is ill-conditioned beyond what either formulation resolves: NEITHER solver's pose reprojects the
+    three base points exactly (5-10 px off, where a well-posed sample gives < 1e-6), the two poses differ by metres, and whether
+    the four errors stay below tau = 10 px is decided by rounding -- the oracle (Gao + Ferrari + Horn) says yes at 6.5 px, the
+    device formulation (Gao + Ferrari + triad / Newton) no at 10.55 px.  What OpenCV's own P3P would say cannot be known here
+    (OpenCV internals unpinned).  The hypothesis is a wrong-expert straggler that does not win; winner, pose and
+    every other hypothesis of that frame agree.  This test pins the sample so that a change of either solver that moves it
+    is noticed."""
+    f = S.make_frame(5874, E=12, true_expert=874 % 12)
+    cells = [(57, 47), (58, 48), (56, 48), (56, 47)]
+    obj = np.array([[f["coords"][7, c, y, x] for c in range(3)] for x, y in cells], np.float64)
+    img = np.array([[x * 8 + 4, y * 8 + 4] for x, y in cells], np.float64)
+
+    def reproj(r, t):
+        th = np.linalg.norm(r)
+        K = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]]) / th
+        R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+        P = obj @ R.T + t
+        return np.hypot(FX * P[:, 0] / P[:, 2] + CX - img[:, 0], FY * P[:, 1] / P[:, 2] + CY - img[:, 1])
+
+    ok_o, r_o, t_o = oracle.p3p(obj, img, FX, FY, CX, CY)
+    ok_p, r_p, t_p = _probe_p3p(probe, obj, img)
+    assert ok_o and ok_p
+    e_o, e_p = reproj(r_o, t_o), reproj(r_p, t_p)
+    assert np.abs(t_o - t_p).max() > 1.0                  # metres apart
+    assert e_o[:3].min() > 1.0 and e_p[:3].min() > 1.0    # neither reprojects its own three base points: not a resolved P3P solution
+    assert e_o.max() < 10.0 < e_p.max()                   # ... and tau = 10 px falls between the two
+    assert t_o[2] > 50 and t_p[2] > 50                    # the sliver's camera: tens of metres out

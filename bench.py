@@ -635,10 +635,16 @@ def main():
                     row["rocprofv3_avg_us"] = sum(k["per_step_us"] for k in ks) if ks else None
                 kernels.append(row)
             out["kernels"] = kernels
+            speculative = bool(spec_info and spec_info["calls"])
+            if speculative:
+                out["kernels_note"] = ("stage times are those of the launch sequence IN STREAM ORDER (esac_hip_time_stages); the timed steps ran the "
+                                       "speculative route, where most of the `sample` stage -- the straggler chain -- runs on the context's own stream "
+                                       "beside score / select / refine: ms_per_step is less than the sum of the stages (profiles/r06_timeline_%s.txt)" % config_name)
             # what a step spends outside its kernels: against the live stage times and against the committed rocprofv3 durations
+            # (not defined for the speculative route: its kernels overlap)
             rp = [r.get("rocprofv3_avg_us") for r in kernels]
-            out["host_turn_us"] = {"vs_live_stage_times": elapsed / steps * 1e6 - tot * 1e3,
-                                   "vs_rocprofv3_durations": elapsed / steps * 1e6 - sum(v or 0.0 for v in rp) if prof and any(rp) else None,
+            out["host_turn_us"] = {"vs_live_stage_times": None if speculative else elapsed / steps * 1e6 - tot * 1e3,
+                                   "vs_rocprofv3_durations": elapsed / steps * 1e6 - sum(v or 0.0 for v in rp) if prof and any(rp) and not speculative else None,
                                    "split_us": host_split,
                                    "note": "ms_per_step - sum of the stages' kernel durations: launch call of the first kernel, command processor, "
                                            "kernel boundaries, record hand-off, Python.  split_us: means of the library's host-side stamps over THESE "

@@ -32,7 +32,8 @@ BUF_REFINE_INFO = 19
 BUF_BWD_TEAM_INFO = 20
 BUF_SPEC_INFO = 21
 BUF_SPEC_FLAGS = 22
-REFINE_TEAM_MAX, REFINE_TEAM_DEFAULT = 32, 8
+REFINE_TEAM_MAX, REFINE_TEAM_EIGHT, REFINE_TEAM_AUTO = 32, 8, -1
+REFINE_TEAM_DEFAULT = REFINE_TEAM_AUTO  # what a fresh context does: 8 members, or the smallest team <= 16 that lowers the cells per lane
 MAX_REF_STEPS = 100
 BWD_MAX_SLOTS = 1000
 
@@ -371,8 +372,9 @@ class Engine:
         return {"calls": int(v[0]), "failures": int(v[1]), "last_speculative": bool(v[2]), "last_failed": bool(v[3])}
 
     def set_refine_team(self, members=REFINE_TEAM_DEFAULT):
-        """Workgroups that share the winner's refinement on a small single-frame grid (0 / 1: one workgroup;
-        esac_hip_set_refine_team)."""
+        """Workgroups that share the winner's refinement on a small single-frame grid (0 / 1: one workgroup; a number: exactly
+        that many; REFINE_TEAM_AUTO = the default policy: 8, or the smallest team <= 16 that lowers the cells a lane holds --
+        10 on the 60x80 grid; esac_hip_set_refine_team)."""
         _check(self.lib.esac_hip_set_refine_team(self.ctx, int(members)), self.lib)
 
     def bwd_team_info(self):
@@ -598,7 +600,8 @@ def forward_batch(sceneCoordinates, hypAssignment, outPoses, shiftX, shiftY, foc
                   inlierThreshold, inlierAlpha, inlierBeta, maxReproj, subSampling):
     """Batched companion of `forward` (new API): sceneCoordinates [B,E,3,H,W] (or [E,3,H,W] shared),
     hypAssignment [B,N] int64, outPoses [B,4,4] float32 written in place; returns the list of winning experts.
-    Frame b is exactly what the b-th of B consecutive `forward` calls would compute."""
+    Frame b is what the b-th of B consecutive `forward` calls would compute (discrete outputs identical; poses to the rounding of
+    the LM sums, bit for bit when the single calls refine with teams of 8 like a batch does: include/esac_hip.h)."""
     if hypAssignment.dim() != 2 or hypAssignment.dtype != torch.int64:
         raise RuntimeError("esac.forward_batch: hypAssignment must be int64 [B,N]")
     if sceneCoordinates.dtype != torch.float32 or sceneCoordinates.dim() not in (4, 5) or sceneCoordinates.size(-3) != 3:

@@ -34,6 +34,7 @@ static_assert(ESAC_RES_SCORE == ESAC_RES_SCORE_K && ESAC_RES_HYP == ESAC_RES_HYP
                   ESAC_MAX_REF_STEPS == ESAC_MAX_REF_STEPS_K && ESAC_BWD_MAX_SLOTS == ESAC_BWD_SLOTS_K &&
                   ESAC_FLAG_EXACT_SCORES == ESAC_FLAG_EXACT_SCORES_K && ESAC_FLAG_EXACT_SAMPLING == ESAC_FLAG_EXACT_SAMPLING_K &&
                   ESAC_FLAG_SCORES_BY_INDEX == ESAC_FLAG_SCORES_BY_INDEX_K && ESAC_REFINE_TEAM_MAX == ESAC_REFINE_TEAM_MAX_K &&
+                  ESAC_REFINE_TEAM_DEFAULT == ESAC_REFINE_TEAM_DEFAULT_K &&
                   (ESAC_FLAG_AUTO_EXACT & (ESAC_FLAG_EXACT_SCORES | ESAC_FLAG_EXACT_SAMPLING | ESAC_FLAG_SCORES_BY_INDEX)) == 0,
               "result layout drifted between include/esac_hip.h and esac_kernels.hpp");
 
@@ -88,6 +89,8 @@ struct esac_hip_ctx {
     bool coop_stall = false;  // ESAC_DEBUG_COOP_STALL
     int team = ESAC_REFINE_TEAM_DEFAULT;  // members of the refinement team on small grids (esac_hip_set_refine_team; 0: one workgroup)
     bool team_spread = false;             // ESAC_DEBUG_TEAM_SPREAD: the members are consecutive workgroups (one per XCD)
+    bool team_auto = true;                // the default team size is chosen per grid (ESAC_REFINE_TEAM_AUTO=0: exactly the default, A/B)
+    bool team_auto_env_off = false;
     unsigned long long refine_tag = 0;    // tag of the most recent shared (cooperative / team) refinement launch, 0: none yet
     unsigned long long checked_tag = 0;   // the failed launch esac_hip_check has already counted as a strike
     bool refine_was_team = false;         // the most recent forward's refinement launch was a team's
@@ -225,6 +228,8 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
         c->team = g < 2 ? 0 : (g > ESAC_REFINE_TEAM_MAX ? ESAC_REFINE_TEAM_MAX : g);
     }
     if (const char* e = getenv("ESAC_FOLD_SELECT")) c->fold_select = atoi(e) != 0;
+    if (const char* e = getenv("ESAC_REFINE_TEAM_AUTO")) c->team_auto_env_off = atoi(e) == 0;
+    if (c->team_auto_env_off || getenv("ESAC_REFINE_TEAM")) c->team_auto = false;  // (an explicit start value is an explicit size)
     if (const char* e = getenv("ESAC_SLOT_TEAMS")) c->slot_teams = atoi(e) != 0;
     if (const char* e = getenv("ESAC_SPECULATE")) c->spec_off = c->spec_env_off = atoi(e) == 0;
     *out = c;
@@ -463,6 +468,7 @@ static int make_args(esac_hip_ctx* c, const float* d_sc, const int64_t* d_assign
     a.coop_max = c->coop_max;
     a.coop_extra = c->coop_stall ? 1 : 0;
     a.team = c->team;  // (the forward entry points fold the time-out latch in: forward_team)
+    a.team_auto = c->team_auto ? 1 : 0;
     a.team_stride = c->team_spread ? 1 : 8;
     a.solo = 0;
     a.spec_mode = 0;
@@ -1337,8 +1343,11 @@ extern "C" int esac_hip_write_hyps(esac_hip_ctx* c, const double* h_hyps, int N)
 
 extern "C" int esac_hip_set_refine_team(esac_hip_ctx* c, int members) {
     if (!c) return fail(-1, "null context");
-    if (members < 0 || members > ESAC_REFINE_TEAM_MAX) return fail(-4, "esac_hip_set_refine_team: %d members (0..%d)", members, ESAC_REFINE_TEAM_MAX);
-    c->team = members < 2 ? 0 : members;
+    if (members < ESAC_REFINE_TEAM_AUTO || members > ESAC_REFINE_TEAM_MAX)
+        return fail(-4, "esac_hip_set_refine_team: %d members (0..%d, or ESAC_REFINE_TEAM_AUTO)", members, ESAC_REFINE_TEAM_MAX);
+    // ESAC_REFINE_TEAM_AUTO: back to the default policy (the size chosen per grid); a number: exactly that many
+    c->team_auto = members == ESAC_REFINE_TEAM_AUTO && !c->team_auto_env_off;
+    c->team = members == ESAC_REFINE_TEAM_AUTO ? ESAC_REFINE_TEAM_DEFAULT : members < 2 ? 0 : members;
     c->team_latched_off = false;  // an explicit request re-arms the forward teams and the training path's slot teams
     c->team_strikes = 0;
     c->slot_teams = true;

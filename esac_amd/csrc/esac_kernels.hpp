@@ -15,6 +15,7 @@ constexpr int ESAC_REFINE_LDS_CAP = 8192;  // correspondences the refinement ker
 constexpr int ESAC_REFINE_THREADS = 256;   // 4 wavefronts = one per SIMD of the one CU a refinement occupies
 constexpr int ESAC_ERR_UNROLL = 8;         // cells per lane in flight in the error pass
 constexpr int ESAC_REFINE_COOP_MAX = 256;  // workgroups that may share one refinement (one per CU: all must be resident)
+constexpr int ESAC_REFINE_TEAM_DEFAULT_K = 8;  // = ESAC_REFINE_TEAM_DEFAULT (include/esac_hip.h)
 constexpr int ESAC_REFINE_TEAM_MAX_K = 32;   // ... on a small grid: a team on ONE XCD (its 32 CUs; esac_refine_team.hip)
 constexpr int ESAC_REFINE_TEAM_MIN_CELLS = 1024;  // smaller grids are refined by one workgroup (a pass is shorter than an exchange)
 constexpr int ESAC_TEAM_BATCH_MAX = 32;           // frames of a batch that are refined by teams of 8 (32 teams = the chip's 256 CUs at once)
@@ -149,6 +150,7 @@ struct KArgs {
     int coop_extra;                     // ESAC_DEBUG_COOP_STALL: workgroups the barrier waits for beyond those launched (0 normally)
     unsigned long long coop_tag;        // launch number << 20: tags the exchange granules and the failure word of THIS refinement launch
     int team;                           // members of a refinement team on small grids (0: one workgroup refines; esac_hip_set_refine_team)
+    int team_auto;                      // 1: a.team == the default stands for "the smallest team <= 16 that lowers the cells per lane" (refine_team_members)
     int team_stride;                    // the team's members are the workgroups blockIdx.x % team_stride == 0 (8: one XCD; 1: debug, spread)
     int solo;                           // 1: launch_refine takes ONE workgroup per refinement whatever the shape (the retry after a shared
                                         // refinement timed out: neither a team nor cooperating workgroups, both need co-residency again)

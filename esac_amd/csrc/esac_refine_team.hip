@@ -768,6 +768,16 @@ int refine_team_members(const KArgs& a) {
     const int need = (P + TEAM_CPL_MAX * REFINE_B - 1) / (TEAM_CPL_MAX * REFINE_B);
     if (G < need) G = need;
     if (G < 2) G = 2;
+    // the default size (round 6): a pass costs a lane its cells, and every lane of a member walks as many as its fullest lane
+    // holds -- eight members of 600 cells hold THREE per lane on the 60x80 grid, ten of 480 hold two.  Up to 16 members exchange
+    // without LDS staging (refine_common.hpp: team_collect_lds), so: the smallest team <= 16 that lowers the cells per lane.
+    if (a.team_auto && a.team == ESAC_REFINE_TEAM_DEFAULT_K && G <= 16) {
+        const int cpl = ((P + G - 1) / G + REFINE_B - 1) / REFINE_B;
+        if (cpl >= 2) {
+            const int G2 = (P + REFINE_B * (cpl - 1) - 1) / (REFINE_B * (cpl - 1));
+            if (G2 > G && G2 <= 16) G = G2;
+        }
+    }
     if (a.coop_max < G * (a.team_stride > 0 ? a.team_stride : 8)) return 0;
     return G;
 }

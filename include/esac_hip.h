@@ -209,8 +209,10 @@ int esac_hip_forward(esac_hip_ctx* ctx, const float* d_scene_coords, const int64
  * occupies a single CU for its refinement tail, so independent frames are what fills the other 255.
  * d_scene_coords  frame b at d_scene_coords + b * sc_frame_stride (elements; 0 = every frame uses the same maps),
  *                 each [E,3,H,W]; d_hyp_assign [B,N]; p describes ONE frame (N = hypotheses per frame).
- * Frame b draws the RNG streams of call p->call + b: the batch is bit-identical to B sequential
- * esac_hip_forward calls with consecutive call counters.
+ * Frame b draws the RNG streams of call p->call + b: the batch equals B sequential esac_hip_forward calls with consecutive
+ * call counters -- every discrete output identical, the poses bit for bit when the single calls refine on the batch's route
+ * (esac_hip_set_refine_team(ctx, 8): a batch's teams are 8 per frame, a single call's default team is chosen per grid), else to
+ * the rounding of the LM sums (~1e-9).
  * Outputs are frame-major: d_scores_out [B,N], d_result_out / h_result_out [B,ESAC_RES_DOUBLES].
  */
 int esac_hip_forward_batch(esac_hip_ctx* ctx, int B, const float* d_scene_coords, int64_t sc_frame_stride,
@@ -384,6 +386,12 @@ int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
  * teams too). */
 #define ESAC_REFINE_TEAM_MAX 32
 #define ESAC_REFINE_TEAM_DEFAULT 8
+/* The default POLICY (a fresh context; esac_hip_set_refine_team(ctx, ESAC_REFINE_TEAM_AUTO) restores it): ESAC_REFINE_TEAM_DEFAULT
+ * members, or -- round 6 -- the smallest team of at most 16 that lowers the cells a lane holds: every lane of a member walks as
+ * many cells per pass as its fullest lane owns, eight members of 600 cells hold three per lane on the 60x80 grid, TEN of 480
+ * hold two (a pass 0.3 us shorter, the call 2.5 us; teams of up to 16 exchange without an LDS stage).  Batches and the training
+ * path's slot teams stay at 8 per team (32 teams of 8 are the chip's 256 CUs).  A number asks for exactly that many. */
+#define ESAC_REFINE_TEAM_AUTO (-1)
 int esac_hip_set_refine_team(esac_hip_ctx* ctx, int members);
 
 /* How a blocking call waits for its result record (written by the last kernel into pinned host memory):

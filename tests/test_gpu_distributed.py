@@ -323,7 +323,9 @@ def test_failed_record_is_not_an_empty_shard(engine):
         engine.set_debug()
         engine.set_refine_team(api.REFINE_TEAM_DEFAULT)
     res = engine.forward_device(sc, ha, engine.make_params(1, 60, 80, n_total, **kw))
-    assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]) and best[api.RES_SCORE] == res[api.RES_SCORE]
+    # (the winner's exact score: the shards re-scored it in the selection kernel, the plain call in its team's prologue, member by
+    # member -- the same terms in another order)
+    assert int(best[api.RES_HYP]) == int(res[api.RES_HYP]) and abs(best[api.RES_SCORE] - res[api.RES_SCORE]) <= 1e-12 * abs(res[api.RES_SCORE])
     np.testing.assert_allclose(best[api.RES_POSE:api.RES_POSE + 16], res[api.RES_POSE:api.RES_POSE + 16], rtol=0, atol=1e-6)
 
 

@@ -209,7 +209,9 @@ def test_batched_forward_equals_sequential_calls(engine):
     try:
         # (N * B <= 2048 throughout: beyond that the fp32 score stream runs with 4 wavefronts per hypothesis instead of 8 --
         # another summation order of the cells, so non-contender scores and the softmax statistics move in their last fp32 digit)
-        for B, team, N in ((12, api.REFINE_TEAM_DEFAULT, 96), (12, 0, 96), (35, api.REFINE_TEAM_DEFAULT, 48)):
+        # (exactly 8 members for the single calls: a batch's teams are 8 per frame, the single call's default is 10 on this grid --
+        # another order of the LM sums)
+        for B, team, N in ((12, api.REFINE_TEAM_EIGHT, 96), (12, 0, 96), (35, api.REFINE_TEAM_EIGHT, 48)):
             frames = [S.make_frame(70 + b, E=2, true_expert=b % 2) for b in range(B)]
             assigns = np.stack([S.gating_assignment(f, N, mode="gating") for f in frames])
             coords = torch.from_numpy(np.stack([f["coords"] for f in frames])).cuda()
@@ -220,7 +222,7 @@ def test_batched_forward_equals_sequential_calls(engine):
             res_b = engine.forward_batch(coords, ha, p, scores_out=scores_b)
             batch_teams = team != 0 and B <= 32
             assert engine.refine_info()["mode"] == ("team" if batch_teams else "one_workgroup")
-            for single_team in (0, api.REFINE_TEAM_DEFAULT):
+            for single_team in (0, api.REFINE_TEAM_EIGHT):
                 engine.set_refine_team(single_team)
                 for b in range(B if single_team == team else 4):
                     q = engine.make_params(2, 60, 80, N, call=40 + b)

@@ -256,11 +256,13 @@ class Engine:
             raise RuntimeError("esac.backward: the gradient tensor must be a dense float32 device tensor shaped like sceneCoordinates")
         gt = np.ascontiguousarray(np.asarray(gt_pose, np.float32).reshape(16))
         host = np.zeros(4, np.float64) if want_host else None
-        with torch.cuda.device(self.device):
-            _check(self.lib.esac_hip_backward(
-                self.ctx, sc.data_ptr(), out_gradients.data_ptr(), ha.data_ptr(), gt.ctypes.data_as(C.c_void_p),
-                float(w_rot), float(w_trans), float(loss_cut), C.byref(params), self._stream(),
-                host.ctypes.data_as(C.c_void_p) if want_host else None), self.lib)
+        # (the library makes the context's GPU current itself: no torch device guard on the call path, as in forward_device)
+        rc = self.lib.esac_hip_backward(
+            self.ctx, sc.data_ptr(), out_gradients.data_ptr(), ha.data_ptr(), gt.ctypes.data,
+            float(w_rot), float(w_trans), float(loss_cut), C.byref(params), self._stream(),
+            host.ctypes.data if want_host else None)
+        if rc != 0:
+            _check(rc, self.lib)
         self._keep = (sc, ha, out_gradients)
         return host
 

@@ -104,7 +104,7 @@ __device__ __forceinline__ TauBand make_band(const KArgs& a) {
 // instead.  out: next_set; the 27 totals over the team in LDS (s_tot: [0, 27) the totals, [32, 59) their negatives, what
 // the lane-dealt step gathers from), tail = totals 24..26 (identical in every thread of every member); M, K = chain-rule
 // matrices at param, column j in lane j of every row (the left Jacobian of SO(3) and [t]x of it, lm_lanes.hpp).
-template <int CPL>
+template <int CPL, int WIDE>
 __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& cl, const double (&param)[6], const Cam& cam, const TauBand& band,
                                           unsigned run_set, bool use_next, unsigned& next_set, double (&tail)[3], const LaneConst& lc, double (&M)[3],
                                           double (&K)[3], Coop& co, double* s_part, double* s_tot, double* s_x, long long* g_cyc) {
@@ -194,7 +194,7 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
     wave_totals28_to_lds<TEAM_NSUM>(sums, s_part);
     team_publish<TEAM_NSUM>(workgroup_total28<REFINE_B>(s_part), co);
     lm_lane_chain<double>(tg, param + 3, lc.hot, M, K);  // while the exchange is in flight
-    team_collect_lds<TEAM_NSUM, true>(co, s_tot, s_x);
+    team_collect_lds<TEAM_NSUM, true, WIDE>(co, s_tot, s_x);
     tail[0] = s_tot[24];
     tail[1] = s_tot[25];
     tail[2] = s_tot[26];
@@ -257,7 +257,7 @@ __device__ __forceinline__ bool team_step(bool fresh, const LaneConst& lc, const
 // Returns the winner (local index); win_score, nc and the record inputs come back through the references.  Writes what
 // k_select_rescore writes: scores / exact_flag / scores_user of every hypothesis, n_contenders, stats (member 0).
 constexpr int TEAM_SEL_CHUNK = 16;  // contenders re-scored per exchange (16 x 12 pose values fit one load per thread)
-template <int CPL>
+template <int CPL, int WIDE>
 __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>& cl, bool cells_loaded, int cell0, int cell1, const Cam& cam, Coop& co,
                                            bool writer, double* s_part, double* s_tot, double* s_x, double* s_best, int* s_besti, int* s_bestg, int* s_list,
                                            double* s_rt, double& win_score, int& nc_out, RecordInputs& rec_in) {
@@ -352,7 +352,7 @@ __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>&
         __syncthreads();
         double tot[TEAM_SEL_CHUNK];
         team_publish<TEAM_SEL_CHUNK>(t < TEAM_SEL_CHUNK ? (s_part[t] + s_part[28 + t]) + (s_part[56 + t] + s_part[84 + t]) : 0.0, co);
-        team_collect<TEAM_SEL_CHUNK>(tot, co, s_tot, s_x);
+        team_collect<TEAM_SEL_CHUNK, WIDE>(tot, co, s_tot, s_x);
         if (co.dead) break;
         if (t < cnt) {
             const int h = s_list[c0 + t];
@@ -498,8 +498,9 @@ __device__ __forceinline__ int team_select_exact(const KArgs& a, bool writer, do
 // at most ESAC_TEAM_BATCH_MAX frames in place of the slot -- every frame's winner gets what the single call's gets (8 CUs of
 // one XCD, the selection folded in for <= 256 hypotheses), each team with its own granules.
 enum : int { TEAM_SINGLE = 0, TEAM_SLOTS = 1, TEAM_FRAMES = 2 };
-template <int CPL, int MODE = TEAM_SINGLE>
+template <int CPL, int MODE = TEAM_SINGLE, int WIDE = 8>
 __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
+    static_assert(MODE == TEAM_SINGLE || WIDE == 8, "slot and batch teams have eight members");
     constexpr int B = REFINE_B;
     constexpr bool SLOTS = MODE == TEAM_SLOTS;
     if (MODE == TEAM_SINGLE && spec_gate_closed(a)) return;
@@ -625,9 +626,9 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         win = team_select_exact(a, writer, s_part, s_tot, s_best, s_besti, s_bestg, win_score, nc, rec_in);
     } else if (a.fold_select) {
         __syncthreads();  // (s_pow10, s_coop_dead)
-        team_collect<1>(census, co, s_tot, s_x);
+        team_collect<1, WIDE>(census, co, s_tot, s_x);
         note_census(census[0]);
-        win = team_select<CPL>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_x, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
+        win = team_select<CPL, WIDE>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_x, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
                                rec_in);
     } else {
         nc = a.n_contenders[0];
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
     if (a.E != 1) load_cells(a.sc + (size_t)e * 3 * P);
     if (SLOTS || a.fold_select != 1) {
-        team_collect<1>(census, co, s_tot, s_x);
+        team_collect<1, WIDE>(census, co, s_tot, s_x);
         note_census(census[0]);
     }
     CYC_END(1);
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     bool ends_refit = true;
     const double inv_f = 1.0 / cam.fx;
     for (;;) {
-        team_pass<CPL>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, lc, M, K, co, s_part, s_tot, s_x, g_cyc);
+        team_pass<CPL, WIDE>(a, cl, param, cam, band, run_set, ends_refit, next_set, sums, lc, M, K, co, s_part, s_tot, s_x, g_cyc);
         if (co.dead) break;  // an exchange timed out: the sums are garbage, the call reports it
         CYC_BEGIN();
         bool fresh = true;  // normal equations from this pass (else: state CHECK_ERR failed, retry from `prev` with a larger lambda)
@@ -834,12 +835,20 @@ unsigned long long launch_refine_team(const KArgs& a, hipStream_t s) {
         return b.coop_tag;
     }
     const dim3 grid(G * b.team_stride), block(REFINE_B);
+    // one instantiation per (cells per lane, members it can collect): see team_collect_lds
+#define ESAC_LAUNCH_TEAM(CPL_)                                                                                 \
+    do {                                                                                                       \
+        if (G <= 8)       hipLaunchKernelGGL((k_refine_team<CPL_, TEAM_SINGLE, 8>), grid, block, 0, s, b);     \
+        else if (G <= 16) hipLaunchKernelGGL((k_refine_team<CPL_, TEAM_SINGLE, 16>), grid, block, 0, s, b);    \
+        else              hipLaunchKernelGGL((k_refine_team<CPL_, TEAM_SINGLE, 32>), grid, block, 0, s, b);    \
+    } while (0)
     switch (cpl) {
-        case 1: hipLaunchKernelGGL((k_refine_team<1>), grid, block, 0, s, b); break;
-        case 2: hipLaunchKernelGGL((k_refine_team<2>), grid, block, 0, s, b); break;
-        case 3: hipLaunchKernelGGL((k_refine_team<3>), grid, block, 0, s, b); break;
-        default: hipLaunchKernelGGL((k_refine_team<4>), grid, block, 0, s, b); break;
+        case 1: ESAC_LAUNCH_TEAM(1); break;
+        case 2: ESAC_LAUNCH_TEAM(2); break;
+        case 3: ESAC_LAUNCH_TEAM(3); break;
+        default: ESAC_LAUNCH_TEAM(4); break;
     }
+#undef ESAC_LAUNCH_TEAM
     return b.coop_tag;
 }
 

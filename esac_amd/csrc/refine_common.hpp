@@ -281,9 +281,13 @@ __device__ __forceinline__ void team_publish(double own, const Coop& co) {
 // else touches until the next workgroup barrier.
 // team_collect_lds: the totals stay in LDS -- s_tot[k], and with NEG s_tot[32 + k] = -total (what the lane-dealt LM step
 // gathers per lane, lm_lanes.hpp) -- visible to every thread when it returns; team_collect reads all of them back.
-template <int NV, bool NEG>
+// WIDE = how many members the INSTANTIATION can collect: 8, 16 or 32 (co.expect <= WIDE; the launcher picks the kernel by the
+// team's size).  One path per instantiation: as run-time branches the three paths, inlined at every exchange site, grew the
+// team kernel by 2,000 instructions and cost the eight-member teams 1.5 us a call (round 6, profiles/r06_ab_team10.txt).
+template <int NV, bool NEG, int WIDE>
 __device__ __forceinline__ void team_collect_lds(Coop& co, double* s_tot, double* s_x = nullptr) {
     static_assert(NV <= 32 && REFINE_B == 256 && TEAM_MAX <= 32, "poll layout");
+    static_assert(WIDE == 8 || WIDE == 16 || WIDE == 32, "members an instantiation collects");
     if (co.dead) return;
     const unsigned long long want = co.tag | (co.arrivals + 1ull);
     const u32x4* buf = co.gran + (size_t)(co.arrivals & 1ull) * (TEAM_MAX * 32);
@@ -309,14 +313,13 @@ __device__ __forceinline__ void team_collect_lds(Coop& co, double* s_tot, double
         if ((spins & 63) != 0) return false;
         return wall_clock64() - t_first > co.spin_limit || __hip_atomic_load(co.failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == co.tag;
     };
-    bool row16 = false;
+    constexpr bool row16 = WIDE == 16;
     double val_b = 0.0;  // (9 .. 16 members: this thread's second value, 16 + t >> 4)
-    if (co.expect > 8 && co.expect <= 16) {
+    if constexpr (WIDE == 16) {
         // 9 .. 16 members (round 6: ten members of 480 cells hold TWO cells per lane on the 60x80 grid where eight hold three):
         // thread t polls values t >> 4 and 16 + (t >> 4) of member t & 15 -- two granule loads in flight -- and four DPP stages
         // add the members of a 16-lane row in one fixed order.  No LDS staging, no barrier in front of the sums (the path for
         // up to 32 members below costs ~0.25 us a round: with it ten members measured 0.6 us SLOWER than eight).
-        row16 = true;
         const int j16 = threadIdx.x & 15, k16 = threadIdx.x >> 4;
         const bool need_a = j16 < co.expect && k16 < NV, need_b = j16 < co.expect && 16 + k16 < NV;
         const u32x4* pa = buf + (need_a ? j16 * 32 + k16 : 0);
@@ -339,7 +342,7 @@ __device__ __forceinline__ void team_collect_lds(Coop& co, double* s_tot, double
             }
         }
         if (!need_b) val_b = 0.0;
-    } else if (co.expect <= 8 || s_x == nullptr) {
+    } else if constexpr (WIDE == 8) {
         if (j < co.expect && k < NV) {
             const u32x4* p = buf + j * 32 + k;
             for (long spins = 1;; spins++) {
@@ -393,7 +396,7 @@ __device__ __forceinline__ void team_collect_lds(Coop& co, double* s_tot, double
     val += dpp_move<0xB1>(val);   // lanes (0,1) (2,3) (4,5) (6,7)
     val += dpp_move<0x4E>(val);   // quads
     val += dpp_move<0x141>(val);  // all eight
-    if (row16) {
+    if constexpr (row16) {
         val += dpp_move<0x140>(val);  // row_mirror: the other eight members of the row
         val_b += dpp_move<0xB1>(val_b);
         val_b += dpp_move<0x4E>(val_b);
@@ -418,7 +421,7 @@ __device__ __forceinline__ void team_collect_lds(Coop& co, double* s_tot, double
     co.dead = *co.s_dead != 0;
     co.arrivals += 1ull;
 }
-template <int NV>
+template <int NV, int WIDE>
 __device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* s_tot, double* s_x = nullptr) {
     if (co.dead) {  // (v is DEFINED on every way out: the caller's accumulators then die at its reduction and are
                     // reduced in place -- left untouched here they stay live and every one of them is copied first)
@@ -426,7 +429,7 @@ __device__ __forceinline__ void team_collect(double (&v)[NV], Coop& co, double* 
         for (int kk = 0; kk < NV; kk++) v[kk] = 0.0;
         return;
     }
-    team_collect_lds<NV, false>(co, s_tot, s_x);
+    team_collect_lds<NV, false, WIDE>(co, s_tot, s_x);
 #pragma unroll
     for (int kk = 0; kk < NV; kk++) v[kk] = s_tot[kk];
 }

@@ -152,20 +152,8 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
         }
     }
     next_set = nset;
-    if (a.errs && use_next) {  // debug option (esac_hip_set_debug): the error image of the pose; nothing downstream reads it
-#pragma unroll
-        for (int p = 0; p < CPL; p++) {
-            if (!on[p]) continue;
-            float err = (float)sqrt(e2[p]);
-            if (!band.all_in) err = (nset >> p) & 1u ? fminf(err, band.tau_below) : fmaxf(err, band.tau);  // the fp32 value on the decided side
-            if (undecided[p]) {
-                double Rx[9];
-                rodrigues_vec2mat<false>(param, Rx, nullptr);
-                err = project_exact_err(Rx, param + 3, cam, (float)cl.X[p], (float)cl.Y[p], (float)cl.Z[p], (float)cl.px[p], (float)cl.py[p]);
-            }
-            a.errs[cl.cell[p]] = err < band.max_reproj ? err : band.max_reproj;
-        }
-    }
+    // (ESAC_DEBUG_ERROR_IMAGE is served by the one-workgroup kernel -- refine_team_members: a debug option's stores and its exact
+    // projections inside THIS loop cost every call 1.2 us: the code is here whether it runs or not)
     // (a), (c): 0/1 weights the optimiser cannot see through (one basic block, no chain sunk under a branch)
     double sums[TEAM_NSUM];
 #pragma unroll
@@ -760,6 +748,7 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
 int refine_team_members(const KArgs& a) {
     const int P = a.H * a.W;
     if (a.team < 2 || P > TEAM_MAX * TEAM_CPL_MAX * REFINE_B || P < ESAC_REFINE_TEAM_MIN_CELLS || !a.coop_partials) return 0;
+    if (a.errs) return 0;  // ESAC_DEBUG_ERROR_IMAGE: the error image is written by the one-workgroup kernel (k_refine)
     if (a.frames != 1) {  // a small batch: a team of 8 per frame (k_refine_team<CPL, TEAM_FRAMES>), all teams resident together
         return a.frames <= ESAC_TEAM_BATCH_MAX && P <= 8 * TEAM_CPL_MAX * REFINE_B && a.coop_max >= 8 * ESAC_TEAM_BATCH_MAX ? 8 : 0;
     }

@@ -139,7 +139,10 @@ __device__ __forceinline__ void team_pass(const KArgs& a, const TeamCells<CPL>& 
             any_undecided |= undecided[p];
             if (on[p] && (in2 || band.all_in)) nset |= 1u << p;
         }
-        if (__any(any_undecided)) {  // the reference's own sequence, op by op (rodrigues as cv::Rodrigues, contraction off)
+        // (a branch hint on the two paths a round practically never takes -- this one and the pseudo-inverse step: where the compiler
+        // lays them out is worth 0.9 us of the call; the kernel is bound by the instructions it fetches and issues, profiles/r06_ab_team10.txt.
+        // Hints on the cheap rare branches -- a dead exchange, the time-out -- measured 0.3 us the other way.)
+        if (__builtin_expect(__any(any_undecided) != 0, 0)) {  // the reference's own sequence, op by op (rodrigues as cv::Rodrigues, contraction off)
             double Rx[9];
             rodrigues_vec2mat<false>(param, Rx, nullptr);
 #pragma unroll
@@ -223,7 +226,7 @@ __device__ __forceinline__ bool team_step(bool fresh, const LaneConst& lc, const
     CYC_BEGIN();
     double dx[6];
     if (!fresh) CYC_ADD(17, 1);  // (profiling build: rejected trials ...
-    if (!lm_lane_solve<double>(c, dg, lc.hot, lambda, dx)) {
+    if (__builtin_expect(!lm_lane_solve<double>(c, dg, lc.hot, lambda, dx), 0)) {
         CYC_ADD(18, 1);          // ... and pseudo-inverse steps of the frame)
         double U21[21], g6[6];
         lm_lane_to_u21<double>(c, U21, g6);

@@ -264,4 +264,28 @@ __device__ __forceinline__ Centre map_centre(const KArgs& a, const float* __rest
 }
 
 
+// ---- speculative forward (KArgs::spec_mode): hand-offs between the streams of a call
+// Hand-off words between the streams of a speculative call: the epoch of the call they belong to, written through to memory
+// (sc1) and polled past the caches -- valid between any two CUs.
+__device__ __forceinline__ void spec_word_set(const KArgs& a, int which) {
+    __hip_atomic_store(a.spec_state + which, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool spec_word_is_set(const KArgs& a, int which) {
+    return __hip_atomic_load(a.spec_state + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+}
+// Every wait for such a word is bounded in wall time: a word that never comes (the other stream's launch failed, or something
+// else holds its queue) costs ESAC_SPEC_WAIT_TICKS and is reported (status 5: the host runs the call again in stream order) -- never a hang.
+constexpr long long ESAC_SPEC_WAIT_TICKS = 2000000;  // 20 ms of the 100 MHz wall clock
+__device__ __forceinline__ bool spec_wait_word(const KArgs& a, int which, int patience = 1) {
+    // (relaxed loads past the caches while waiting, ONE acquire when the word is there: an acquire per poll invalidates the XCD's
+    // L2 every 0.2 us under whatever else runs on it -- with the join and the ten members of the gated refinement polling
+    // beside the straggler chain, k_sample_decide took 23 us instead of 13.6)
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(a.spec_state + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > patience * ESAC_SPEC_WAIT_TICKS) return false;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
 }  // namespace esac

@@ -1140,20 +1140,18 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
 // platform even when it is long satisfied (scripts/dev/fork_join.hip, profiles/r06_*timeline*), a polled word ~1 us.
 // The waits are bounded in wall time: a word that never comes (the other stream's launch failed) costs ESAC_SPEC_WAIT_TICKS, is
 // counted in spec_state[5] and reported by the join (status 5) -- never a hang.
-constexpr long long ESAC_SPEC_WAIT_TICKS = 2000000;  // 20 ms of the 100 MHz wall clock
-__device__ __forceinline__ bool spec_wait_word(const KArgs& a, int which) {
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(a.spec_state + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > ESAC_SPEC_WAIT_TICKS) return false;
-    }
-    return true;
-}
 __global__ __launch_bounds__(64) void k_spec_wait(KArgs a, int which) {
     if (threadIdx.x == 0 && !spec_wait_word(a, which)) a.spec_state[5] += 1.0;  // (timed out: the chain runs late, the results stay right)
 }
 void launch_spec_wait(const KArgs& a, int which, hipStream_t s) { hipLaunchKernelGGL(k_spec_wait, dim3(1), dim3(64), 0, s, a, which); }
 
+// spec_mode 2: "the join is done" (its verdict in spec_state[0], every output it patched written back): what the gated second
+// refinement on the caller's stream waits for.  Called by the join's first wavefront behind its stores.
+__device__ __forceinline__ void spec_join_done(const KArgs& a) {
+    if (a.spec_mode != 2) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.spec_state + 7, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 template <int B>
 __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
     constexpr int K = ESAC_FIRST_WIDE_MAX / B;  // hypotheses per thread (sample_can_split: N <= ESAC_FIRST_WIDE_MAX)
@@ -1183,15 +1181,21 @@ __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
         strag[k] = in ? a.spec_flag[h] : 0;
         exact[k] = in ? a.exact_flag[h] : 0;
     }
-    const double rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
+    // spec_mode 1: the speculative refinement ran in front of this launch on the same stream -- its record and status word are
+    // there; spec_mode 2: this launch runs BESIDE it (behind the selection, on a stream of the context's own) and waits for its word
+    double rec_pre = 0.0;
+    if (a.spec_mode != 2) rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
     if (threadIdx.x == 0) {
         s_nc = 0;
         // the straggler chain and the stragglers' scores are the OTHER stream's: wait for its "done" word
-        s_chain_ok = spec_wait_word(a, 4);
+        bool ok = spec_wait_word(a, 4);
+        if (a.spec_mode == 2) ok = spec_wait_word(a, 6) && ok;
+        s_chain_ok = ok;
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the other stream's kernels wrote, not what this CU's caches hold
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the other streams' kernels wrote, not what this CU's caches hold
     const bool chain_ok = s_chain_ok != 0;
+    if (a.spec_mode == 2) rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int h = (int)threadIdx.x + k * B;
@@ -1355,23 +1359,27 @@ __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
             a.spec_state[0] = 0.0;
             a.spec_state[5] += 1.0;
         }
+        spec_join_done(a);
         return;
     }
     // the speculative refinement's record is final when it refined THE winner (and ran to its end: a team that timed out is the
     // host's business, status 3, exactly as on the serial route)
     const double rec_hyp = __shfl(rec_pre, ESAC_RES_HYP_K), rec_score = __shfl(rec_pre, ESAC_RES_SCORE_K);
-    const bool held = rec_hyp == (double)global_hyp(a, win) && rec_score == win_score;
+    // (spec_mode 2: the refinement started from the fp32 argmax of the settled hypotheses and knew no exact score -- the record gets it here)
+    const bool held = rec_hyp == (double)global_hyp(a, win) && (a.spec_mode == 2 || rec_score == win_score);
     if (!held && status != 3.0) {
         if (lane == 0) {
             a.spec_state[0] = a.epoch;
             a.spec_state[2] += 1.0;  // failed speculations on this context so far (ESAC_BUF_SPEC_INFO)
         }
         if (a.result_pin && a.spec_gate != 2) pin_deliver(a.result_pin, lane == 32 ? a.epoch : lane == 33 ? 4.0 : 0.0);  // (2: a gated refinement follows)
+        spec_join_done(a);
         return;
     }
     if (lane == 0) a.spec_state[0] = 0.0;
     double v = lane < 32 ? rec_pre : lane == 32 ? a.epoch : lane == 33 ? status : 0.0;
-    if (lane == ESAC_RES_PROB_K) v = exp(rec_score - (double)m) / acc[0];
+    if (lane == ESAC_RES_SCORE_K) v = win_score;
+    if (lane == ESAC_RES_PROB_K) v = exp(win_score - (double)m) / acc[0];  // (held: win_score is the record's score)
     if (lane == ESAC_RES_ENTROPY_K) v = entropy;
     if (lane == ESAC_RES_CONTENDERS_K) v = (double)(int)acc[2];
     if (lane < 32) {
@@ -1379,6 +1387,7 @@ __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
         if (a.result_user) a.result_user[lane] = lane == 31 ? (status == 3.0 ? 3.0 : 1.0) : v;  // ESAC_RES_VALID (refine_write_record)
     }
     if (a.result_pin) pin_deliver(a.result_pin, v);
+    spec_join_done(a);
 }
 void launch_spec_join(const KArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_spec_join<1024>, dim3(1), dim3(1024), 0, s, a); }
 

@@ -175,6 +175,7 @@ struct KArgs {
     int* spec_cnt;          // [1] workgroups of k_score_stragglers that are done (the last one writes spec_state[4] and leaves this at zero)
     int spec_gate;          // refinement kernels: 1 = return at once unless spec_state[0] is this call's epoch (asynchronous calls: the
                             // second refinement is enqueued unconditionally and runs only when the speculation failed)
+    int spec_debug;         // 1: ESAC_DEBUG_SPEC_SECOND_BEST
     // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
     int* order;           // [N] hypothesis at sorted position pos (sorted by expert)
     float* rt_sorted;     // [N,12] rt32 rows in sorted order

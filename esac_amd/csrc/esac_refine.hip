@@ -485,7 +485,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const long long cyc_start = clock64();
 #endif
     CYC_BEGIN();
-    if (!SLOTS && spec_gate_closed(a)) return;
+    if (!SLOTS && spec_gate_closed(a, &lds.coop_dead)) return;
     if (!SLOTS) spec_open_chain(a);
     if (SLOTS && (int)blockIdx.x >= a.bwd.n_sel[0]) return;
     if (SLOTS && a.bwd.team_max_slots > 0 && a.bwd.n_sel[0] <= a.bwd.team_max_slots) return;  // few slots: the team launch refines them
@@ -499,13 +499,16 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const bool writer = !SHARED || co.g == 0;  // the workgroup that owns the outputs
 
     // ---- draw(probs, training=false): argmax of the exact scores, first (global) index on ties
-    const int nc = SLOTS ? 0 : a.n_contenders[0];
-    const int picked = SLOTS ? 0 : refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
+    // (spec_mode 2 -- speculative with the selection running beside this kernel: the fp32 argmax of the settled hypotheses; score,
+    // probability, entropy and contender count of the record are k_spec_join's to fill in)
+    const bool fast_pick = !SLOTS && a.spec_mode == 2;
+    const int nc = SLOTS || fast_pick ? 0 : a.n_contenders[0];
+    const int picked = SLOTS ? 0 : fast_pick ? spec_pick_fast<B>(a, s_best, s_besti, s_bestg) : refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
     const int win = SLOTS ? a.bwd.sel[blockIdx.x] : picked;
     if (!SLOTS && spec_nothing_to_refine(a, win, writer)) return;
-    const double win_score = a.scores[win];
+    const double win_score = fast_pick ? 0.0 : a.scores[win];
     RecordInputs rec_in{0.0, 0.0, 0ull};
-    if (!SLOTS && writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
+    if (!SLOTS && writer && threadIdx.x < 64) rec_in = fast_pick ? RecordInputs{0.0, 0.0, a.status[0]} : refine_record_inputs(a, win_score);
     const int e = expert_of(a, win);
     const float* __restrict__ mx = a.sc + (size_t)e * 3 * P;
 

@@ -494,8 +494,6 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     static_assert(MODE == TEAM_SINGLE || WIDE == 8, "slot and batch teams have eight members");
     constexpr int B = REFINE_B;
     constexpr bool SLOTS = MODE == TEAM_SLOTS;
-    if (MODE == TEAM_SINGLE && spec_gate_closed(a)) return;
-    if (MODE == TEAM_SINGLE) spec_open_chain(a);
     if (MODE == TEAM_SINGLE && (blockIdx.x % a.team_stride) != 0) return;  // the other seven of every eight exist for placement: block b runs on XCD b % 8
     const int slot = MODE != TEAM_SINGLE ? (int)(blockIdx.x >> 6) * 8 + (int)(blockIdx.x & 7) : 0;  // slot / frame of this block's team
     if (SLOTS && slot >= a.bwd.n_sel[0]) return;
@@ -532,6 +530,8 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     double* const s_rt = lds.rt;
     double* const s_pow10 = lds.pow10;
     if (a.team_stride < 0) lds.pad[threadIdx.x] = 1;  // (never: keeps the allocation)
+    if (MODE == TEAM_SINGLE && spec_gate_closed(a, &lds.coop_dead)) return;  // (a gated launch: only when the join found the speculation failed)
+    if (MODE == TEAM_SINGLE) spec_open_chain(a);
     const int P = a.H * a.W;
     const Cam cam = make_cam(a);
     long long g_cyc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -622,11 +622,19 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         win = team_select<CPL, WIDE>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_x, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
                                rec_in);
     } else {
-        nc = a.n_contenders[0];
-        win = refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
-        if (MODE == TEAM_SINGLE && spec_nothing_to_refine(a, win, writer)) return;
-        win_score = a.scores[win];
-        if (writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
+        if (MODE == TEAM_SINGLE && a.spec_mode == 2) {
+            // speculative, the selection running beside this kernel: the fp32 argmax of the settled hypotheses; score, probability,
+            // entropy and contender count of the record are k_spec_join's to fill in
+            win = spec_pick_fast<B>(a, s_best, s_besti, s_bestg);
+            if (spec_nothing_to_refine(a, win, writer)) return;
+            if (writer && threadIdx.x < 64) rec_in = RecordInputs{0.0, 0.0, a.status[0]};
+        } else {
+            nc = a.n_contenders[0];
+            win = refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
+            if (MODE == TEAM_SINGLE && spec_nothing_to_refine(a, win, writer)) return;
+            win_score = a.scores[win];
+            if (writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
+        }
     }
     const int e = expert_of(a, win);
     double pose[6];

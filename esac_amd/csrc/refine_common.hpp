@@ -487,32 +487,114 @@ __device__ __forceinline__ int refine_pick_winner(const KArgs& a, double* s_best
 }
 
 // ---- speculative forward (KArgs::spec_mode, esac_kernels.hip: k_spec_join)
-// A gated launch (asynchronous calls: the second refinement is enqueued whatever the join will find) runs only when the join
-// marked this call's speculation as failed.
-__device__ __forceinline__ bool spec_gate_closed(const KArgs& a) { return a.spec_gate && a.spec_state[0] != a.epoch; }
-// Hand-off words between the two streams of a speculative call: the epoch of the call they belong to, written through to memory
-// (sc1) and polled past the caches -- valid between any two CUs.
-__device__ __forceinline__ void spec_word_set(const KArgs& a, int which) {
-    __hip_atomic_store(a.spec_state + which, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool spec_word_is_set(const KArgs& a, int which) {
-    return __hip_atomic_load(a.spec_state + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
+// A gated launch (the second refinement of a speculative call is enqueued with the call, whatever the join will find) runs only
+// when the join marked this call's speculation as failed.  spec_gate 1: the join ran in front of this launch on the same stream --
+// its verdict is there.  spec_gate 3: the join runs on a stream of the context's own (spec_mode 2) -- thread 0 waits for its "done"
+// word first.  s_flag: an int of LDS.  Workgroup-uniform; contains a barrier when the gate is 3.
+__device__ __forceinline__ bool spec_gate_closed(const KArgs& a, int* s_flag) {
+    if (!a.spec_gate) return false;
+    if (a.spec_gate == 3) {
+        // (the join itself waits up to 2 x ESAC_SPEC_WAIT_TICKS for its two words before it reports status 5: this wait outlasts it, so
+        // that the caller's stream never falls idle in front of the join's report)
+        if (threadIdx.x == 0) *s_flag = spec_wait_word(a, 7, 4) ? 1 : 0;
+        __syncthreads();
+        const bool came = *s_flag != 0;
+        __syncthreads();  // (s_flag is the caller's to reuse)
+        if (!came) return true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the join and the selection beside it wrote, not what this CU's caches hold
+        return __hip_atomic_load(a.spec_state + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch;
+    }
+    return a.spec_state[0] != a.epoch;
 }
 // "The straggler chain may start": the first workgroup of the SPECULATIVE refinement is running, i.e. the launch has its CUs.
 // (The chain's thousands of single-wavefront workgroups fill every SIMD; a refinement launched into that waits for it to drain.)
 __device__ __forceinline__ void spec_open_chain(const KArgs& a) {
-    if (a.spec_mode == 1 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) spec_word_set(a, 3);
+    if (a.spec_mode != 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) spec_word_set(a, 3);
 }
-// The speculative refinement found no settled contender (every hypothesis a straggler, or every settled score NaN): there is
-// nothing to refine yet -- the record says so (hypothesis -1: k_spec_join then sends the call to the second refinement).
-// Workgroup-uniform; every workgroup sharing the refinement takes the same way out.
+// spec_mode 2: "the speculative refinement is done" -- its record is in the workspace, its status word in spec_state[1].  Called by a
+// whole wavefront of the workgroup that owns the outputs, behind its stores.
+__device__ __forceinline__ void spec_refine_done(const KArgs& a) {
+    if (a.spec_mode != 2) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.spec_state + 6, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The speculative refinement found nothing to refine (every hypothesis a straggler, or every settled score NaN): the record says so
+// (hypothesis -1: k_spec_join then sends the call to the second refinement).  Workgroup-uniform; every workgroup sharing the
+// refinement takes the same way out.  spec_mode 1: `win` is refine_pick_winner's (no settled contender: exact_flag[win] == 0);
+// spec_mode 2: spec_pick_fast's (none: 0x7fffffff).
 __device__ __forceinline__ bool spec_nothing_to_refine(const KArgs& a, int win, bool writer) {
-    if (a.spec_mode != 1 || a.exact_flag[win]) return false;
-    if (writer && threadIdx.x == 0) {
-        a.result[ESAC_RES_HYP_K] = -1.0;
-        a.spec_state[1] = 0.0;
+    if (a.spec_mode == 0) return false;
+    if (a.spec_mode == 1 ? a.exact_flag[win] != 0 : win != 0x7fffffff) return false;
+    if (writer && threadIdx.x < 64) {
+        if (threadIdx.x == 0) {
+            a.result[ESAC_RES_HYP_K] = -1.0;
+            a.spec_state[1] = 0.0;
+        }
+        spec_refine_done(a);
     }
     return true;
+}
+// spec_mode 2: the hypothesis the speculative refinement works on is the fp32 argmax among the SETTLED hypotheses (first global
+// index on ties) -- the selection proper (band, exact re-scores: k_select_rescore) runs beside the refinement, and k_spec_join
+// checks that its winner is this one (the two differ only when the fp32 stream and the reference arithmetic order two
+// near-equal scores differently).  Every thread returns the (local) index, 0x7fffffff: none.  Contains a workgroup barrier.
+template <int B>
+__device__ __forceinline__ int spec_pick_fast_but(const KArgs& a, int skip, double* s_best, int* s_besti, int* s_bestg) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float bs = -INFINITY;
+    int bi = 0x7fffffff, bg = 0x7fffffff;
+    for (int h = threadIdx.x; h < a.N; h += B) {
+        if (a.spec_flag[h] || h == skip) continue;
+        const float s = a.fast_scores[h];
+        const int g = global_hyp(a, h);
+        if (s > bs || (s == bs && g < bg)) {  // (NaN: never)
+            bs = s;
+            bi = h;
+            bg = g;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float os = __shfl_xor(bs, o);
+        const int oi = __shfl_xor(bi, o);
+        const int og = __shfl_xor(bg, o);
+        if (os > bs || (os == bs && og < bg)) {
+            bs = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    __syncthreads();  // (s_best may still be read: a second pick)
+    if (lane == 0) {
+        s_best[wave] = (double)bs;
+        s_besti[wave] = bi;
+        s_bestg[wave] = bg;
+    }
+    __syncthreads();
+    double ds = s_best[0];
+    bi = s_besti[0];
+    bg = s_bestg[0];
+#pragma unroll
+    for (int w = 1; w < B / 64; w++) {
+        const double os = s_best[w];
+        const int oi = s_besti[w];
+        const int og = s_bestg[w];
+        if (os > ds || (os == ds && og < bg)) {
+            ds = os;
+            bi = oi;
+            bg = og;
+        }
+    }
+    return bi;
+}
+template <int B>
+__device__ __forceinline__ int spec_pick_fast(const KArgs& a, double* s_best, int* s_besti, int* s_bestg) {
+    int win = spec_pick_fast_but<B>(a, -1, s_best, s_besti, s_bestg);
+    if (a.spec_debug == 1 && win != 0x7fffffff) {  // ESAC_DEBUG_SPEC_SECOND_BEST (tests): the runner-up, if there is one
+        const int second = spec_pick_fast_but<B>(a, win, s_best, s_besti, s_bestg);
+        if (second != 0x7fffffff) win = second;
+    }
+    return win;
 }
 
 // ---- pose2trans (esac_util.h:537-548) and the result record.
@@ -576,7 +658,7 @@ __device__ __forceinline__ void refine_write_record(const KArgs& a, const Record
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wavefront: its LDS operations complete in order
     const double v = lane < 34 ? s_rec[lane] : 0.0;
-    if (a.spec_mode == 1 && lane == 33) a.spec_state[1] = v;  // speculative refinement: the status word waits for k_spec_join
+    if (a.spec_mode != 0 && lane == 33) a.spec_state[1] = v;  // speculative refinement: the status word waits for k_spec_join
     if (lane < 32) {
         a.result[lane] = v;
         // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" (0) from a record (1); 3 = the workgroups sharing this
@@ -588,6 +670,7 @@ __device__ __forceinline__ void refine_write_record(const KArgs& a, const Record
         // ~15-20 us of a blocking call's latency), 34 words + their check word, no fence (esac_kernels.hpp: pin_mix)
         pin_deliver(a.result_pin, v);
     }
+    spec_refine_done(a);
 }
 
 }  // namespace esac

@@ -369,6 +369,11 @@ int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
  * statement) and delivers the record, or, when the winner is not the one that was refined, has the refinement run again.  Every
  * output -- poses, scores, flags, statistics, the record -- is what the serial order produces (ESAC_BUF_SPEC_INFO counts). */
 #define ESAC_DEBUG_NO_SPECULATION 8
+/* ESAC_DEBUG_SPEC_SECOND_BEST (tests only): the speculative refinement starts from the SECOND-best settled hypothesis of the fp32
+ * ranking instead of the best -- the situation in which the fp32 stream and the reference arithmetic order two near-equal scores
+ * differently.  The join must find that the refined hypothesis is not the winner and the gated second refinement must deliver
+ * the serial route's outputs. */
+#define ESAC_DEBUG_SPEC_SECOND_BEST 16
 int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
 
 /* The winner's refinement (refineHyp, esac_util.h:378-454) on a single frame whose grid fits one workgroup's LDS list

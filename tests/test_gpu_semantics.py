@@ -604,24 +604,26 @@ def test_team_time_out_is_bounded_and_latches(oracle):
         rec = eng.forward_device(sc, hat, p).copy()
         return rec, time.perf_counter() - t0
 
-    _, dt0 = timed_call()
+    # (wall-clock bounds on a shared box: the references are the best of three calls, the upper bounds say "not seconds")
+    dt0 = min(timed_call()[1] for _ in range(3))
     eng.set_debug(coop_stall=True)
     try:
         rec1, dt1 = timed_call()
         info = eng.refine_info()
         assert info["team_fallbacks"] == 1 and info["mode"] == "one_workgroup" and not info["team_latched_off"], (info, dt1)
-        assert 0.0008 < dt1 - dt0 < 0.05, (dt0, dt1)  # the 1 ms wait + one workgroup's refinement (+ first-use costs of that route), not seconds
+        assert 0.0008 < dt1 - dt0 < 0.5, (dt0, dt1)  # the 1 ms wait + one workgroup's refinement (+ first-use costs of that route), not seconds
         np.testing.assert_array_equal(rec1[:31], solo[:31])
         rec2, dt2 = timed_call()
         info = eng.refine_info()
         assert info["team_fallbacks"] == 2 and info["team_latched_off"], info
-        assert 0.0008 < dt2 - dt0 < 0.05, (dt0, dt2)  # measured 1.2 ms (scripts/dev/stall_probe.py); the bound leaves room for a loaded host
-                                                      # (one run of the suite beside other jobs read 65 ms here once, 1.2 ms on three re-runs)
+        assert 0.0008 < dt2 - dt0 < 0.5, (dt0, dt2)  # measured 1.2 ms (scripts/dev/stall_probe.py); the bound leaves room for a loaded host
+                                                     # (one run of the suite beside other jobs read 65 ms here once, 1.2 ms on three re-runs)
         np.testing.assert_array_equal(rec2[:31], solo[:31])
         rec3, dt3 = timed_call()  # latched: one workgroup at once, no time-out to wait for
         info = eng.refine_info()
         assert info["team_fallbacks"] == 2 and info["mode"] == "one_workgroup" and not info["timed_out"] and info["team_latched_off"], info
         np.testing.assert_array_equal(rec3[:31], solo[:31])
+        dt3 = min([dt3] + [timed_call()[1] for _ in range(2)])  # (still latched: the same route every time)
         assert dt3 < dt0 + 0.0005, (dt0, dt3)
     finally:
         eng.set_debug()

@@ -21,10 +21,10 @@ pytestmark = pytest.mark.gpu
 KEYS = ("tries", "xy", "hyps", "flags", "scores", "user", "counts", "imap")
 
 
-def _run(engine, frame, ha, call, nospec, seed=1305, want_device_record=False):
+def _run(engine, frame, ha, call, nospec, seed=1305, want_device_record=False, second_best=False):
     E, _, H, W = frame["coords"].shape
     sc, hat = torch.from_numpy(frame["coords"]).cuda(), torch.from_numpy(ha).cuda()
-    engine.set_debug(no_speculation=nospec)
+    engine.set_debug(no_speculation=nospec, spec_second_best=second_best)
     try:
         p = engine.make_params(E, H, W, len(ha), focal=frame["focal"], ppx=frame["ppx"], ppy=frame["ppy"], sub_sampling=frame["sub"],
                                seed=seed, call=call)
@@ -105,6 +105,31 @@ def test_a_straggler_that_wins(engine, oracle):
                 r_err, t_err = S.pose_errors(spec["rec"][api.RES_POSE:api.RES_POSE + 16].reshape(4, 4), ref["pose"])
                 assert r_err <= 1e-4 and t_err <= 1e-3
     assert won >= 1 and held >= 1, (won, held)  # both ways out of the join were taken
+
+
+@pytest.mark.parametrize("E,N", [(3, 300), (10, 1024), (12, 4096)])
+def test_the_refined_hypothesis_is_not_the_winner_of_the_settled(engine, E, N):
+    """The speculative refinement starts from the fp32 argmax of the settled hypotheses while the selection proper (band, exact
+    re-scores) runs beside it; the two can disagree when the fp32 stream and the reference arithmetic order two near-equal scores
+    differently.  ESAC_DEBUG_SPEC_SECOND_BEST forces that situation (the refinement starts from the runner-up): the join must find
+    that the refined hypothesis is not the winner, the gated second refinement must run, and every output -- blocking and
+    asynchronous -- is the serial route's."""
+    for k in range(3):
+        f = S.make_frame(1200 + k, E=E)
+        ha = S.gating_assignment(f, N, mode="gating")
+        serial = _run(engine, f, ha, call=20 + k, nospec=True)
+        other = S.make_frame(1300 + k, E=E)
+        _run(engine, other, S.gating_assignment(other, N, mode="gating"), call=k, nospec=False)
+        spec = _run(engine, f, ha, call=20 + k, nospec=False, second_best=True)
+        assert spec["info"]["last_speculative"] and spec["info"]["last_failed"]
+        _assert_same(serial, spec, "second best, frame %d" % k)
+        _run(engine, other, S.gating_assignment(other, N, mode="gating"), call=k, nospec=False)
+        asyn = _run(engine, f, ha, call=20 + k, nospec=False, second_best=True, want_device_record=True)
+        assert asyn["info"]["last_failed"] and asyn["dev_rec"][31] == 1.0
+        for key in KEYS:
+            np.testing.assert_array_equal(serial[key], asyn[key], err_msg=key)
+        np.testing.assert_array_equal(asyn["dev_rec"][:31], serial["rec"][:31])
+        engine.check()
 
 
 def test_nothing_settled_by_the_first_pass(engine):

@@ -276,13 +276,20 @@ __device__ __forceinline__ bool spec_word_is_set(const KArgs& a, int which) {
 // Every wait for such a word is bounded in wall time: a word that never comes (the other stream's launch failed, or something
 // else holds its queue) costs ESAC_SPEC_WAIT_TICKS and is reported (status 5: the host runs the call again in stream order) -- never a hang.
 constexpr long long ESAC_SPEC_WAIT_TICKS = 2000000;  // 20 ms of the 100 MHz wall clock
-__device__ __forceinline__ bool spec_wait_word(const KArgs& a, int which, int patience = 1) {
+#ifndef ESAC_SPEC_POLL_SLEEP
+#define ESAC_SPEC_POLL_SLEEP 4  // x 64 cycles between two polls
+#endif
+__device__ __forceinline__ bool spec_wait_word(const KArgs& a, int which, int patience = 1, int which2 = -1) {
     // (relaxed loads past the caches while waiting, ONE acquire when the word is there: an acquire per poll invalidates the XCD's
     // L2 every 0.2 us under whatever else runs on it -- with the join and the ten members of the gated refinement polling
-    // beside the straggler chain, k_sample_decide took 23 us instead of 13.6)
+    // beside the straggler chain, k_sample_decide took 23 us instead of 13.6.  which2: a second word to wait for, polled in
+    // the same trip to memory.)
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(a.spec_state + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) {
-        __builtin_amdgcn_s_sleep(16);
+    for (;;) {
+        const double w1 = __hip_atomic_load(a.spec_state + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double w2 = which2 >= 0 ? __hip_atomic_load(a.spec_state + which2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.epoch;
+        if (w1 == a.epoch && w2 == a.epoch) break;
+        __builtin_amdgcn_s_sleep(ESAC_SPEC_POLL_SLEEP);
         if (wall_clock64() - t0 > patience * ESAC_SPEC_WAIT_TICKS) return false;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

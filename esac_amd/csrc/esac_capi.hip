@@ -120,7 +120,6 @@ struct esac_hip_ctx {
     // speculative forward (forward_impl): the straggler chain of the sampler runs on this stream beside the launch stream
     hipStream_t side = nullptr;
     hipStream_t side2 = nullptr;          // ... and the selection among the settled hypotheses + the join on this one, beside the speculative refinement
-    int spec_route = 2;                   // 2: selection and join beside the refinement (side2); 1: in front of / behind it on the launch stream (ESAC_SPEC_ROUTE)
     bool spec_off = false, spec_env_off = false;  // ESAC_DEBUG_NO_SPECULATION / ESAC_SPECULATE=0
     bool spec_second_best = false;        // ESAC_DEBUG_SPEC_SECOND_BEST
     long long spec_calls = 0;             // forward calls that took the speculative route
@@ -235,7 +234,6 @@ extern "C" int esac_hip_create(esac_hip_ctx** out, int device) {
     if (c->team_auto_env_off || getenv("ESAC_REFINE_TEAM")) c->team_auto = false;  // (an explicit start value is an explicit size)
     if (const char* e = getenv("ESAC_SLOT_TEAMS")) c->slot_teams = atoi(e) != 0;
     if (const char* e = getenv("ESAC_SPECULATE")) c->spec_off = c->spec_env_off = atoi(e) == 0;
-    if (const char* e = getenv("ESAC_SPEC_ROUTE")) c->spec_route = atoi(e) == 1 ? 1 : 2;
     *out = c;
     return 0;
 }
@@ -665,7 +663,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
     if (spec_ok && !c->side) {
         HIP_OK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     }
-    if (spec_ok && c->spec_route == 2 && !c->side2) {
+    if (spec_ok && !c->side2) {
         HIP_OK(hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking));
     }
     if (tm) HIP_OK(hipEventRecord(c->ev[0], s));
@@ -699,51 +697,38 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         // single-wavefront workgroups fill every SIMD of the chip, and whatever the launch stream starts while it is in full
         // swing finds no CU to run on until it has drained (measured: started behind the first pass, the selection took 27 us
         // instead of 10; started behind the score kernel, the refinement's team waited 34 us for its CUs).
-        // spec_route 2 (round 6, second half): the SELECTION among the settled hypotheses leaves the critical path too.  The refinement
-        // starts from the fp32 argmax of the settled hypotheses (spec_mode 2: spec_pick_fast) right behind the score kernel; the
-        // selection kernel (band, exact re-scores) and the join behind it run on a second stream of the context's own, the join
-        // resident and waiting when the refinement and the chain finish ("the refinement is done": spec_state[6]); the gated second
-        // refinement on the caller's stream waits for the join's verdict ("the join is done": spec_state[7]).  Every waiter is still
-        // enqueued behind what it waits for.
-        const bool beside = c->spec_route == 2;
-        if (!beside) {
-            launch_select_rescore(as, s);
-            if ((rc = check_launch("k_select_rescore (settled)"))) return rc;
-        }
+        // The SELECTION among the settled hypotheses is not on the critical path either (round 6, second half).  The refinement starts
+        // from the fp32 argmax of the settled hypotheses (spec_mode 2: spec_pick_fast) right behind the score kernel; the selection
+        // kernel (band, exact re-scores) and the join behind it run on a second stream of the context's own, the join resident and
+        // waiting when the refinement and the chain finish ("the refinement is done": spec_state[6]); the gated second refinement
+        // on the caller's stream waits for the join's verdict ("the join is done": spec_state[7]).  Every waiter is enqueued
+        // behind what it waits for.  (With selection and join on the caller's stream, in front of and behind the refinement:
+        // cfg3 0.1404 ms against 0.1288, cfg4 0.1915 against 0.184, same box -- profiles/r06_ab_select_beside.txt.)
         if (tm) HIP_OK(hipEventRecord(c->ev[3], s));
         KArgs ar = as;
-        if (beside) ar.spec_mode = 2;
+        ar.spec_mode = 2;
         ar.spec_debug = c->spec_second_best ? 1 : 0;
         c->refine_tag = launch_refine(ar, s);  // (its first workgroup opens the chain: spec_open_chain)
         c->refine_was_team = refine_team_members(ar) > 0;
         if ((rc = check_launch("k_refine (speculative)"))) return rc;
         // (host order: the selection first -- the join waits behind it; a launch call is 3-4 us of host time, and the chain's five
         // in front of it would hold the selection back by 20 us.  The JOIN is enqueued behind the chain it waits for.)
-        if (beside) {
-            launch_spec_wait(a, 3, c->side2);
-            launch_select_rescore(as, c->side2);
-            if ((rc = check_launch("k_select_rescore (settled)"))) return rc;
-        }
+        launch_spec_wait(a, 3, c->side2);
+        launch_select_rescore(as, c->side2);
+        if ((rc = check_launch("k_select_rescore (settled)"))) return rc;
         launch_spec_wait(a, 3, c->side);
         launch_sample_stragglers_on(chain, chain_waves, c->side);
         launch_score_stragglers(a, c->side);  // behind the chain on the side stream; its last workgroup writes "the chain is done"
         if ((rc = check_launch("straggler chain"))) return rc;
-        KArgs aj = a;
-        aj.spec_gate = 2;
-        if (beside) {
-            aj.spec_mode = 2;
-            launch_spec_join(aj, c->side2);
-        } else {
-            launch_spec_join(aj, s);
-        }
+        launch_spec_join(a, c->side2);
         if ((rc = check_launch("k_spec_join"))) return rc;
         {
             // The second refinement is enqueued NOW and returns at once unless the join marked the speculation as failed
             // (KArgs::spec_gate): a failed speculation then costs the refinement, not a host round trip on top of it (and an
             // asynchronous call could not look at the join's verdict anyway); a speculation that held has delivered its record
-            // before this launch starts
+            // before the gate opens
             KArgs ag = a;
-            ag.spec_gate = beside ? 3 : 1;
+            ag.spec_gate = 1;
             const unsigned long long tag2 = launch_refine(ag, s);
             (void)tag2;  // (esac_hip_check follows the speculative launch's tag: a team time-out there is the common case of the two)
             if ((rc = check_launch("k_refine (gated)"))) return rc;

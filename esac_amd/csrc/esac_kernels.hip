@@ -1121,21 +1121,24 @@ __global__ __launch_bounds__(B) void k_select_rescore(KArgs a) {
 }
 
 // ================================================================= speculative forward: the join
-// The launch stream has scored, selected among and refined the winner of the hypotheses the sampler's first pass SETTLED; the
-// straggler chain and the stragglers' fp32 scores have finished beside it.  This kernel (ONE workgroup, the arithmetic of
-// k_select_rescore<1024, true> statement by statement, so that every number is the serial route's) completes the selection over
-// ALL hypotheses:
+// The launch stream has scored the hypotheses the sampler's first pass SETTLED and refined the best of them (fp32 ranking); on a
+// second stream of the context's own the selection among the settled hypotheses (k_select_rescore, spec_mode 1) has run beside that
+// refinement, and this kernel behind it; on the first one the straggler chain and the stragglers' fp32 scores.  This kernel (ONE
+// workgroup, the arithmetic of k_select_rescore<1024, true> statement by statement, so that every number is the serial route's) is
+// resident before refinement and chain are done, loads what the selection left, waits for their two "done" words, and completes the
+// selection over ALL hypotheses:
 //   * fp32 maximum and band over all of them; a settled hypothesis that was a contender of the narrower (settled-only) band but is
 //     not one of the final band gets its fp32 score back (what the serial route leaves there); a straggler outside the band gets
 //     its fp32 score, one inside is re-scored in reference arithmetic (esac_util.h:235-260) -- practically never: stragglers are
 //     wrong-expert hypotheses;
 //   * softMax / entropy statistics over all fp32 scores (esac_util.h:461-497), number of contenders;
 //   * draw's argmax over the exact scores of the final band, first global index on ties (esac_util.h:512-529).
-// It is the speculative winner (what else, with stragglers that score a hundredth of it): the record the refinement left in the
-// workspace gets the final probability / entropy / contender count and goes to the caller (device record, pinned host slot).
-// Otherwise spec_state[0] = this call's epoch: a blocking call reads status 4 from the pinned slot and launches the refinement
-// again (the workspace now holds exactly what k_select_rescore would have left: refine_pick_winner finds the true winner); an
-// asynchronous call has that launch enqueued already, gated on this word.
+// It is the hypothesis that was refined (what else, with stragglers that score a hundredth of it -- unless the fp32 stream and
+// the reference arithmetic order two near-equal scores differently): the record the refinement left in the workspace gets the
+// exact score, the final probability / entropy / contender count and goes to the caller (device record, pinned host slot).
+// Otherwise spec_state[0] = this call's epoch: the second refinement launch, enqueued with the call on the caller's stream and
+// waiting for this kernel's "done" word (spec_state[7]), runs -- the workspace now holds exactly what k_select_rescore would have
+// left: refine_pick_winner finds the true winner.
 // Hand-off words instead of events: an event between two streams costs the waiting side 8-13 us on this
 // platform even when it is long satisfied (scripts/dev/fork_join.hip, profiles/r06_*timeline*), a polled word ~1 us.
 // The waits are bounded in wall time: a word that never comes (the other stream's launch failed) costs ESAC_SPEC_WAIT_TICKS, is
@@ -1145,10 +1148,9 @@ __global__ __launch_bounds__(64) void k_spec_wait(KArgs a, int which) {
 }
 void launch_spec_wait(const KArgs& a, int which, hipStream_t s) { hipLaunchKernelGGL(k_spec_wait, dim3(1), dim3(64), 0, s, a, which); }
 
-// spec_mode 2: "the join is done" (its verdict in spec_state[0], every output it patched written back): what the gated second
-// refinement on the caller's stream waits for.  Called by the join's first wavefront behind its stores.
+// "The join is done" (its verdict in spec_state[0], every output it patched written back): what the gated second refinement on
+// the caller's stream waits for.  Called by the join's first wavefront behind its stores.
 __device__ __forceinline__ void spec_join_done(const KArgs& a) {
-    if (a.spec_mode != 2) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(a.spec_state + 7, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1181,21 +1183,16 @@ __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
         strag[k] = in ? a.spec_flag[h] : 0;
         exact[k] = in ? a.exact_flag[h] : 0;
     }
-    // spec_mode 1: the speculative refinement ran in front of this launch on the same stream -- its record and status word are
-    // there; spec_mode 2: this launch runs BESIDE it (behind the selection, on a stream of the context's own) and waits for its word
-    double rec_pre = 0.0;
-    if (a.spec_mode != 2) rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
     if (threadIdx.x == 0) {
         s_nc = 0;
-        // the straggler chain and the stragglers' scores are the OTHER stream's: wait for its "done" word
-        bool ok = spec_wait_word(a, 4);
-        if (a.spec_mode == 2) ok = spec_wait_word(a, 6) && ok;
-        s_chain_ok = ok;
+        // the straggler chain with the stragglers' scores and the speculative refinement are OTHER streams': wait for their "done" words
+        s_chain_ok = spec_wait_word(a, 4, 1, 6);
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the other streams' kernels wrote, not what this CU's caches hold
     const bool chain_ok = s_chain_ok != 0;
-    if (a.spec_mode == 2) rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
+    // the speculative refinement's record and status word
+    const double rec_pre = threadIdx.x < 32 ? a.result[threadIdx.x] : threadIdx.x == 33 ? a.spec_state[1] : 0.0;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int h = (int)threadIdx.x + k * B;
@@ -1365,14 +1362,13 @@ __global__ __launch_bounds__(B) void k_spec_join(KArgs a) {
     // the speculative refinement's record is final when it refined THE winner (and ran to its end: a team that timed out is the
     // host's business, status 3, exactly as on the serial route)
     const double rec_hyp = __shfl(rec_pre, ESAC_RES_HYP_K), rec_score = __shfl(rec_pre, ESAC_RES_SCORE_K);
-    // (spec_mode 2: the refinement started from the fp32 argmax of the settled hypotheses and knew no exact score -- the record gets it here)
-    const bool held = rec_hyp == (double)global_hyp(a, win) && (a.spec_mode == 2 || rec_score == win_score);
+    // (the refinement started from the fp32 argmax of the settled hypotheses and knew no exact score -- the record gets it here)
+    const bool held = rec_hyp == (double)global_hyp(a, win);
     if (!held && status != 3.0) {
         if (lane == 0) {
             a.spec_state[0] = a.epoch;
             a.spec_state[2] += 1.0;  // failed speculations on this context so far (ESAC_BUF_SPEC_INFO)
         }
-        if (a.result_pin && a.spec_gate != 2) pin_deliver(a.result_pin, lane == 32 ? a.epoch : lane == 33 ? 4.0 : 0.0);  // (2: a gated refinement follows)
         spec_join_done(a);
         return;
     }

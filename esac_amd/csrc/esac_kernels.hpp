@@ -165,16 +165,18 @@ struct KArgs {
     // beside them on a stream of the context's own; k_spec_join then folds the stragglers in and delivers -- or finds that a
     // straggler wins after all, and the refinement runs again for it.  Every output is what the serial order produces.
     int spec_mode;          // 0: off.  Score / selection kernels: 1 = the settled hypotheses only (spec_flag[h] == 0).
-                            // Refinement kernels: 1 = speculative (no record leaves the workspace; the status word
-                            // goes to spec_state[1]; no settled contender at all: give up at once)
+                            // Refinement kernels: 2 = speculative (the hypothesis to refine is the fp32 argmax of the settled ones --
+                            // the selection runs beside the refinement; no record leaves the workspace; the status word goes to
+                            // spec_state[1], then "done" to spec_state[6]; nothing settled at all: give up at once)
     uint8_t* spec_flag;     // [N] 1: the sampler's first pass left hypothesis h to the straggler chain (written there, read-only afterwards)
     double* spec_state;     // [8] [0] the epoch of the call whose speculation FAILED (k_spec_join), [1] status word of the speculative
                             // refinement, [2] failed speculations so far, [3] "the chain may start" = the epoch of the call whose
                             // speculative refinement has STARTED (its workgroups are resident), [4] "the chain is done" = the epoch
-                            // of the call whose straggler chain has finished, [5] hand-offs that timed out so far
+                            // of the call whose straggler chain has finished, [5] hand-offs that timed out so far, [6] "the speculative
+                            // refinement is done", [7] "the join is done" (each the epoch of the call it belongs to)
     int* spec_cnt;          // [1] workgroups of k_score_stragglers that are done (the last one writes spec_state[4] and leaves this at zero)
-    int spec_gate;          // refinement kernels: 1 = return at once unless spec_state[0] is this call's epoch (asynchronous calls: the
-                            // second refinement is enqueued unconditionally and runs only when the speculation failed)
+    int spec_gate;          // refinement kernels: 1 = wait for "the join is done", then return at once unless spec_state[0] is this call's
+                            // epoch (the second refinement is enqueued with the call and runs only when the speculation failed)
     int spec_debug;         // 1: ESAC_DEBUG_SPEC_SECOND_BEST
     // tile-stationary score (esac_score_tiled.hip); null / 0 when the call uses the per-hypothesis stream
     int* order;           // [N] hypothesis at sorted position pos (sorted by expert)

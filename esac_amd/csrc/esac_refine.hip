@@ -505,7 +505,7 @@ __global__ __launch_bounds__(B) void k_refine(KArgs a) {
     const int nc = SLOTS || fast_pick ? 0 : a.n_contenders[0];
     const int picked = SLOTS ? 0 : fast_pick ? spec_pick_fast<B>(a, s_best, s_besti, s_bestg) : refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
     const int win = SLOTS ? a.bwd.sel[blockIdx.x] : picked;
-    if (!SLOTS && spec_nothing_to_refine(a, win, writer)) return;
+    if (fast_pick && spec_nothing_to_refine(a, win, writer)) return;
     const double win_score = fast_pick ? 0.0 : a.scores[win];
     RecordInputs rec_in{0.0, 0.0, 0ull};
     if (!SLOTS && writer && threadIdx.x < 64) rec_in = fast_pick ? RecordInputs{0.0, 0.0, a.status[0]} : refine_record_inputs(a, win_score);

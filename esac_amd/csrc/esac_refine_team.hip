@@ -631,7 +631,6 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         } else {
             nc = a.n_contenders[0];
             win = refine_pick_winner<B>(a, s_best, s_besti, s_bestg);
-            if (MODE == TEAM_SINGLE && spec_nothing_to_refine(a, win, writer)) return;
             win_score = a.scores[win];
             if (writer && threadIdx.x < 64) rec_in = refine_record_inputs(a, win_score);
         }

@@ -488,13 +488,12 @@ __device__ __forceinline__ int refine_pick_winner(const KArgs& a, double* s_best
 
 // ---- speculative forward (KArgs::spec_mode, esac_kernels.hip: k_spec_join)
 // A gated launch (the second refinement of a speculative call is enqueued with the call, whatever the join will find) runs only
-// when the join marked this call's speculation as failed.  spec_gate 1: the join ran in front of this launch on the same stream --
-// its verdict is there.  spec_gate 3: the join runs on a stream of the context's own (spec_mode 2) -- thread 0 waits for its "done"
-// word first.  s_flag: an int of LDS.  Workgroup-uniform; contains a barrier when the gate is 3.
+// when the join marked this call's speculation as failed.  The join runs on a stream of the context's own: thread 0 waits for its
+// "done" word first.  s_flag: an int of LDS.  Workgroup-uniform; contains barriers when the launch is gated.
 __device__ __forceinline__ bool spec_gate_closed(const KArgs& a, int* s_flag) {
     if (!a.spec_gate) return false;
-    if (a.spec_gate == 3) {
-        // (the join itself waits up to 2 x ESAC_SPEC_WAIT_TICKS for its two words before it reports status 5: this wait outlasts it, so
+    {
+        // (the join itself waits up to ESAC_SPEC_WAIT_TICKS for its two words before it reports status 5: this wait outlasts it, so
         // that the caller's stream never falls idle in front of the join's report)
         if (threadIdx.x == 0) *s_flag = spec_wait_word(a, 7, 4) ? 1 : 0;
         __syncthreads();
@@ -504,14 +503,13 @@ __device__ __forceinline__ bool spec_gate_closed(const KArgs& a, int* s_flag) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the join and the selection beside it wrote, not what this CU's caches hold
         return __hip_atomic_load(a.spec_state + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch;
     }
-    return a.spec_state[0] != a.epoch;
 }
 // "The straggler chain may start": the first workgroup of the SPECULATIVE refinement is running, i.e. the launch has its CUs.
 // (The chain's thousands of single-wavefront workgroups fill every SIMD; a refinement launched into that waits for it to drain.)
 __device__ __forceinline__ void spec_open_chain(const KArgs& a) {
-    if (a.spec_mode != 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) spec_word_set(a, 3);
+    if (a.spec_mode == 2 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) spec_word_set(a, 3);
 }
-// spec_mode 2: "the speculative refinement is done" -- its record is in the workspace, its status word in spec_state[1].  Called by a
+// "The speculative refinement is done" -- its record is in the workspace, its status word in spec_state[1].  Called by a
 // whole wavefront of the workgroup that owns the outputs, behind its stores.
 __device__ __forceinline__ void spec_refine_done(const KArgs& a) {
     if (a.spec_mode != 2) return;
@@ -520,11 +518,9 @@ __device__ __forceinline__ void spec_refine_done(const KArgs& a) {
 }
 // The speculative refinement found nothing to refine (every hypothesis a straggler, or every settled score NaN): the record says so
 // (hypothesis -1: k_spec_join then sends the call to the second refinement).  Workgroup-uniform; every workgroup sharing the
-// refinement takes the same way out.  spec_mode 1: `win` is refine_pick_winner's (no settled contender: exact_flag[win] == 0);
-// spec_mode 2: spec_pick_fast's (none: 0x7fffffff).
+// refinement takes the same way out.  `win`: spec_pick_fast's (none: 0x7fffffff).
 __device__ __forceinline__ bool spec_nothing_to_refine(const KArgs& a, int win, bool writer) {
-    if (a.spec_mode == 0) return false;
-    if (a.spec_mode == 1 ? a.exact_flag[win] != 0 : win != 0x7fffffff) return false;
+    if (a.spec_mode != 2 || win != 0x7fffffff) return false;
     if (writer && threadIdx.x < 64) {
         if (threadIdx.x == 0) {
             a.result[ESAC_RES_HYP_K] = -1.0;
@@ -534,7 +530,7 @@ __device__ __forceinline__ bool spec_nothing_to_refine(const KArgs& a, int win, 
     }
     return true;
 }
-// spec_mode 2: the hypothesis the speculative refinement works on is the fp32 argmax among the SETTLED hypotheses (first global
+// The hypothesis the speculative refinement works on is the fp32 argmax among the SETTLED hypotheses (first global
 // index on ties) -- the selection proper (band, exact re-scores: k_select_rescore) runs beside the refinement, and k_spec_join
 // checks that its winner is this one (the two differ only when the fp32 stream and the reference arithmetic order two
 // near-equal scores differently).  Every thread returns the (local) index, 0x7fffffff: none.  Contains a workgroup barrier.
@@ -658,7 +654,7 @@ __device__ __forceinline__ void refine_write_record(const KArgs& a, const Record
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // one wavefront: its LDS operations complete in order
     const double v = lane < 34 ? s_rec[lane] : 0.0;
-    if (a.spec_mode != 0 && lane == 33) a.spec_state[1] = v;  // speculative refinement: the status word waits for k_spec_join
+    if (a.spec_mode == 2 && lane == 33) a.spec_state[1] = v;  // speculative refinement: the status word waits for k_spec_join
     if (lane < 32) {
         a.result[lane] = v;
         // ESAC_RES_VALID: lets a zero-padded exchange buffer tell "no record" (0) from a record (1); 3 = the workgroups sharing this

@@ -362,11 +362,13 @@ int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
 /* ESAC_DEBUG_NO_SPECULATION (tests, A/B measurements): esac_hip_forward runs its kernels strictly one after the other on the
  * caller's stream.  By default a single-frame call with several experts and at most 8192 hypotheses (the screened sampling
  * route, the fp32 ranking stream, grids below 32768 cells) is SPECULATIVE: once the sampler's first pass (32 tries per
- * hypothesis) has settled the hypotheses of usable experts, those are scored, selected from and their winner refined on the
- * caller's stream, while the sampler's straggler chain -- the wrong-expert hypotheses that need ~10^3 tries each and practically
- * never win -- and the stragglers' scores run beside them on a stream the context owns; a join kernel then completes the
- * selection over all hypotheses (band, re-scores, softmax statistics, argmax: the serial route's arithmetic statement by
- * statement) and delivers the record, or, when the winner is not the one that was refined, has the refinement run again.  Every
+ * hypothesis) has settled the hypotheses of usable experts, those are scored and the best of them (fp32 ranking) is refined on
+ * the caller's stream, while on two streams the context owns the sampler's straggler chain -- the wrong-expert hypotheses that
+ * need ~10^3 tries each and practically never win -- with the stragglers' scores, and the selection among the settled hypotheses
+ * (band, exact re-scores) run beside that refinement; a join kernel then completes the selection over all hypotheses (band,
+ * re-scores, softmax statistics, argmax: the serial route's arithmetic statement by statement) and delivers the record, or, when
+ * the winner is not the hypothesis that was refined, has the refinement run again (a second launch, enqueued with the call on the
+ * caller's stream and gated on the join's verdict: work the caller enqueues behind the call sees the final outputs).  Every
  * output -- poses, scores, flags, statistics, the record -- is what the serial order produces (ESAC_BUF_SPEC_INFO counts). */
 #define ESAC_DEBUG_NO_SPECULATION 8
 /* ESAC_DEBUG_SPEC_SECOND_BEST (tests only): the speculative refinement starts from the SECOND-best settled hypothesis of the fp32

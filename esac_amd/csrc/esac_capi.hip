@@ -325,7 +325,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     rc |= alloc(&c->ws.span_acc, (size_t)2);
     rc |= alloc(&c->ws.spec_flag, (size_t)nN);
     rc |= alloc(&c->ws.spec_state, (size_t)8);
-    rc |= alloc(&c->ws.spec_cnt, (size_t)1);
+    rc |= alloc(&c->ws.spec_cnt, (size_t)ESAC_SPEC_CNT_INTS);
     if (rc) {
         if (old_hyps) (void)hipFree(old_hyps);
         return rc;
@@ -333,7 +333,7 @@ static int ensure_ws(esac_hip_ctx* c, int N1, int P1, int B = 1) {
     HIP_OK(hipMemset(c->ws.span_acc, 0, 2 * sizeof(long long)));
     HIP_OK(hipMemset(c->ws.spec_flag, 0, (size_t)nN));
     HIP_OK(hipMemset(c->ws.spec_state, 0, 8 * sizeof(double)));
-    HIP_OK(hipMemset(c->ws.spec_cnt, 0, sizeof(int)));
+    HIP_OK(hipMemset(c->ws.spec_cnt, 0, ESAC_SPEC_CNT_INTS * sizeof(int)));
     HIP_OK(hipMemset(c->ws.coop_counter, 0, 2 * sizeof(unsigned long long)));  // [1]: tag of the last failed shared refinement (esac_hip_check)
     HIP_OK(hipMemset(c->ws.coop_partials, 0, (size_t)ESAC_TEAM_BATCH_MAX * ESAC_TEAM_GRANULES * 2 * sizeof(double)));  // (also the teams' granules)
     HIP_OK(hipMemset(c->ws.refine_info, 0, 8 * sizeof(int)));

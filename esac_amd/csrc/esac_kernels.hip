@@ -939,10 +939,23 @@ __global__ __launch_bounds__(B) void k_score_stragglers(KArgs a) {
     }
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (nwork <= 1 || __hip_atomic_fetch_add(a.spec_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwork - 1) {
-            __hip_atomic_store(a.spec_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(a.spec_state + 4, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // arrivals in two levels: workgroup b at counter 1 + b % 32 (each on a cache line of its own), the last one there at counter
+        // 0 -- at most ~32 atomics on any one address (the 900 stragglers of the 12-expert shape at ONE counter were 4 us of this
+        // kernel, which is the end of the call's critical path there)
+        bool last = true;
+        if (nwork > 1) {
+            const int j = (int)blockIdx.x & (ESAC_SPEC_CNT_FAN - 1);
+            const int expect = (nwork - j + ESAC_SPEC_CNT_FAN - 1) / ESAC_SPEC_CNT_FAN;  // workgroups b < nwork with b % FAN == j
+            int* const sub = a.spec_cnt + ESAC_SPEC_CNT_STRIDE * (1 + j);
+            last = __hip_atomic_fetch_add(sub, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1;
+            if (last) {
+                __hip_atomic_store(sub, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int groups = nwork < ESAC_SPEC_CNT_FAN ? nwork : ESAC_SPEC_CNT_FAN;
+                last = __hip_atomic_fetch_add(a.spec_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1;
+                if (last) __hip_atomic_store(a.spec_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
+        if (last) __hip_atomic_store(a.spec_state + 4, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

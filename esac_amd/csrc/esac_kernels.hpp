@@ -94,6 +94,8 @@ struct BwdArgs {
                                      // pinned slot (KArgs::result_pin) and leaves this at zero
 };
 
+constexpr int ESAC_SPEC_CNT_FAN = 32, ESAC_SPEC_CNT_STRIDE = 32;  // counters of the second level; ints between two counters (128 bytes)
+constexpr int ESAC_SPEC_CNT_INTS = ESAC_SPEC_CNT_STRIDE * (1 + ESAC_SPEC_CNT_FAN);
 struct KArgs {
     // inputs (device)
     const float* sc;        // [E,3,H,W]
@@ -174,7 +176,8 @@ struct KArgs {
                             // speculative refinement has STARTED (its workgroups are resident), [4] "the chain is done" = the epoch
                             // of the call whose straggler chain has finished, [5] hand-offs that timed out so far, [6] "the speculative
                             // refinement is done", [7] "the join is done" (each the epoch of the call it belongs to)
-    int* spec_cnt;          // [1] workgroups of k_score_stragglers that are done (the last one writes spec_state[4] and leaves this at zero)
+    int* spec_cnt;          // [ESAC_SPEC_CNT_INTS] arrival counters of k_score_stragglers' workgroups, two levels (the last arrival writes
+                            // spec_state[4]; every counter is left at zero)
     int spec_gate;          // refinement kernels: 1 = wait for "the join is done", then return at once unless spec_state[0] is this call's
                             // epoch (the second refinement is enqueued with the call and runs only when the speculation failed)
     int spec_debug;         // 1: ESAC_DEBUG_SPEC_SECOND_BEST

@@ -638,8 +638,8 @@ def main():
             speculative = bool(spec_info and spec_info["calls"])
             if speculative:
                 out["kernels_note"] = ("stage times are those of the launch sequence IN STREAM ORDER (esac_hip_time_stages); the timed steps ran the "
-                                       "speculative route, where most of the `sample` stage -- the straggler chain -- runs on the context's own stream "
-                                       "beside score / select / refine: ms_per_step is less than the sum of the stages (profiles/r06_timeline_%s.txt)" % config_name)
+                                       "speculative route, where most of the `sample` stage -- the straggler chain -- and the `select_rescore` stage run on the context's own streams "
+                                       "beside the refinement: ms_per_step is less than the sum of the stages (profiles/r06_timeline_%s.txt)" % config_name)
             # what a step spends outside its kernels: against the live stage times and against the committed rocprofv3 durations
             # (not defined for the speculative route: its kernels overlap)
             rp = [r.get("rocprofv3_avg_us") for r in kernels]

@@ -249,14 +249,14 @@ __device__ __forceinline__ bool team_step(bool fresh, const LaneConst& lc, const
 // k_select_rescore writes: scores / exact_flag / scores_user of every hypothesis, n_contenders, stats (member 0).
 constexpr int TEAM_SEL_CHUNK = 16;  // contenders re-scored per exchange (16 x 12 pose values fit one load per thread)
 template <int CPL, int WIDE>
-__device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>& cl, bool cells_loaded, int cell0, int cell1, const Cam& cam, Coop& co,
+__device__ __forceinline__ int team_select(const KArgs& a, const float fs, const TeamCells<CPL>& cl, bool cells_loaded, int cell0, int cell1, const Cam& cam, Coop& co,
                                            bool writer, double* s_part, double* s_tot, double* s_x, double* s_best, int* s_besti, int* s_bestg, int* s_list,
                                            double* s_rt, double& win_score, int& nc_out, RecordInputs& rec_in) {
     constexpr int B = REFINE_B;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int P = a.H * a.W;
-    // fp32 maximum (NaN-ignoring) and the band of contenders
-    const float fs = t < a.N ? a.fast_scores[t] : -INFINITY;
+    // fp32 maximum (NaN-ignoring) and the band of contenders (fs: this thread's hypothesis' fp32 score, -inf beyond N -- loaded by the
+    // caller with the first trip to memory of the kernel)
     float m = fs;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -408,12 +408,11 @@ __device__ __forceinline__ int team_select(const KArgs& a, const TeamCells<CPL>&
 // hypothesis in reference arithmetic -- softMax / entropy over those scores (esac_util.h:461-497) and draw's argmax
 // (esac_util.h:512-529, first global index on ties), what k_stats_exact + refine_pick_winner do in a launch of their own.
 // Every member computes the same from the same scores; no exchange.
-__device__ __forceinline__ int team_select_exact(const KArgs& a, bool writer, double* s_part, double* s_tot, double* s_best, int* s_besti, int* s_bestg,
-                                                 double& win_score, int& nc_out, RecordInputs& rec_in) {
+__device__ __forceinline__ int team_select_exact(const KArgs& a, const double sc, bool writer, double* s_part, double* s_tot, double* s_best, int* s_besti,
+                                                 int* s_bestg, double& win_score, int& nc_out, RecordInputs& rec_in) {
     constexpr int B = REFINE_B;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const double sc = t < a.N ? a.scores[t] : -INFINITY;
-    double m = sc;  // fmax ignores NaN, as k_stats_exact
+    double m = sc;  // (sc: this thread's hypothesis' exact score, -inf beyond N)  fmax ignores NaN, as k_stats_exact
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if (lane == 0) s_best[wave] = m;
@@ -474,7 +473,8 @@ __device__ __forceinline__ int team_select_exact(const KArgs& a, bool writer, do
         }
     }
     const int win = bi == 0x7fffffff ? 0 : bi;
-    win_score = a.scores[win];
+    // the winner's score: the maximum found (no second trip to memory); with no score above -inf at all what hypothesis 0 holds
+    win_score = bi == 0x7fffffff ? a.scores[0] : bs;
     rec_in = RecordInputs{exp(win_score - m) / acc[0], entropy, a.status[0]};
     return win;
 }
@@ -605,6 +605,19 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         }
     };
     if (a.E == 1) load_cells(a.sc);
+    // the folded selection has one hypothesis per thread: its pose is fetched WITH its score, and the winner's thread hands it round
+    // through LDS -- a barrier instead of a second, dependent trip to memory between the argmax and the first pass
+    // (and so is its score: a workgroup barrier waits for the loads in flight, so whatever the selection loaded behind its first
+    // barrier was a trip of its own)
+    double my_hyp[6] = {0, 0, 0, 0, 0, 0};
+    double my_score = -INFINITY;
+    float my_fast = -INFINITY;
+    if (!SLOTS && a.fold_select && (int)threadIdx.x < a.N) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) my_hyp[k] = a.hyps[(size_t)threadIdx.x * 6 + k];
+        if (a.fold_select == 2) my_score = a.scores[threadIdx.x];
+        else                    my_fast = a.fast_scores[threadIdx.x];
+    }
     int nc = 0, win;
     double win_score = 0;
     RecordInputs rec_in{0.0, 0.0, 0ull};
@@ -614,13 +627,13 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
         __syncthreads();  // (s_pow10, s_coop_dead)
     } else if (a.fold_select == 2) {
         __syncthreads();  // (s_pow10, s_coop_dead)
-        win = team_select_exact(a, writer, s_part, s_tot, s_best, s_besti, s_bestg, win_score, nc, rec_in);
+        win = team_select_exact(a, my_score, writer, s_part, s_tot, s_best, s_besti, s_bestg, win_score, nc, rec_in);
     } else if (a.fold_select) {
         __syncthreads();  // (s_pow10, s_coop_dead)
         team_collect<1, WIDE>(census, co, s_tot, s_x);
         note_census(census[0]);
-        win = team_select<CPL, WIDE>(a, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_x, s_best, s_besti, s_bestg, s_list, s_rt, win_score, nc,
-                               rec_in);
+        win = team_select<CPL, WIDE>(a, my_fast, cl, a.E == 1, cell0, cell1, cam, co, writer, s_part, s_tot, s_x, s_best, s_besti, s_bestg, s_list, s_rt,
+                               win_score, nc, rec_in);
     } else {
         if (MODE == TEAM_SINGLE && a.spec_mode == 2) {
             // speculative, the selection running beside this kernel: the fp32 argmax of the settled hypotheses; score, probability,
@@ -637,8 +650,18 @@ __global__ __launch_bounds__(REFINE_B) void k_refine_team(KArgs a) {
     }
     const int e = expert_of(a, win);
     double pose[6];
+    if (!SLOTS && a.fold_select) {
+        if ((int)threadIdx.x == win) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
+            for (int k = 0; k < 6; k++) s_rt[k] = my_hyp[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; k++) pose[k] = s_rt[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) pose[k] = a.hyps[(size_t)win * 6 + k];
+    }
     if (a.E != 1) load_cells(a.sc + (size_t)e * 3 * P);
     if (SLOTS || a.fold_select != 1) {
         team_collect<1, WIDE>(census, co, s_tot, s_x);

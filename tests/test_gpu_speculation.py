@@ -193,3 +193,20 @@ def test_where_the_route_applies(engine):
     finally:
         engine.set_debug()
     assert last(3, 512)
+
+
+def test_streams_that_share_one_hardware_queue():
+    """The route's three streams hand over through polled words, and every waiter is enqueued behind the launch it waits for -- so
+    streams that the runtime maps onto ONE hardware queue (GPU_MAX_HW_QUEUES=1: everything serialises) cannot wait for each other:
+    the same comparisons in a process of that kind -- no time-out (status 5 would switch the speculation off and the
+    `last_speculative` assertions would fail), every output the serial route's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_speculation.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "equals_the_serial_route or straggler_that_wins or not_the_winner_of_the_settled or asynchronous"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]

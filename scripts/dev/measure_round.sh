@@ -14,6 +14,13 @@ last() { grep '^{' | tail -1; }
 declare -A ARGS=( [cfg2]="" [cfg3]="--steps 200 --warmup 20 --no-extras" [cfg4]="--steps 100 --warmup 10 --no-extras --no-exact"
                   [cfg5a]="--steps 30 --warmup 3 --no-extras" [cfg5b]="--steps 8 --warmup 2 --no-extras" )
 declare -A PARGS=( [cfg2]="" [cfg3]="--steps 100 --warmup 10" [cfg4]="--steps 60 --warmup 6" [cfg5a]="--steps 12 --warmup 2" [cfg5b]="--steps 4 --warmup 1" )
+# the rocprofv3 passes FIRST: the bench lines then embed the profiles of the tree they run on (profile_stale: false) -- bench.py reads
+# the newest profiles/r*_<cfg>_kernels.json, so the summaries are copied there on the box before the lines are taken
+if [ -z "$BENCH_ONLY" ]; then
+  for c in $CFGS; do bash scripts/dev/profile_cfg.sh $c $RND ${PARGS[$c]} > $P/log_$c.txt 2>&1; done
+  cp $P/${RND}_cfg*_kernels.json $P/${RND}_cfg*_kernels.txt profiles/ 2>/dev/null
+  rm -rf gpurun_out/prof_${RND}_*
+fi
 for c in $CFGS; do
   timeout 1200 python bench.py --config $c ${ARGS[$c]} 2> $P/err_$c.txt | last > $P/${RND}_bench_$c.json
 done
@@ -35,8 +42,4 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
-if [ -z "$BENCH_ONLY" ]; then
-  for c in $CFGS; do bash scripts/dev/profile_cfg.sh $c $RND ${PARGS[$c]} > $P/log_$c.txt 2>&1; done
-  cat $P/${RND}_cfg*_kernels.txt
-  rm -rf gpurun_out/prof_${RND}_*
-fi
+if [ -z "$BENCH_ONLY" ]; then cat $P/${RND}_cfg*_kernels.txt; fi

@@ -53,7 +53,7 @@ FLAG_EXACT_SCORES, FLAG_SCORE_TILED, FLAG_SCORE_STREAM, FLAG_PACK_MAPS, FLAG_EXA
 FLAG_AUTO_EXACT = 64
 FLAG_REFINE_SOLO = 128
 WAIT_SPIN, WAIT_YIELD, WAIT_BLOCK = 0, 1, 2
-DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL, DEBUG_TEAM_SPREAD, DEBUG_NO_SPECULATION, DEBUG_SPEC_SECOND_BEST = 1, 2, 4, 8, 16
+DEBUG_ERROR_IMAGE, DEBUG_COOP_STALL, DEBUG_TEAM_SPREAD, DEBUG_NO_SPECULATION, DEBUG_SPEC_SECOND_BEST, DEBUG_SPEC_LOSE_CHAIN = 1, 2, 4, 8, 16, 32
 
 
 class Params(C.Structure):
@@ -364,10 +364,11 @@ class Engine:
         """Waits for the device; raises if the most recent (asynchronous) call met an out-of-range hypAssignment."""
         _check(self.lib.esac_hip_check(self.ctx), self.lib)
 
-    def set_debug(self, keep_error_image=False, coop_stall=False, team_spread=False, no_speculation=False, spec_second_best=False):
+    def set_debug(self, keep_error_image=False, coop_stall=False, team_spread=False, no_speculation=False, spec_second_best=False,
+                  spec_lose_chain=False):
         _check(self.lib.esac_hip_set_debug(self.ctx, (DEBUG_ERROR_IMAGE if keep_error_image else 0) | (DEBUG_COOP_STALL if coop_stall else 0) |
                                            (DEBUG_TEAM_SPREAD if team_spread else 0) | (DEBUG_NO_SPECULATION if no_speculation else 0) |
-                                           (DEBUG_SPEC_SECOND_BEST if spec_second_best else 0)), self.lib)
+                                           (DEBUG_SPEC_SECOND_BEST if spec_second_best else 0) | (DEBUG_SPEC_LOSE_CHAIN if spec_lose_chain else 0)), self.lib)
 
     def spec_info(self):
         """The speculative forward route (several experts: the straggler chain beside the refinement; ESAC_BUF_SPEC_INFO)."""

@@ -270,9 +270,6 @@ __device__ __forceinline__ Centre map_centre(const KArgs& a, const float* __rest
 __device__ __forceinline__ void spec_word_set(const KArgs& a, int which) {
     __hip_atomic_store(a.spec_state + which, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ bool spec_word_is_set(const KArgs& a, int which) {
-    return __hip_atomic_load(a.spec_state + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.epoch;
-}
 // Every wait for such a word is bounded in wall time: a word that never comes (the other stream's launch failed, or something
 // else holds its queue) costs ESAC_SPEC_WAIT_TICKS and is reported (status 5: the host runs the call again in stream order) -- never a hang.
 constexpr long long ESAC_SPEC_WAIT_TICKS = 2000000;  // 20 ms of the 100 MHz wall clock

@@ -122,6 +122,7 @@ struct esac_hip_ctx {
     hipStream_t side2 = nullptr;          // ... and the selection among the settled hypotheses + the join on this one, beside the speculative refinement
     bool spec_off = false, spec_env_off = false;  // ESAC_DEBUG_NO_SPECULATION / ESAC_SPECULATE=0
     bool spec_second_best = false;        // ESAC_DEBUG_SPEC_SECOND_BEST
+    bool spec_lose_chain = false;         // ESAC_DEBUG_SPEC_LOSE_CHAIN
     long long spec_calls = 0;             // forward calls that took the speculative route
     double last_spec_epoch = 0;           // epoch of the most recent speculative call (0: the most recent forward was not)
     ncclComm_t comm = nullptr;  // esac_hip_comm_init: this context's rank in an RCCL communicator (the multi-GPU score exchange)
@@ -718,7 +719,7 @@ static int forward_impl(esac_hip_ctx* c, const float* d_sc, long long sc_frame_s
         if ((rc = check_launch("k_select_rescore (settled)"))) return rc;
         launch_spec_wait(a, 3, c->side);
         launch_sample_stragglers_on(chain, chain_waves, c->side);
-        launch_score_stragglers(a, c->side);  // behind the chain on the side stream; its last workgroup writes "the chain is done"
+        if (!c->spec_lose_chain) launch_score_stragglers(a, c->side);  // behind the chain on the side stream; its last workgroup writes "the chain is done"
         if ((rc = check_launch("straggler chain"))) return rc;
         launch_spec_join(a, c->side2);
         if ((rc = check_launch("k_spec_join"))) return rc;
@@ -1380,6 +1381,7 @@ extern "C" int esac_hip_set_debug(esac_hip_ctx* c, int flags) {
     c->team_spread = (flags & ESAC_DEBUG_TEAM_SPREAD) != 0;
     c->spec_off = c->spec_env_off || (flags & ESAC_DEBUG_NO_SPECULATION) != 0;
     c->spec_second_best = (flags & ESAC_DEBUG_SPEC_SECOND_BEST) != 0;
+    c->spec_lose_chain = (flags & ESAC_DEBUG_SPEC_LOSE_CHAIN) != 0;
     return 0;
 }
 

@@ -376,6 +376,11 @@ int esac_hip_set_timing(esac_hip_ctx* ctx, int enabled);
  * differently.  The join must find that the refined hypothesis is not the winner and the gated second refinement must deliver
  * the serial route's outputs. */
 #define ESAC_DEBUG_SPEC_SECOND_BEST 16
+/* ESAC_DEBUG_SPEC_LOSE_CHAIN (tests only): the last launch of the straggler chain's stream -- the one that reports "the chain is
+ * done" -- is left out, as if it had failed.  The join's wait is bounded (20 ms): it must report status 5, a blocking call must run
+ * again in stream order and return that route's outputs, and the context must stop speculating; an asynchronous call's device
+ * record carries ESAC_RES_VALID = 3 (esac_hip_pick_record: -12). */
+#define ESAC_DEBUG_SPEC_LOSE_CHAIN 32
 int esac_hip_set_debug(esac_hip_ctx* ctx, int flags);
 
 /* The winner's refinement (refineHyp, esac_util.h:378-454) on a single frame whose grid fits one workgroup's LDS list

@@ -210,3 +210,52 @@ def test_streams_that_share_one_hardware_queue():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
+def test_a_chain_that_never_reports_is_a_bounded_wait_and_a_serial_rerun(oracle):
+    """ESAC_DEBUG_SPEC_LOSE_CHAIN leaves out the launch that writes "the chain is done" (as if it had failed, or something else held
+    its queue).  Every wait of the route is bounded: the join gives up after 20 ms and reports status 5, the gated second refinement
+    (whose patience outlasts the join's) closes, the blocking call runs again in stream order and returns THAT route's outputs, and
+    the context stops speculating; an asynchronous call's device record says "not a record" (ESAC_RES_VALID = 3)."""
+    import time
+    eng = api.Engine(0)  # a context of its own: this test switches its speculation off for good
+    f = S.make_frame(1400, E=3)
+    ha = S.gating_assignment(f, 512, mode="gating")
+    serial = _run(eng, f, ha, call=9, nospec=True)
+    spec = _run(eng, f, ha, call=9, nospec=False)
+    assert spec["info"]["last_speculative"]
+    _assert_same(serial, spec, "the route itself, before the chain is lost")
+    # asynchronous: nobody reruns the call -- the record must not pass for one
+    eng.set_debug(spec_lose_chain=True)
+    try:
+        E, _, H, W = f["coords"].shape
+        sc, hat = torch.from_numpy(f["coords"]).cuda(), torch.from_numpy(ha).cuda()
+        p = eng.make_params(E, H, W, len(ha), focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=1305, call=9)
+        dev_rec = torch.full((32,), -7.0, dtype=torch.float64, device="cuda")
+        t0 = time.perf_counter()
+        eng.forward_device(sc, hat, p, result_out=dev_rec, want_host=False)
+        torch.cuda.synchronize()
+        dt_async = time.perf_counter() - t0
+        assert dev_rec.cpu().numpy()[31] == 3.0
+        assert 0.015 < dt_async < 0.5, dt_async  # the join's 20 ms, not a hang
+        # blocking: status 5 -> the same call again, in stream order
+        scores = torch.full((len(ha),), -7.0, dtype=torch.float64, device="cuda")
+        t0 = time.perf_counter()
+        rec = eng.forward_device(sc, hat, p, scores_out=scores)
+        dt = time.perf_counter() - t0
+        assert 0.015 < dt < 0.5, dt
+        np.testing.assert_array_equal(rec, serial["rec"])
+        np.testing.assert_array_equal(scores.cpu().numpy(), serial["user"])
+        for key, buf in (("hyps", api.BUF_HYPS), ("tries", api.BUF_TRIES), ("scores", api.BUF_SCORES), ("flags", api.BUF_EXACT_FLAGS),
+                         ("counts", api.BUF_INLIER_COUNTS), ("imap", api.BUF_INLIER_MAP)):
+            np.testing.assert_array_equal(eng.read(buf), serial[key], err_msg=key)
+        info = eng.spec_info()
+        assert not info["last_speculative"]  # (the rerun was the stream-order route)
+    finally:
+        eng.set_debug()
+    # ... and the context has stopped speculating: the next call is in stream order at once, and right
+    again = _run(eng, f, ha, call=9, nospec=False)
+    assert not again["info"]["last_speculative"]
+    _assert_same(serial, again, "after the context stopped speculating")
+    ref = oracle.forward(f["coords"], ha, focal=f["focal"], ppx=f["ppx"], ppy=f["ppy"], sub_sampling=f["sub"], seed=1305, call=9)
+    assert int(again["rec"][api.RES_HYP]) == ref["winner"]

@@ -219,7 +219,7 @@ OWN_BOUND = {
              "(where ESAC_FLAG_AUTO_EXACT applies -- cfg2 -- the stage is k_rescore: dependent fp64 chains, 16 wavefronts per hypothesis)",
     "select_rescore": "latency: one launch, a few fp64 re-scores",
     "refine": "a chain of ~25 dependent rounds, each bound by the instruction COUNT of one wavefront per SIMD (points + 24 moments, wavefront reduction, "
-              "the LM step dealt to the lanes of a DPP row) + one exchange between the 8 workgroups of the team (an L2 hop and two LDS round trips) "
+              "the LM step dealt to the lanes of a DPP row) + one exchange between the workgroups of the team (ten on the 60x80 grid) (an L2 hop and two LDS round trips) "
               "(single frames and batches of <= 32 on 60x80-sized grids); fp64 VALU issue of ONE CU elsewhere",
 }
 

@@ -178,6 +178,58 @@ int main(int argc, char** argv) {
         hipFree_(d_buf);
         printf("comm ok: one-rank RCCL communicator, all-reduce of 288 doubles in place\n");
     }
+    if (argc > 3 && strcmp(argv[3], "spec") == 0) {
+        /* several experts from plain C: the wall as expert 0, two maps of noise as experts 1 and 2, 512 hypotheses of which every
+         * third sits on a wrong expert.  By default the call takes the speculative route (streams of the context's own beside the
+         * caller's); with ESAC_DEBUG_NO_SPECULATION every launch runs in stream order: the two records and the two score vectors
+         * must be the same bits, and ESAC_BUF_SPEC_INFO must say which route ran. */
+        int (*p_esac_hip_set_debug)(esac_hip_ctx*, int);
+        RESOLVE(esac_hip_set_debug);
+        enum { E3 = 3, N3 = 512 };
+        float* sc3 = (float*)malloc(sizeof(float) * 3 * P * E3);
+        int64_t* as3 = (int64_t*)malloc(sizeof(int64_t) * N3);
+        unsigned lcg = 12345u;
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const float px = (float)(x * 8 + 4), py = (float)(y * 8 + 4);
+                sc3[0 * P + y * W + x] = (px - 320.0f) / 525.0f * 3.0f;
+                sc3[1 * P + y * W + x] = (py - 240.0f) / 525.0f * 3.0f;
+                sc3[2 * P + y * W + x] = 3.0f;
+            }
+        for (int i = 3 * P; i < 3 * P * E3; i++) {
+            lcg = lcg * 1664525u + 1013904223u;
+            sc3[i] = (float)(lcg >> 8) / 16777216.0f * 6.0f - 3.0f + ((i / P) % 3 == 2 ? 4.0f : 0.0f); /* x, y in [-3, 3), z in [1, 7) */
+        }
+        for (int i = 0; i < N3; i++) as3[i] = i % 3 == 2 ? 1 + (i / 3) % 2 : 0;
+        void *d_sc3 = NULL, *d_as3 = NULL, *d_scores = NULL;
+        if (hipMalloc_(&d_sc3, sizeof(float) * 3 * P * E3) || hipMalloc_(&d_as3, sizeof(int64_t) * N3) || hipMalloc_(&d_scores, sizeof(double) * N3)) return 30;
+        if (hipMemcpy_(d_sc3, sc3, sizeof(float) * 3 * P * E3, 1) || hipMemcpy_(d_as3, as3, sizeof(int64_t) * N3, 1)) return 31;
+        esac_hip_params q = p;
+        q.E = E3; q.N = N3; q.call = 77;
+        double rec[2][ESAC_RES_DOUBLES];
+        static double scores[2][N3];
+        int32_t info[2][4];
+        for (int route = 0; route < 2; route++) { /* 0: default (speculative), 1: stream order */
+            if (p_esac_hip_set_debug(ctx, route ? ESAC_DEBUG_NO_SPECULATION : 0) != 0) return 32;
+            if (p_esac_hip_forward(ctx, (const float*)d_sc3, (const int64_t*)d_as3, &q, NULL, (double*)d_scores, NULL, rec[route]) != 0) {
+                fprintf(stderr, "forward (several experts, route %d): %s\n", route, p_esac_hip_last_error());
+                return 33;
+            }
+            if (p_esac_hip_read(ctx, ESAC_BUF_SPEC_INFO, info[route], sizeof(info[route])) != 0) return 34;
+            if (hipMemcpy_(scores[route], d_scores, sizeof(double) * N3, 2)) return 35;
+        }
+        p_esac_hip_set_debug(ctx, 0);
+        if (!(info[0][2] == 1 && info[1][2] == 0)) {
+            fprintf(stderr, "routes: speculative %d, stream order %d\n", info[0][2], info[1][2]);
+            return 36;
+        }
+        if (memcmp(rec[0], rec[1], sizeof(double) * 31) != 0 || memcmp(scores[0], scores[1], sizeof(scores[0])) != 0) return 37;
+        if ((int)rec[0][ESAC_RES_EXPERT] != 0) return 38; /* the winner sits on the wall */
+        printf("spec ok: 3 experts x 512 hypotheses, speculative route == stream order bit for bit (winner %d on expert %d, %d inliers)\n",
+               (int)rec[0][ESAC_RES_HYP], (int)rec[0][ESAC_RES_EXPERT], (int)rec[0][ESAC_RES_INLIERS]);
+        hipFree_(d_sc3); hipFree_(d_as3); hipFree_(d_scores);
+        free(sc3); free(as3);
+    }
     hipFree_(d_grad); hipFree_(d_sc); hipFree_(d_assign);
     free(sc);
     p_esac_hip_destroy(ctx);

@@ -187,3 +187,15 @@ def test_c_program_runs_forward_and_backward_without_torch():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "forward ok" in out.stdout and "backward ok" in out.stdout
 
+
+
+@pytest.mark.gpu
+def test_c_program_runs_the_several_expert_route_without_torch():
+    """Several experts from the plain C caller: the default call takes the speculative route (the library's own streams beside the
+    caller's NULL stream), ESAC_DEBUG_NO_SPECULATION the stream order -- the same record and the same score vector, bit for bit."""
+    import subprocess
+    from tests.native import build as nb
+    exe = nb.build_abi_check()
+    out = subprocess.run([exe, build.LIB_PATH, "gpu", "spec"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "spec ok" in out.stdout

@@ -1686,8 +1686,12 @@ constexpr int ESAC_CHAIN_PER_HYP = 8;
         // hypotheses: four ~12 us rounds back to back, 51 us measured): two wavefronts per hypothesis, four lanes per try
         // (32 tries per round -- 93 % of the hypotheses of a usable map are settled in it) put two hypotheses on a CU at a
         // time.
-        if (total <= 256) hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, a.frames), dim3(256), 0, s, b);
-        else              hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, a.frames), dim3(128), 0, s, b);
+        // 513 .. 1024 hypotheses (round 6): ONE wavefront per hypothesis, two lanes per try -- the same 32 tries in one round, a
+        // chain of two candidates instead of one, and all 1024 wavefronts resident at once instead of 2048 in two waves of
+        // workgroups: 29.9 -> 25.4 us at config 3 (four lanes per try at one wavefront, two rounds of 16 tries: 29.9 again)
+        if (total <= 256)      hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, a.frames), dim3(256), 0, s, b);
+        else if (total <= 512) hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, a.frames), dim3(128), 0, s, b);
+        else                   hipLaunchKernelGGL((k_sample<64, 2>), dim3(a.N, a.frames), dim3(64), 0, s, b);
     } else if (total <= 4096 && !handover) {
         hipLaunchKernelGGL((k_sample<128, 1>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
@@ -1744,8 +1748,9 @@ int launch_sample_split(const KArgs& a, hipStream_t s, KArgs* chain, int* chain_
     *chain_waves = (int)(w8 < ESAC_CHAIN_WAVES ? ESAC_CHAIN_WAVES : (w8 > 131072 ? 131072 : w8));
     if (total <= ESAC_SPLIT_LATENCY_MAX) {
         b.handover = ESAC_SPLIT_HANDOVER;
-        if (total <= 256) hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, 1), dim3(256), 0, s, b);
-        else              hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, 1), dim3(128), 0, s, b);
+        if (total <= 256)      hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, 1), dim3(256), 0, s, b);
+        else if (total <= 512) hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, 1), dim3(128), 0, s, b);
+        else                   hipLaunchKernelGGL((k_sample<64, 2>), dim3(a.N, 1), dim3(64), 0, s, b);
         b.first_try = b.handover;
     } else {
         hipLaunchKernelGGL(k_sample_first<32>, dim3((a.N + 1) / 2, 1), dim3(64), 0, s, b);

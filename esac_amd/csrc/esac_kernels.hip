@@ -1686,12 +1686,15 @@ constexpr int ESAC_CHAIN_PER_HYP = 8;
         // hypotheses: four ~12 us rounds back to back, 51 us measured): two wavefronts per hypothesis, four lanes per try
         // (32 tries per round -- 93 % of the hypotheses of a usable map are settled in it) put two hypotheses on a CU at a
         // time.
-        // 513 .. 1024 hypotheses (round 6): ONE wavefront per hypothesis, two lanes per try -- the same 32 tries in one round, a
-        // chain of two candidates instead of one, and all 1024 wavefronts resident at once instead of 2048 in two waves of
-        // workgroups: 29.9 -> 25.4 us at config 3 (four lanes per try at one wavefront, two rounds of 16 tries: 29.9 again)
-        if (total <= 256)      hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, a.frames), dim3(256), 0, s, b);
-        else if (total <= 512) hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, a.frames), dim3(128), 0, s, b);
-        else                   hipLaunchKernelGGL((k_sample<64, 2>), dim3(a.N, a.frames), dim3(64), 0, s, b);
+        // 513 .. 1024 hypotheses that hand their stragglers over (round 6): ONE wavefront per hypothesis, two lanes per try -- the
+        // same 32 tries in one round, a chain of two candidates instead of one, and all 1024 wavefronts resident at once instead of
+        // 2048 in two waves of workgroups: 29.9 -> 25.4 us at config 3 (four lanes per try at one wavefront, two rounds of 16
+        // tries: 29.9 again).  Without a hand-over (one expert, ESAC_FLAG_EXACT_SAMPLING) a straggler walks its whole budget in this
+        // kernel, one try per lane: two wavefronts per hypothesis halve that tail (config 3 on the guaranteed routes: 0.56 ms
+        // against 0.89 with one)
+        if (total <= 256)                    hipLaunchKernelGGL((k_sample<256, 2>), dim3(a.N, a.frames), dim3(256), 0, s, b);
+        else if (total <= 512 || !handover)  hipLaunchKernelGGL((k_sample<128, 4>), dim3(a.N, a.frames), dim3(128), 0, s, b);
+        else                                 hipLaunchKernelGGL((k_sample<64, 2>), dim3(a.N, a.frames), dim3(64), 0, s, b);
     } else if (total <= 4096 && !handover) {
         hipLaunchKernelGGL((k_sample<128, 1>), dim3(a.N, a.frames), dim3(128), 0, s, b);
     } else {  // throughput: passes of 16 tries with four hypotheses per wavefront, then the unaccepted rest by the screened chain
